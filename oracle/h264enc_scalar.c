@@ -1,0 +1,109 @@
+/*
+ * oracle/h264enc_scalar.c -- the scalar C macroblock loop behind the
+ * reference's command line (BASELINE.json configs[0]: plumbing, no GPU, no
+ * /dev/cedar). TEST INFRASTRUCTURE: it is the CPU twin of the product CLI
+ * (cedarx_h264_encoder_amd/csrc/h264enc_cli.c) and is never shipped as a
+ * fallback of it.
+ *
+ * Usage and behaviour follow userspace/h264enc.c:134-201:
+ *   h264enc_scalar <infile|-> <width> <height> <outfile>
+ * reads width*height luma bytes then width*height/2 chroma bytes per frame,
+ * stops at the first short read, exit codes as the reference (-1 on usage or
+ * open errors, 0 at EOF). Extra knobs come from the environment so the four
+ * positional arguments stay: H264ENC_QP, H264ENC_KEYINT, H264ENC_SLICES,
+ * H264ENC_SEARCH.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "h264o.h"
+
+static int read_frame(int fd, uint8_t *buffer, int size) /* h264enc.c:119-132 */
+{
+	int total = 0;
+
+	while (total < size) {
+		ssize_t len = read(fd, buffer + total, (size_t)(size - total));
+
+		if (len <= 0)
+			return -1;
+		total += (int)len;
+	}
+	return total;
+}
+
+static int env_int(const char *name, int dflt)
+{
+	const char *v = getenv(name);
+
+	return v && *v ? atoi(v) : dflt;
+}
+
+int main(int argc, char **argv)
+{
+	h264o_config cfg;
+	h264o_enc *enc;
+	uint8_t *luma, *chroma, *out;
+	int width, height, fd_in, fd_out, err, cap, frame_count = 0;
+
+	if (argc != 5) {
+		printf("Usage: %s <infile> <width> <height> <outfile>\n", argv[0]);
+		return -1;
+	}
+	width = atoi(argv[2]);
+	height = atoi(argv[3]);
+	if (strcmp(argv[1], "-")) {
+		fd_in = open(argv[1], O_RDONLY | O_LARGEFILE);
+		if (fd_in == -1) {
+			fprintf(stderr, "%s(): Failed to open input file %s: %s\n", __func__, argv[1], strerror(errno));
+			return -1;
+		}
+	} else {
+		fd_in = 0;
+	}
+	fd_out = open(argv[4], O_CREAT | O_RDWR | O_TRUNC, 0644);
+	if (fd_out == -1) {
+		fprintf(stderr, "%s(): Failed to open output file %s\n", __func__, argv[4]);
+		return -1;
+	}
+	h264o_default_config(&cfg, width, height);
+	cfg.qp = env_int("H264ENC_QP", cfg.qp);
+	cfg.keyint = env_int("H264ENC_KEYINT", cfg.keyint);
+	cfg.slice_count = env_int("H264ENC_SLICES", cfg.slice_count);
+	cfg.search_range = env_int("H264ENC_SEARCH", cfg.search_range);
+	enc = h264o_open(&cfg, &err);
+	if (!enc) {
+		fprintf(stderr, "%s(): config failed: %s\n", __func__, strerror(-err));
+		return err;
+	}
+	cap = h264o_max_frame_bytes(enc);
+	luma = malloc((size_t)width * height);
+	chroma = malloc((size_t)width * height / 2);
+	out = malloc((size_t)cap);
+	if (!luma || !chroma || !out)
+		return -ENOMEM;
+	while (1) {
+		int ret;
+
+		if (read_frame(fd_in, luma, width * height) != width * height)
+			break;
+		if (read_frame(fd_in, chroma, width * height / 2) != width * height / 2)
+			break;
+		ret = h264o_encode(enc, luma, chroma, out, cap);
+		if (ret < 0) {
+			fprintf(stderr, "%s(): %d: encode failed: %s\n", __func__, frame_count, strerror(-ret));
+		} else {
+			printf("\rFrame %5d: %5dbytes", frame_count, ret);
+			if (write(fd_out, out, (size_t)ret) != ret)
+				fprintf(stderr, "%s(): short write\n", __func__);
+			frame_count++;
+		}
+	}
+	h264o_close(enc);
+	return 0;
+}
