@@ -1,0 +1,126 @@
+"""Oracle vs the reference-derived known-answer vectors.
+
+These are the only results the reference pins for this path: the bytes its
+header writer (kernel/cedar.c:187-223, :868-1030) produces.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "headers.json")))
+
+
+def _hex(s):
+    return bytes(int(x, 16) for x in s.split())
+
+
+def _sps(c):
+    buf = np.zeros(64, np.uint8)
+    n = ol.lib().h264o_write_sps(ctypes.byref(c), buf.ctypes.data, 64)
+    return buf[:n].tobytes()
+
+
+def _pps(c):
+    buf = np.zeros(64, np.uint8)
+    n = ol.lib().h264o_write_pps(ctypes.byref(c), buf.ctypes.data, 64)
+    return buf[:n].tobytes()
+
+
+@pytest.mark.parametrize("v", G["sps"], ids=lambda v: v["name"])
+def test_sps_known_answers(v):
+    c = ol.default_config(v["width"], v["height"], profile_idc=v["profile"], level_idc=v["level"])
+    assert _sps(c) == _hex(v["hex"])
+
+
+@pytest.mark.parametrize("v", G["sps_reference_quirk"], ids=lambda v: v["name"])
+def test_sps_reference_trailing_quirk_is_the_only_difference(v):
+    c = ol.default_config(v["width"], v["height"], profile_idc=v["profile"], level_idc=v["level"])
+    got = _sps(c)
+    assert got == _hex(v["standard_hex"])
+    assert _hex(v["hex"]) == got + b"\x00"  # cedar.c:883-890 stray byte, documented divergence
+
+
+@pytest.mark.parametrize("v", G["pps"], ids=lambda v: v["name"])
+def test_pps_known_answers(v):
+    c = ol.default_config(320, 240, qp=v["qp"])
+    assert _pps(c) == _hex(v["hex"])
+
+
+def test_pps_differs_from_reference_literal_only_in_entropy_flag():
+    v = G["pps_reference_literal"][0]
+    got = bytearray(_pps(ol.default_config(320, 240, qp=v["qp"])))
+    ref = _hex(v["hex"])
+    assert len(got) == len(ref)
+    diff = [i for i in range(len(ref)) if got[i] != ref[i]]
+    assert diff == [5] and got[5] ^ ref[5] == 0x20  # entropy_coding_mode_flag bit
+
+
+@pytest.mark.parametrize("v", G["slice_header"], ids=lambda v: v["name"])
+def test_slice_header_known_answers(v):
+    c = ol.default_config(320, 240)
+    buf = np.zeros(64, np.uint8)
+    nbits = ctypes.c_int()
+    n = ol.lib().h264o_write_slice_header(ctypes.byref(c), v["idr"], v["frame_num"], v["idr_pic_id"], 0,
+                                          buf.ctypes.data, 64, ctypes.byref(nbits))
+    got = buf[:n].tobytes()
+    want = _hex(v["hex"])
+    assert nbits.value == v["nbits"]
+    assert got[:len(want)] == want
+    if "tail_bits" in v:
+        tail = format(got[len(want)], "08b")[:len(v["tail_bits"])]
+        assert tail == v["tail_bits"]
+
+
+@pytest.mark.parametrize("v", G["cavlc_block"], ids=lambda v: v["name"])
+def test_cavlc_block_known_answer(v):
+    lv = np.array(v["levels_zigzag"], np.int16)
+    out = np.zeros(64, np.uint8)
+    n = ol.lib().h264o_cavlc_block(lv.ctypes.data, v["max_coeff"], v["nC"], out.ctypes.data, 64)
+    bits = "".join(format(b, "08b") for b in out)[:n]
+    assert bits == v["bits"]
+
+
+def test_transform_known_answers():
+    """constant block -> only W[0][0] = 16c; DC-only d -> (d+32)>>6 everywhere."""
+    for cst in (1, -3, 100):
+        x = np.full(16, cst, np.int16)
+        w = np.zeros(16, np.int16)
+        ol.lib().h264o_fdct4x4(x.ctypes.data, w.ctypes.data)
+        assert w[0] == 16 * cst and not w[1:].any()
+    for d in (64, 640, -640, 100):
+        coef = np.zeros(16, np.int16)
+        coef[0] = d
+        dst = np.full(16, 128, np.uint8)
+        ol.lib().h264o_idct4x4_add(coef.ctypes.data, dst.ctypes.data, 4)
+        assert (dst == np.clip(128 + ((d + 32) >> 6), 0, 255)).all()
+
+
+def test_config_validation_follows_reference_rules():
+    """kernel/cedar.c:749-789: odd sizes, QP outside 1..47, keyint outside 1..31 -> EINVAL."""
+    import errno
+    for kw in ({"width": 321}, {"height": 241}, {"qp": 0}, {"qp": 48}, {"keyint": 0}, {"keyint": 32}):
+        base = dict(width=320, height=240)
+        base.update({k: v for k, v in kw.items() if k in ("width", "height")})
+        c = ol.default_config(base["width"], base["height"], **{k: v for k, v in kw.items() if k not in base})
+        with pytest.raises(OSError) as e:
+            ol.OracleEncoder(c)
+        assert e.value.errno == errno.EINVAL
+
+
+def test_gop_cadence_and_frame_num():
+    """cedar.c:1047-1050, :1193-1196: I P..P repeating; SPS/PPS only before frame 0."""
+    c = ol.default_config(32, 32, keyint=3, qp=30)
+    e = ol.OracleEncoder(c)
+    y, uv = ol.gen_frame("A", 32, 32, 0)
+    types = []
+    for f in range(7):
+        au = e.encode(y, uv)
+        nal_types = [au[i + 4] & 0x1f for i in range(len(au) - 4) if au[i:i + 4] == b"\0\0\0\1"]
+        types.append(nal_types)
+    assert types[0] == [7, 8, 5]
+    assert types[1:] == [[1], [1], [5], [1], [1], [5]]

@@ -1,0 +1,85 @@
+"""Closed-loop conformance of the oracle: decode(stream) == in-loop recon.
+
+The container has no H.264 decoder, so the stream is decoded
+by the independently written test decoder (oracle/h264o_dec.c) and compared
+sample for sample with the encoder's deblocked reconstruction.
+"""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+CASES = [
+    # (w, h, qp, keyint, frames, pattern, slices)
+    (64, 48, 30, 1, 3, "A", 1),
+    (64, 48, 30, 1, 3, "B", 1),
+    (64, 48, 24, 1, 2, "C", 1),
+    (320, 240, 30, 1, 3, "B", 1),   # BASELINE configs[0] shape (I only)
+    (64, 48, 30, 25, 6, "A", 1),
+    (64, 48, 30, 25, 6, "B", 1),
+    (320, 240, 30, 25, 5, "B", 1),
+    (64, 48, 24, 25, 4, "C", 1),
+    (70, 50, 24, 25, 4, "B", 1),    # not a multiple of 16: padding + cropping
+    (320, 240, 24, 25, 4, "B", 4),  # config[3] structure: 4 slices, idc 2
+    (48, 80, 24, 4, 6, "B", 5),     # ragged slice split 1/1/1/1/1
+    (64, 48, 5, 3, 4, "C", 1),      # very low QP: big levels, escape codes
+    (64, 48, 47, 3, 4, "B", 1),     # maximum QP the reference accepts
+    (16, 16, 24, 2, 4, "C", 1),     # one macroblock
+    (432, 32, 24, 2, 3, "B", 1),    # wide and flat
+]
+
+
+@pytest.mark.parametrize("w,h,qp,keyint,frames,pattern,slices", CASES)
+def test_decode_equals_recon(w, h, qp, keyint, frames, pattern, slices):
+    cfg = ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices)
+    enc, dec = ol.OracleEncoder(cfg), ol.OracleDecoder()
+    for f in range(frames):
+        y, uv = ol.gen_frame(pattern, w, h, f)
+        au = enc.encode(y, uv)
+        assert dec.decode(au) == 1
+        ry, ruv = enc.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(ry, dy), "luma mismatch frame %d" % f
+        assert np.array_equal(ruv, duv), "chroma mismatch frame %d" % f
+        assert dec.crop_size() == (w, h)
+        # the reconstruction must resemble the source
+        src = y.reshape(h, w).astype(np.float64)
+        mse = ((src - ry[:h, :w]) ** 2).mean()
+        assert mse < (400 if qp <= 30 else 3000)
+
+
+def test_static_scene_is_all_skip():
+    """pattern A is static: every P picture collapses to one mb_skip_run."""
+    cfg = ol.default_config(320, 240, qp=30, keyint=25)
+    enc = ol.OracleEncoder(cfg)
+    y, uv = ol.gen_frame("A", 320, 240, 0)
+    enc.encode(y, uv)
+    au = enc.encode(y, uv)
+    assert len(au) < 16
+    assert all(m.type == ol.MB_PSKIP for m in enc.mbs())
+
+
+def test_global_motion_is_found():
+    """pattern B moves by (3,2) px/frame: content at x in frame f-1 sits at x-3
+    in frame f, so the best match for a block is at (+3,+2) in the reference."""
+    cfg = ol.default_config(320, 240, qp=24, keyint=25)
+    enc = ol.OracleEncoder(cfg)
+    for f in range(2):
+        enc.encode(*ol.gen_frame("B", 320, 240, f))
+    mb = enc.mb_array()
+    inner = mb.reshape(15, 20)[2:-2, 2:-2]
+    frac = ((inner["mvx"] == 3) & (inner["mvy"] == 2)).mean()
+    assert frac > 0.8
+
+
+def test_no_start_code_emulation_in_payload():
+    cfg = ol.default_config(64, 48, qp=5, keyint=1)
+    enc = ol.OracleEncoder(cfg)
+    au = enc.encode(*ol.gen_frame("A", 64, 48, 0))
+    # inside any NAL payload no 00 00 00/01/02 may appear
+    starts = [i for i in range(len(au) - 3) if au[i:i + 4] == b"\0\0\0\1"]
+    for k, s in enumerate(starts):
+        e = starts[k + 1] if k + 1 < len(starts) else len(au)
+        payload = au[s + 4:e]
+        for i in range(len(payload) - 2):
+            assert not (payload[i] == 0 and payload[i + 1] == 0 and payload[i + 2] < 3)
