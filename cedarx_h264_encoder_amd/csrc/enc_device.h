@@ -1,0 +1,173 @@
+// cedarx_h264_encoder_amd/csrc/enc_device.h
+// Device-side building blocks shared by the gfx950 kernels: 4x4 integer
+// transform pair, quantiser, wave reductions, intra predictors.
+// Everything is integer arithmetic (H.264 clause 8.5); results must equal the
+// scalar oracle bit for bit, which tests/ check through the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "enc_internal.h"
+
+namespace cedar {
+
+#define DEVI __device__ __forceinline__
+
+constexpr int LEVEL_MAX = 2047; // keeps every level inside the baseline CAVLC escape range
+
+// zig-zag scan index -> raster index, and position class of a raster index
+__device__ constexpr uint8_t kZigzag[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
+__device__ constexpr uint8_t kPosClass[16] = { 0, 2, 0, 2, 2, 1, 2, 1, 0, 2, 0, 2, 2, 1, 2, 1 };
+// coding-order 4x4 block index -> position in 4x4-block units
+__device__ constexpr uint8_t kBlkX[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
+__device__ constexpr uint8_t kBlkY[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
+
+DEVI int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+DEVI int iabs(int v) { return v < 0 ? -v : v; }
+DEVI int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+DEVI uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+		v = o < v ? o : v;
+	}
+	return v;
+}
+
+DEVI int wave_sum_i32(int v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+// forward core transform, raster in / raster out (clause 8.5 encoder twin)
+DEVI void fdct4x4(const int r[16], int w[16])
+{
+	int t[16];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int a = r[4 * i] + r[4 * i + 3], b = r[4 * i + 1] + r[4 * i + 2];
+		int c = r[4 * i + 1] - r[4 * i + 2], d = r[4 * i] - r[4 * i + 3];
+		t[4 * i] = a + b;
+		t[4 * i + 1] = 2 * d + c;
+		t[4 * i + 2] = a - b;
+		t[4 * i + 3] = d - 2 * c;
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int a = t[i] + t[12 + i], b = t[4 + i] + t[8 + i];
+		int c = t[4 + i] - t[8 + i], d = t[i] - t[12 + i];
+		w[i] = a + b;
+		w[4 + i] = 2 * d + c;
+		w[8 + i] = a - b;
+		w[12 + i] = d - 2 * c;
+	}
+}
+
+// inverse core transform of scaled coefficients (rows first, then columns:
+// clause 8.5.12.2), result (x+32)>>6 added to pred with clipping
+DEVI void idct4x4_add(const int d[16], const int pred[16], int out[16])
+{
+	int t[16];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int e0 = d[4 * i] + d[4 * i + 2], e1 = d[4 * i] - d[4 * i + 2];
+		int e2 = (d[4 * i + 1] >> 1) - d[4 * i + 3], e3 = d[4 * i + 1] + (d[4 * i + 3] >> 1);
+		t[4 * i] = e0 + e3;
+		t[4 * i + 1] = e1 + e2;
+		t[4 * i + 2] = e1 - e2;
+		t[4 * i + 3] = e0 - e3;
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		int e0 = t[i] + t[8 + i], e1 = t[i] - t[8 + i];
+		int e2 = (t[4 + i] >> 1) - t[12 + i], e3 = t[4 + i] + (t[12 + i] >> 1);
+		out[i] = clip255(pred[i] + ((e0 + e3 + 32) >> 6));
+		out[4 + i] = clip255(pred[4 + i] + ((e1 + e2 + 32) >> 6));
+		out[8 + i] = clip255(pred[8 + i] + ((e1 - e2 + 32) >> 6));
+		out[12 + i] = clip255(pred[12 + i] + ((e0 - e3 + 32) >> 6));
+	}
+}
+
+DEVI int quant1(int w, int mf, int f, int qbits)
+{
+	uint32_t a = (uint32_t)iabs(w);
+	int l = (int)((a * (uint32_t)mf + (uint32_t)f) >> qbits);
+	l = l > LEVEL_MAX ? LEVEL_MAX : l;
+	return w < 0 ? -l : l;
+}
+
+// Quantise w[] (raster) into lv[] (zig-zag) from scan position `first`, build the
+// scaled coefficients d[] (raster; d[0] left alone when first == 1), count levels.
+DEVI int quant_dequant(const int w[16], int first, const int32_t mf[3], const int32_t dv[3],
+		       int f, int qbits, int qshift, int lv[16], int d[16])
+{
+	int n = 0;
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		if (i < first) {
+			lv[i] = 0;
+			continue;
+		}
+		const int r = kZigzag[i], c = kPosClass[r];
+		int l = quant1(w[r], mf[c], f, qbits);
+		lv[i] = l;
+		n += l != 0;
+		d[r] = (l * dv[c]) << qshift;
+	}
+	return n;
+}
+
+// ---- intra 4x4 prediction from the 15-entry edge array ----
+// E[0]=E[1]=l3, E[2]=l2, E[3]=l1, E[4]=l0, E[5]=tl, E[6..13]=t0..t7, E[14]=t7
+// tab entry = kind<<4 | k (built on the host by build_pred4_table)
+DEVI int pred4_px(int ent, const uint8_t *E, int dc)
+{
+	int kind = ent >> 4, k = ent & 15;
+	int a = E[k > 0 ? k - 1 : 0], b = E[k], c = E[k + 1 < 15 ? k + 1 : 14];
+	int v = b;
+	v = kind == 1 ? (b + c + 1) >> 1 : v;
+	v = kind == 2 ? (a + 2 * b + c + 2) >> 2 : v;
+	v = kind == 3 ? dc : v;
+	return v;
+}
+
+DEVI bool mode4_allowed(int mode, bool has_top, bool has_left)
+{
+	switch (mode) {
+	case 0: case 3: case 7: return has_top;
+	case 1: case 8: return has_left;
+	case 2: return true;
+	default: return has_top && has_left;
+	}
+}
+
+// availability of the neighbours of the 4x4 block with coding index idx
+// (top-right by the decoding-order rule, clause 6.4.11.4)
+DEVI void blk4_avail(int idx, bool top_mb, bool left_mb, bool tr_mb, bool &ht, bool &hl, bool &htr)
+{
+	const int bx = kBlkX[idx], by = kBlkY[idx];
+	// internal top-right availability bitmask over coding index: 2,6,8,9,10,12,14
+	const uint32_t tri = (1u << 2) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12) | (1u << 14);
+	ht = by > 0 || top_mb;
+	hl = bx > 0 || left_mb;
+	htr = by == 0 ? (bx < 3 ? top_mb : tr_mb) : ((tri >> idx) & 1);
+}
+
+DEVI int mv_bits(int d)
+{
+	int a = iabs(d);
+	return a == 0 ? 1 : 2 * (31 - __clz(8 * a)) + 1;
+}
+
+DEVI int median3(int a, int b, int c)
+{
+	int mn = a < b ? a : b, mx = a < b ? b : a;
+	return c < mn ? mn : (c > mx ? mx : c);
+}
+
+} // namespace cedar

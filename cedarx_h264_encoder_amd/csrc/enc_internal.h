@@ -1,0 +1,143 @@
+// cedarx_h264_encoder_amd/csrc/enc_internal.h
+// Shared between the host session code (enc_session.cpp) and the gfx950
+// kernels (enc_kernels.hip). Not part of the C-ABI (include/cedar_h264enc.h).
+#pragma once
+
+#include <stdint.h>
+
+namespace cedar {
+
+enum : int { MB_I4x4 = 0, MB_I16x16 = 1, MB_P16x16 = 2, MB_PSKIP = 3 };
+
+// Per-macroblock decision record (8 bytes). Written by the analysis kernels,
+// read by deblock and entropy. Plays the role of the VE's MBINFO / MVBUF
+// side buffers (kernel/cedar.c:640, :650-651; cedar_regs.h:57,73).
+struct MbInfo {
+	int8_t type;         // MB_*
+	int8_t i16_mode;     // 0 V 1 H 2 DC 3 Plane
+	int8_t chroma_mode;  // 0 DC 1 H 2 V 3 Plane
+	int8_t cbp;          // bits 0-3 luma 8x8, bits 4-5 chroma
+	int16_t mvx, mvy;    // full-pel
+};
+
+// Quantised levels of one macroblock, int16, zig-zag order inside a block:
+//   [0,256)   luma[16][16]   block index = coding order
+//   [256,272) Intra16x16 DC
+//   [272,280) chroma DC [2][4]
+//   [280,408) chroma AC [2][4][16] (entry 0 of each block unused)
+constexpr int COEF_LUMA = 0;
+constexpr int COEF_DC16 = 256;
+constexpr int COEF_CDC = 272;
+constexpr int COEF_CAC = 280;
+constexpr int COEF_PER_MB = 408;  // 816 bytes = 51 x 16 B
+
+constexpr int NNZ_PER_MB = 24;    // 16 luma (raster bx+4*by), 4 Cb, 4 Cr
+constexpr int SLOT_BYTES = 2048;  // private CAVLC bit buffer of one macroblock
+constexpr int SLOT_WORDS = SLOT_BYTES / 4;
+constexpr int ESC_CHUNK = 256;    // bytes of RBSP per emulation-prevention thread
+constexpr int MAX_UNITS = 1024;   // streams x slices per session
+constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
+
+// What one picture-slice header contributes in front of the macroblock data.
+struct SliceHdr {
+	uint64_t bits;   // right-aligned header bits (<= 64)
+	int32_t nbits;
+	int32_t pad;
+};
+
+// Everything a kernel needs, passed by value. Per-stream arrays are one
+// allocation each with a fixed stride; stream s lives at base + s*stride.
+struct Params {
+	// geometry
+	int32_t width, height;      // source
+	int32_t cw, ch;             // coded (multiples of 16)
+	int32_t mb_w, mb_h, n_mb;
+	int32_t n_streams;
+	int32_t slice_count;        // slices per picture
+	int32_t slice_first, slice_num; // slices this session encodes
+	int32_t row_first, row_num; // MB rows covered by those slices
+	// policy
+	int32_t qp, qpc, search_range, lambda;
+	int32_t is_idr;
+	// quantiser, luma (index = position class 0 even/even, 1 odd/odd, 2 mixed)
+	int32_t mf[3], dv[3], qbits, qshift;
+	int32_t mfc[3], dvc[3], qbits_c, qshift_c;
+	// deblocking thresholds at qp / qpc
+	int32_t alpha_y, beta_y, tc0_y[3];
+	int32_t alpha_c, beta_c, tc0_c[3];
+	// device pointers
+	const uint8_t *const *in_luma;   // [n_streams] tightly packed width x height
+	const uint8_t *const *in_chroma; // [n_streams]
+	uint8_t *src_y, *src_uv;         // padded source planes
+	uint8_t *rec_y, *rec_uv;         // reconstruction being written
+	const uint8_t *ref_y, *ref_uv;   // previous reconstruction (deblocked)
+	MbInfo *mbi;
+	int8_t *i4modes;                 // [n_mb][16]
+	uint8_t *nnz;                    // [n_mb][24]
+	int16_t *coef;                   // [n_mb][COEF_PER_MB]
+	uint32_t *slot;                  // [n_mb][SLOT_WORDS]
+	uint32_t *mb_bits;               // [n_mb]
+	uint8_t *skip;                   // [n_mb]
+	int32_t *mvd;                    // [n_mb][2] quarter-pel differences
+	// per-unit entropy state (unit = stream*slice_num + local slice)
+	uint32_t *bit_off;               // [n_units][unit_mb_cap + 2]
+	uint32_t *run_before;            // same shape
+	uint32_t *unit_bits;             // [n_units] total RBSP bits
+	uint8_t *rbsp;                   // [n_units][rbsp_cap]
+	uint32_t *esc_cnt;               // [n_units][esc_chunks_cap]
+	uint32_t *nal_off;               // [n_units] byte offset of the NAL in out
+	uint32_t *nal_size;              // [n_units]
+	uint32_t *stream_size;           // [n_streams + 2] bytes per stream; [n] total; [n+1] error flags
+	uint8_t *out;                    // compact output: all streams back to back
+	const SliceHdr *hdr;             // [n_units] (identical across streams per slice)
+	const uint32_t *prefix_len;      // [n_streams] bytes reserved in front (SPS+PPS)
+	const uint8_t *pred4_tab;        // [9][16] intra 4x4 predictor table
+	// strides (elements of the respective type)
+	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
+	int32_t unit_mb_cap;             // max macroblocks of one unit
+	int32_t rbsp_cap;                // bytes per unit
+	int32_t esc_chunks_cap;          // per unit
+	int32_t out_cap;                 // bytes total
+	int32_t nal_ref_idc, nal_type;
+};
+
+// slice s of n covers MB rows [r0, r1): the first (mb_h % n) slices get one
+// extra row (3840x2160 in 4 slices: 34/34/34/33).
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+void slice_rows(int mb_h, int n, int s, int *r0, int *r1)
+{
+	int base = mb_h / n, rem = mb_h % n;
+	int start = s * base + (s < rem ? s : rem);
+	*r0 = start;
+	*r1 = start + base + (s < rem ? 1 : 0);
+}
+
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+int slice_of_row(int mb_h, int n, int row)
+{
+	int base = mb_h / n, rem = mb_h % n;
+	int split = rem * (base + 1);
+	return row < split ? row / (base + 1) : rem + (row - split) / base;
+}
+
+// launch wrappers implemented in enc_kernels.hip; all asynchronous on `stream`.
+struct Launch {
+	static int input(const Params &p, void *stream);
+	static int intra_decide(const Params &p, void *stream);
+	static int intra_recon(const Params &p, void *stream);
+	static int inter(const Params &p, void *stream);
+	static int deblock(const Params &p, void *stream);
+	static int entropy(const Params &p, void *stream); // cavlc, scan, pack, escape
+};
+
+// host-built table for the 4x4 intra predictors: entry = kind<<4 | k
+// kind 0 copy E[k], 1 (E[k]+E[k+1]+1)>>1, 2 (E[k-1]+2E[k]+E[k+1]+2)>>2, 3 DC
+void build_pred4_table(uint8_t tab[9 * 16]);
+
+} // namespace cedar

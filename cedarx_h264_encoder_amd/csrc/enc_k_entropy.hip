@@ -1,0 +1,689 @@
+// cedarx_h264_encoder_amd/csrc/enc_k_entropy.hip
+// CAVLC back end on the GPU (clauses 7.3.5, 9.1, 9.2 and Annex B):
+//   k_cavlc      every macroblock packs its own syntax elements into a
+//                private bit buffer (nC contexts need only the neighbours'
+//                coefficient counts, so this is fully parallel); P_Skip decided
+//                here from the median motion-vector predictor
+//   k_scan       per unit: mb_skip_run by a max-scan over skip flags, bit
+//                offsets by a prefix sum of the bit lengths
+//   k_zero/k_pack  bit-granular concatenation into the slice RBSP
+//   k_esc_*      emulation prevention (00 00 0x -> 00 00 03 0x) as count / scan /
+//                write over fixed chunks, NAL start code + header, compact output
+// In the reference all of this is silicon behind PUTBITS/STM registers
+// (kernel/cedar_regs.h:59-63; emulation prevention toggled at cedar.c:872-880).
+#include <hip/hip_runtime.h>
+
+#include "enc_device.h"
+#include "enc_tables.h"
+
+namespace cedar {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------- per-thread MSB-first bit writer into a slot ----------------
+struct BitW {
+	uint32_t *slot; // SLOT_WORDS words; each holds 32 stream bits, first bit = MSB
+	uint64_t acc;
+	int nacc;
+	int words;
+	int overflow;
+};
+
+DEVI void bw_put(BitW &b, uint32_t v, int n)
+{
+	if (n == 0)
+		return;
+	b.acc = (b.acc << n) | (uint64_t)(v & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u)));
+	b.nacc += n;
+	if (b.nacc >= 32) {
+		uint32_t w = (uint32_t)(b.acc >> (b.nacc - 32));
+		if (b.words < SLOT_WORDS)
+			b.slot[b.words] = w;
+		else
+			b.overflow = 1;
+		b.words++;
+		b.nacc -= 32;
+	}
+}
+
+DEVI void bw_ue(BitW &b, uint32_t v)
+{
+	v++;
+	bw_put(b, v, 2 * (32 - __clz(v)) - 1);
+}
+
+DEVI void bw_se(BitW &b, int v)
+{
+	bw_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v));
+}
+
+DEVI int ue_len(uint32_t v)
+{
+	return 2 * (32 - __clz(v + 1)) - 1;
+}
+
+DEVI void bw_code(BitW &b, uint16_t packed)
+{
+	bw_put(b, packed & 0xff, packed >> 8);
+}
+
+DEVI void load_block(const int16_t *src, int lv[16])
+{
+	const u32x4 a = *(const u32x4 *)src, c = *(const u32x4 *)(src + 8);
+	const uint32_t w[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		lv[2 * i] = (int16_t)(w[i] & 0xffff);
+		lv[2 * i + 1] = (int16_t)(w[i] >> 16);
+	}
+}
+
+// residual_block_cavlc (7.3.5.3.2 / 9.2): lv[first .. first+maxc) in scan order
+DEVI void cavlc_block(BitW &b, const int lv[16], int first, int maxc, int nC)
+{
+	// positions of non-zero levels as a bitmask over scan index
+	uint32_t mask = 0;
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		if (i >= first && i < first + maxc && lv[i] != 0)
+			mask |= 1u << (i - first);
+	const int n = __popc(mask);
+	int t1 = 0;
+	{
+		uint32_t m = mask;
+		while (m && t1 < 3) {
+			int hi = 31 - __clz(m);
+			int v = 0;
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				v = (i - first == hi) ? lv[i] : v;
+			if (v != 1 && v != -1)
+				break;
+			t1++;
+			m &= ~(1u << hi);
+		}
+	}
+	if (nC < 0)
+		bw_code(b, kCoeffTokenChromaDC[4 * n + t1]);
+	else
+		bw_code(b, kCoeffToken[(nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3) * 68 + 4 * n + t1]);
+	if (n == 0)
+		return;
+	int suffix_len = (n > 10 && t1 < 3) ? 1 : 0;
+	uint32_t m = mask;
+	for (int k = 0; k < n; k++) {
+		const int hi = 31 - __clz(m);
+		m &= ~(1u << hi);
+		int level = 0;
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			level = (i - first == hi) ? lv[i] : level;
+		if (k < t1) {
+			bw_put(b, level < 0, 1);
+			continue;
+		}
+		const int a = level < 0 ? -level : level;
+		int code = 2 * a - 2 + (level < 0);
+		if (k == t1 && t1 < 3)
+			code -= 2;
+		if (suffix_len == 0) {
+			if (code < 14) {
+				bw_put(b, 1, code + 1);
+			} else if (code < 30) {
+				bw_put(b, 1, 15);
+				bw_put(b, (uint32_t)(code - 14), 4);
+			} else {
+				bw_put(b, 1, 16);
+				bw_put(b, (uint32_t)(code - 30), 12);
+			}
+		} else if (code < (15 << suffix_len)) {
+			bw_put(b, 1, (code >> suffix_len) + 1);
+			bw_put(b, (uint32_t)(code & ((1 << suffix_len) - 1)), suffix_len);
+		} else {
+			bw_put(b, 1, 16);
+			bw_put(b, (uint32_t)(code - (15 << suffix_len)), 12);
+		}
+		if (suffix_len == 0)
+			suffix_len = 1;
+		if (a > (3 << (suffix_len - 1)) && suffix_len < 6)
+			suffix_len++;
+	}
+	const int last = 31 - __clz(mask);
+	const int total_zeros = last + 1 - n;
+	if (n < maxc) {
+		if (maxc == 4)
+			bw_code(b, kTotalZerosChromaDC[(n - 1) * 4 + total_zeros]);
+		else
+			bw_code(b, kTotalZeros[(n - 1) * 16 + total_zeros]);
+	}
+	int zeros_left = total_zeros;
+	m = mask;
+	for (int k = 0; k < n - 1 && zeros_left > 0; k++) {
+		const int hi = 31 - __clz(m);
+		m &= ~(1u << hi);
+		const int next = 31 - __clz(m);
+		const int run = hi - next - 1;
+		bw_code(b, kRunBefore[((zeros_left > 7 ? 7 : zeros_left) - 1) * 16 + run]);
+		zeros_left -= run;
+	}
+}
+
+struct Nb {
+	const uint8_t *cur, *left, *top; // nnz arrays (NULL = unavailable)
+};
+
+DEVI int calc_nc(const Nb &nb, int plane, int bx, int by)
+{
+	const int w = plane ? 2 : 4, base = plane ? 16 + 4 * (plane - 1) : 0;
+	int na = -1, nbv = -1;
+	if (bx > 0)
+		na = nb.cur[base + bx - 1 + w * by];
+	else if (nb.left)
+		na = nb.left[base + w - 1 + w * by];
+	if (by > 0)
+		nbv = nb.cur[base + bx + w * (by - 1)];
+	else if (nb.top)
+		nbv = nb.top[base + bx + w * (w - 1)];
+	if (na >= 0 && nbv >= 0)
+		return (na + nbv + 1) >> 1;
+	return na >= 0 ? na : nbv >= 0 ? nbv : 0;
+}
+
+DEVI void write_residual(BitW &b, const MbInfo &mi, const int16_t *cf, const Nb &nb)
+{
+	int lv[16];
+	if (mi.type == MB_I16x16) {
+		load_block(cf + COEF_DC16, lv);
+		cavlc_block(b, lv, 0, 16, calc_nc(nb, 0, 0, 0));
+	}
+	for (int i8 = 0; i8 < 4; i8++) {
+		if (!(mi.cbp & (1 << i8)))
+			continue;
+		for (int i4 = 0; i4 < 4; i4++) {
+			const int idx = 4 * i8 + i4;
+			const int nC = calc_nc(nb, 0, kBlkX[idx], kBlkY[idx]);
+			load_block(cf + COEF_LUMA + idx * 16, lv);
+			if (mi.type == MB_I16x16)
+				cavlc_block(b, lv, 1, 15, nC);
+			else
+				cavlc_block(b, lv, 0, 16, nC);
+		}
+	}
+	if (mi.cbp & 0x30) {
+		const u32x4 d = *(const u32x4 *)(cf + COEF_CDC);
+		const uint32_t w[4] = { d.x, d.y, d.z, d.w };
+		for (int c = 0; c < 2; c++) {
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				lv[i] = 0;
+			lv[0] = (int16_t)(w[2 * c] & 0xffff);
+			lv[1] = (int16_t)(w[2 * c] >> 16);
+			lv[2] = (int16_t)(w[2 * c + 1] & 0xffff);
+			lv[3] = (int16_t)(w[2 * c + 1] >> 16);
+			cavlc_block(b, lv, 0, 4, -1);
+		}
+		if (mi.cbp & 0x20)
+			for (int c = 0; c < 2; c++)
+				for (int blk = 0; blk < 4; blk++) {
+					load_block(cf + COEF_CAC + (4 * c + blk) * 16, lv);
+					cavlc_block(b, lv, 1, 15, calc_nc(nb, 1 + c, blk & 1, blk >> 1));
+				}
+	}
+}
+
+// ------------------------------------------------------------------------
+// k_cavlc: one thread per macroblock
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cavlc(Params p)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x; // MB index within the encoded rows
+	const int st = blockIdx.y;
+	if (i >= p.row_num * p.mb_w)
+		return;
+	const int my = p.row_first + i / p.mb_w, mx = i % p.mb_w;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
+	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+	const bool has_left = mx > 0, has_top = my > r0;
+
+	MbInfo mi = p.mbi[mbaddr];
+	BitW b;
+	b.slot = p.slot + mbaddr * SLOT_WORDS;
+	b.acc = 0;
+	b.nacc = 0;
+	b.words = 0;
+	b.overflow = 0;
+
+	Nb nb;
+	nb.cur = p.nnz + mbaddr * NNZ_PER_MB;
+	nb.left = has_left ? p.nnz + (mbaddr - 1) * NNZ_PER_MB : nullptr;
+	nb.top = has_top ? p.nnz + (mbaddr - p.mb_w) * NNZ_PER_MB : nullptr;
+	const int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
+	int skip = 0;
+
+	if (p.is_idr) {
+		if (mi.type == MB_I4x4) {
+			bw_ue(b, 0);
+			const int8_t *mo = p.i4modes + mbaddr * 16;
+			for (int idx = 0; idx < 16; idx++) {
+				const int bx = kBlkX[idx], by = kBlkY[idx];
+				// predicted mode (8.3.1.1): DC when either neighbour MB is unavailable
+				int ma = 2, mb_ = 2;
+				bool dcflag = false;
+				if (bx > 0) {
+					ma = mo[idx - (bx & 1 ? 1 : 3)]; // left block inside the MB
+				} else if (has_left) {
+					const MbInfo ml = p.mbi[mbaddr - 1];
+					ma = ml.type == MB_I4x4 ? p.i4modes[(mbaddr - 1) * 16 + idx + 5] : 2;
+				} else {
+					dcflag = true;
+				}
+				if (by > 0) {
+					mb_ = mo[idx - (by & 1 ? 2 : 6)]; // block above inside the MB
+				} else if (has_top) {
+					const MbInfo mt = p.mbi[mbaddr - p.mb_w];
+					mb_ = mt.type == MB_I4x4 ? p.i4modes[(mbaddr - p.mb_w) * 16 + idx + 10] : 2;
+				} else {
+					dcflag = true;
+				}
+				const int pm = dcflag ? 2 : (ma < mb_ ? ma : mb_);
+				const int m = mo[idx];
+				if (m == pm) {
+					bw_put(b, 1, 1);
+				} else {
+					bw_put(b, 0, 1);
+					bw_put(b, (uint32_t)(m < pm ? m : m - 1), 3);
+				}
+			}
+			bw_ue(b, (uint32_t)mi.chroma_mode);
+			bw_ue(b, kCbpCodeIntra[mi.cbp & 0x3f]);
+			if (mi.cbp & 0x3f)
+				bw_se(b, 0);
+		} else {
+			const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
+			bw_ue(b, (uint32_t)t);
+			bw_ue(b, (uint32_t)mi.chroma_mode);
+			bw_se(b, 0);
+		}
+		write_residual(b, mi, cf, nb);
+	} else {
+		// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1)
+		int ax = 0, ay = 0, bx_ = 0, by_ = 0, cx = 0, cy = 0;
+		bool hasA = has_left, hasB = has_top, hasC = false;
+		if (hasA) {
+			const MbInfo m = p.mbi[mbaddr - 1];
+			ax = m.mvx; ay = m.mvy;
+		}
+		if (hasB) {
+			const MbInfo m = p.mbi[mbaddr - p.mb_w];
+			bx_ = m.mvx; by_ = m.mvy;
+			if (mx < p.mb_w - 1) {
+				const MbInfo c = p.mbi[mbaddr - p.mb_w + 1];
+				cx = c.mvx; cy = c.mvy; hasC = true;
+			} else if (mx > 0) {
+				const MbInfo c = p.mbi[mbaddr - p.mb_w - 1];
+				cx = c.mvx; cy = c.mvy; hasC = true;
+			}
+		}
+		int px, py;
+		const int n = (int)hasA + (int)hasB + (int)hasC;
+		if (!hasB && !hasC && hasA) {
+			px = ax; py = ay;
+		} else if (n == 1) {
+			px = hasA ? ax : hasB ? bx_ : cx;
+			py = hasA ? ay : hasB ? by_ : cy;
+		} else {
+			px = median3(ax, bx_, cx);
+			py = median3(ay, by_, cy);
+		}
+		int skx = px, sky = py;
+		if (!hasA || !hasB || (ax == 0 && ay == 0) || (bx_ == 0 && by_ == 0)) {
+			skx = 0; sky = 0;
+		}
+		if (mi.cbp == 0 && mi.mvx == skx && mi.mvy == sky) {
+			skip = 1;
+			mi.type = MB_PSKIP;
+			p.mbi[mbaddr].type = MB_PSKIP; // nobody else reads .type of a P macroblock concurrently
+		} else {
+			bw_ue(b, 0); // P_L0_16x16
+			bw_se(b, 4 * (mi.mvx - px));
+			bw_se(b, 4 * (mi.mvy - py));
+			bw_ue(b, kCbpCodeInter[mi.cbp & 0x3f]);
+			if (mi.cbp & 0x3f)
+				bw_se(b, 0);
+			write_residual(b, mi, cf, nb);
+		}
+	}
+	const uint32_t total = (uint32_t)(b.words * 32 + b.nacc);
+	if (b.nacc > 0) {
+		if (b.words < SLOT_WORDS)
+			b.slot[b.words] = (uint32_t)(b.acc << (32 - b.nacc));
+		else
+			b.overflow = 1;
+	}
+	p.mb_bits[mbaddr] = total;
+	p.skip[mbaddr] = (uint8_t)skip;
+	if (b.overflow)
+		atomicOr(&p.stream_size[p.n_streams + 1], 1u);
+}
+
+// ---------------- block-wide inclusive scans (1024 threads) ----------------
+template <bool IS_MAX>
+DEVI int block_scan_incl(int v, int *s_tmp)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		int o = __shfl_up(v, off, 64);
+		if (lane >= off)
+			v = IS_MAX ? (o > v ? o : v) : v + o;
+	}
+	__syncthreads();
+	if (lane == 63)
+		s_tmp[wave] = v;
+	__syncthreads();
+	if (wave == 0) {
+		int t = lane < 16 ? s_tmp[lane] : (IS_MAX ? -0x7fffffff : 0);
+#pragma unroll
+		for (int off = 1; off < 16; off <<= 1) {
+			int o = __shfl_up(t, off, 64);
+			if (lane >= off)
+				t = IS_MAX ? (o > t ? o : t) : t + o;
+		}
+		if (lane < 16)
+			s_tmp[16 + lane] = t;
+	}
+	__syncthreads();
+	if (wave > 0) {
+		int pre = s_tmp[16 + wave - 1];
+		v = IS_MAX ? (pre > v ? pre : v) : v + pre;
+	}
+	return v;
+}
+
+// ------------------------------------------------------------------------
+// k_scan: one 1024-thread block per unit. Entry e of bit_off / run_before:
+//   e in [0, n): macroblock e of the unit; e == n: slice trailer.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(Params p)
+{
+	__shared__ int s_tmp[32];
+	__shared__ int s_carry_max, s_carry_sum;
+	const int unit = blockIdx.x;
+	const int st = unit / p.slice_num, ls = unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, p.slice_first + ls, &r0, &r1);
+	const int n = (r1 - r0) * p.mb_w;
+	const size_t mb0 = (size_t)st * p.n_mb + (size_t)r0 * p.mb_w;
+	uint32_t *off = p.bit_off + (size_t)unit * (p.unit_mb_cap + 2);
+	uint32_t *run = p.run_before + (size_t)unit * (p.unit_mb_cap + 2);
+	const bool is_p = !p.is_idr;
+	if (threadIdx.x == 0) {
+		s_carry_max = -1;
+		s_carry_sum = p.hdr[ls].nbits;
+	}
+	__syncthreads();
+	for (int base = 0; base <= n; base += 1024) {
+		const int e = base + threadIdx.x;
+		const bool mb = e < n, trailer = e == n;
+		const int sk = mb ? p.skip[mb0 + e] : 0;
+		// last non-skipped macroblock index at or before e (inclusive max-scan)
+		int m = (mb && !sk) ? e : -1;
+		m = block_scan_incl<true>(m, s_tmp);
+		const int cmax = s_carry_max;
+		m = m > cmax ? m : cmax;
+		// exclusive value = inclusive of e-1
+		int prev = __shfl_up(m, 1, 64);
+		__syncthreads();
+		if ((threadIdx.x & 63) == 63)
+			s_tmp[threadIdx.x >> 6] = m;
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0)
+			prev = threadIdx.x == 0 ? cmax : s_tmp[(threadIdx.x >> 6) - 1];
+		const int r = (mb && !sk) || trailer ? e - 1 - prev : 0;
+		int bits = 0;
+		if (mb && !sk)
+			bits = (is_p ? ue_len((uint32_t)r) : 0) + (int)p.mb_bits[mb0 + e];
+		else if (trailer)
+			bits = ((is_p && r > 0) ? ue_len((uint32_t)r) : 0) + 1; // + rbsp stop bit
+		int incl = block_scan_incl<false>(bits, s_tmp);
+		const int csum = s_carry_sum;
+		if (mb || trailer) {
+			off[e] = (uint32_t)(csum + incl - bits);
+			run[e] = (uint32_t)r;
+		}
+		if (trailer)
+			p.unit_bits[unit] = (uint32_t)(csum + incl);
+		__syncthreads();
+		if (threadIdx.x == 1023) {
+			s_carry_max = m;
+			s_carry_sum = csum + incl;
+		}
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------
+// k_zero: clear the part of each unit's RBSP buffer that k_pack will OR into
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero(Params p)
+{
+	const int unit = blockIdx.y;
+	const uint32_t nbytes = (p.unit_bits[unit] + 7) >> 3;
+	const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+	if (i < nbytes + 16 && i + 16 <= (uint32_t)p.rbsp_cap)
+		*(u32x4 *)(p.rbsp + (size_t)unit * p.rbsp_cap + i) = u32x4{ 0, 0, 0, 0 };
+}
+
+// OR the low n bits of v into the RBSP at bit position pos (MSB first)
+DEVI void or_bits(uint32_t *w, uint32_t cap_words, uint32_t pos, uint32_t v, int n)
+{
+	if (n <= 0)
+		return;
+	const uint32_t wi = pos >> 5, s = pos & 31;
+	v = n >= 32 ? v : (v & ((1u << n) - 1u));
+	if (wi + 1 >= cap_words)
+		return; // overflow is reported by k_esc_scan through the size check
+	if (s + n <= 32) {
+		atomicOr(&w[wi], __builtin_bswap32(v << (32 - s - n)));
+	} else {
+		const int lo = s + n - 32; // bits spilling into the next word
+		atomicOr(&w[wi], __builtin_bswap32(v >> lo));
+		atomicOr(&w[wi + 1], __builtin_bswap32(v << (32 - lo)));
+	}
+}
+
+// ------------------------------------------------------------------------
+// k_pack: one thread per entry (header, macroblocks, trailer) of a unit
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(Params p)
+{
+	const int unit = blockIdx.y;
+	const int st = unit / p.slice_num, ls = unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, p.slice_first + ls, &r0, &r1);
+	const int n = (r1 - r0) * p.mb_w;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x; // 0 = header, 1..n = MBs, n+1 = trailer
+	if (t > n + 1)
+		return;
+	uint32_t *w = (uint32_t *)(p.rbsp + (size_t)unit * p.rbsp_cap);
+	const uint32_t capw = (uint32_t)p.rbsp_cap >> 2;
+	const uint32_t *off = p.bit_off + (size_t)unit * (p.unit_mb_cap + 2);
+	const uint32_t *run = p.run_before + (size_t)unit * (p.unit_mb_cap + 2);
+	const bool is_p = !p.is_idr;
+	if (t == 0) {
+		const uint64_t hb = p.hdr[ls].bits;
+		const int hn = p.hdr[ls].nbits;
+		if (hn > 32) {
+			or_bits(w, capw, 0, (uint32_t)(hb >> 32), hn - 32);
+			or_bits(w, capw, (uint32_t)(hn - 32), (uint32_t)hb, 32);
+		} else {
+			or_bits(w, capw, 0, (uint32_t)hb, hn);
+		}
+		return;
+	}
+	const int e = t - 1;
+	uint32_t pos = off[e];
+	if (e == n) { // trailer: pending skip run, then rbsp_trailing_bits
+		if (is_p && run[e] > 0) {
+			const uint32_t v = run[e] + 1;
+			const int len = 2 * (32 - __clz(v)) - 1;
+			or_bits(w, capw, pos, v, len);
+			pos += len;
+		}
+		or_bits(w, capw, pos, 1, 1);
+		return;
+	}
+	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)r0 * p.mb_w + e;
+	if (p.skip[mbaddr])
+		return;
+	if (is_p) {
+		const uint32_t v = run[e] + 1;
+		const int len = 2 * (32 - __clz(v)) - 1;
+		or_bits(w, capw, pos, v, len);
+		pos += len;
+	}
+	const uint32_t nbits = p.mb_bits[mbaddr];
+	const uint32_t *slot = p.slot + mbaddr * SLOT_WORDS;
+	const uint32_t full = nbits >> 5, rem = nbits & 31;
+	for (uint32_t k = 0; k < full && k < (uint32_t)SLOT_WORDS; k++)
+		or_bits(w, capw, pos + 32 * k, slot[k], 32);
+	if (rem && full < (uint32_t)SLOT_WORDS)
+		or_bits(w, capw, pos + 32 * full, slot[full] >> (32 - rem), (int)rem);
+}
+
+// ---------------- emulation prevention ----------------
+// zero-run state (0, 1, 2) of the escaping automaton just before byte `pos`
+DEVI int zero_state_before(const uint8_t *rb, int pos)
+{
+	int run = 0;
+	for (int i = pos - 1; i >= 0 && rb[i] == 0; i--)
+		run++;
+	return run == 0 ? 0 : ((run & 1) ? 1 : 2);
+}
+
+__global__ __launch_bounds__(256) void k_esc_count(Params p)
+{
+	const int unit = blockIdx.y;
+	const int nbytes = (int)((p.unit_bits[unit] + 7) >> 3);
+	const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+	const int start = chunk * ESC_CHUNK;
+	if (chunk >= p.esc_chunks_cap)
+		return;
+	uint32_t cnt = 0;
+	if (start < nbytes) {
+		const uint8_t *rb = p.rbsp + (size_t)unit * p.rbsp_cap;
+		const int end = start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes;
+		int z = zero_state_before(rb, start);
+		for (int i = start; i < end; i++) {
+			const uint8_t v = rb[i];
+			if (z == 2 && v <= 3) {
+				cnt++;
+				z = 0;
+			}
+			z = v == 0 ? z + 1 : 0;
+		}
+	}
+	p.esc_cnt[(size_t)unit * p.esc_chunks_cap + chunk] = cnt;
+}
+
+// one block: per unit exclusive prefix of the escape counts, NAL sizes, compact
+// output offsets (stream-major, each stream preceded by its SPS/PPS prefix)
+__global__ __launch_bounds__(1024) void k_esc_scan(Params p)
+{
+	__shared__ int s_tmp[32];
+	__shared__ int s_carry;
+	__shared__ uint32_t s_pos;
+	const int n_units = p.n_streams * p.slice_num;
+	if (threadIdx.x == 0)
+		s_pos = 0;
+	__syncthreads();
+	for (int unit = 0; unit < n_units; unit++) {
+		const int st = unit / p.slice_num, ls = unit % p.slice_num;
+		const int nbytes = (int)((p.unit_bits[unit] + 7) >> 3);
+		const int chunks = (nbytes + ESC_CHUNK - 1) / ESC_CHUNK;
+		uint32_t *cnt = p.esc_cnt + (size_t)unit * p.esc_chunks_cap;
+		if (threadIdx.x == 0)
+			s_carry = 0;
+		__syncthreads();
+		for (int base = 0; base < chunks; base += 1024) {
+			const int c = base + threadIdx.x;
+			const int v = c < chunks ? (int)cnt[c] : 0;
+			const int incl = block_scan_incl<false>(v, s_tmp);
+			const int carry = s_carry;
+			if (c < chunks)
+				cnt[c] = (uint32_t)(carry + incl - v);
+			__syncthreads();
+			if (threadIdx.x == 1023)
+				s_carry = carry + incl;
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) {
+			uint32_t pos = s_pos;
+			if (ls == 0) {
+				p.stream_size[st] = pos; // start of the stream, fixed up below
+				pos += p.prefix_len[st];
+			}
+			const uint32_t size = 5u + (uint32_t)nbytes + (uint32_t)s_carry;
+			p.nal_off[unit] = pos;
+			p.nal_size[unit] = size;
+			pos += size;
+			s_pos = pos;
+			if (ls == p.slice_num - 1)
+				p.stream_size[st] = pos - p.stream_size[st];
+			if (pos > (uint32_t)p.out_cap || (uint32_t)nbytes + 8u > (uint32_t)p.rbsp_cap)
+				atomicOr(&p.stream_size[p.n_streams + 1], 2u);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		p.stream_size[p.n_streams] = s_pos;
+}
+
+__global__ __launch_bounds__(256) void k_esc_write(Params p)
+{
+	const int unit = blockIdx.y;
+	const int nbytes = (int)((p.unit_bits[unit] + 7) >> 3);
+	const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+	const int start = chunk * ESC_CHUNK;
+	if (start >= nbytes || (p.stream_size[p.n_streams + 1] & 2u))
+		return;
+	const uint8_t *rb = p.rbsp + (size_t)unit * p.rbsp_cap;
+	uint8_t *o = p.out + p.nal_off[unit];
+	if (chunk == 0) { // 4-byte start code on every NAL (cedar.c:875-878) + header byte
+		o[0] = 0;
+		o[1] = 0;
+		o[2] = 0;
+		o[3] = 1;
+		o[4] = (uint8_t)((p.nal_ref_idc << 5) | p.nal_type);
+	}
+	o += 5 + start + p.esc_cnt[(size_t)unit * p.esc_chunks_cap + chunk];
+	const int end = start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes;
+	int z = zero_state_before(rb, start);
+	for (int i = start; i < end; i++) {
+		const uint8_t v = rb[i];
+		if (z == 2 && v <= 3) {
+			*o++ = 3;
+			z = 0;
+		}
+		*o++ = v;
+		z = v == 0 ? z + 1 : 0;
+	}
+}
+
+int Launch::entropy(const Params &p, void *stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const int n_units = p.n_streams * p.slice_num;
+	const int mbs = p.row_num * p.mb_w;
+	hipLaunchKernelGGL(k_cavlc, dim3((mbs + 63) / 64, p.n_streams), dim3(64), 0, s, p);
+	hipLaunchKernelGGL(k_scan, dim3(n_units), dim3(1024), 0, s, p);
+	hipLaunchKernelGGL(k_zero, dim3((p.rbsp_cap / 16 + 255) / 256, n_units), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k_pack, dim3((p.unit_mb_cap + 2 + 255) / 256, n_units), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k_esc_count, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k_esc_scan, dim3(1), dim3(1024), 0, s, p);
+	hipLaunchKernelGGL(k_esc_write, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
+	return (int)hipGetLastError();
+}
+
+} // namespace cedar

@@ -1,0 +1,498 @@
+// cedarx_h264_encoder_amd/csrc/enc_k_parallel.hip
+// The macroblock-parallel gfx950 kernels: input padding, open-loop intra mode
+// decision, and the fused P-macroblock kernel (16x16 SAD search against the
+// deblocked reference + residual + 4x4 transform/quant + reconstruction).
+// One 64-lane wavefront per macroblock; tiles are staged in LDS from 16-byte
+// coalesced loads; SAD candidates are evaluated with v_qsad_pk_u16_u8 (four
+// horizontal offsets per instruction) and reduced across the wave with
+// shuffles. No MFMA: there is no dense contraction on this path.
+//
+// These replace the VE's ISP fetch + ME + transform stages that the reference
+// only triggers (kernel/cedar.c:1068-1080, :1142-1149, :1170-1176).
+#include <hip/hip_runtime.h>
+
+#include "enc_device.h"
+
+namespace cedar {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------
+// k_input: tightly packed width x height nv12 -> padded coded-size planes
+// (edge replication right/bottom). One thread per 16 output bytes.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_input(Params p)
+{
+	const int segs = p.cw >> 4;
+	const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+	const int row = blockIdx.y; // [0, ch) luma, [ch, ch + ch/2) chroma
+	const int st = blockIdx.z;
+	if (seg >= segs)
+		return;
+	const bool luma = row < p.ch;
+	const int prow = luma ? row : row - p.ch;
+	const int srows = luma ? p.height : p.height >> 1;
+	const int sy = prow < srows ? prow : srows - 1;
+	const uint8_t *src = (luma ? p.in_luma[st] : p.in_chroma[st]) + (size_t)sy * p.width;
+	uint8_t *dst = luma ? p.src_y + (size_t)st * p.plane_y_stride + (size_t)prow * p.cw
+			    : p.src_uv + (size_t)st * p.plane_uv_stride + (size_t)prow * p.cw;
+	const int x0 = seg << 4;
+	u32x4 v;
+	if (x0 + 16 <= p.width && ((p.width & 15) == 0) && ((((uintptr_t)src) & 15) == 0)) {
+		v = *(const u32x4 *)(src + x0);
+	} else {
+		uint32_t w[4] = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			int x = x0 + i, sx;
+			if (luma)
+				sx = x < p.width ? x : p.width - 1;
+			else { // replicate the last CbCr pair
+				int pr = x >> 1, lim = (p.width >> 1) - 1;
+				sx = 2 * (pr < lim ? pr : lim) + (x & 1);
+			}
+			w[i >> 2] |= (uint32_t)src[sx] << (8 * (i & 3));
+		}
+		v = u32x4{ w[0], w[1], w[2], w[3] };
+	}
+	*(u32x4 *)(dst + x0) = v;
+}
+
+int Launch::input(const Params &p, void *stream)
+{
+	dim3 grid((p.cw / 16 + 255) / 256, p.ch + p.ch / 2, p.n_streams);
+	hipLaunchKernelGGL(k_input, grid, dim3(256), 0, (hipStream_t)stream, p);
+	return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// k_inter: one wave per macroblock of a P picture.
+// LDS: reference window 48x48 luma (+-16), 25 rows x 32 CbCr pairs chroma.
+// ------------------------------------------------------------------------
+#define REF_STRIDE 48
+#define REFC_STRIDE 64
+
+__global__ __launch_bounds__(64) void k_inter(Params p)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_ref[48 * REF_STRIDE + 64];
+	__shared__ __attribute__((aligned(16))) uint8_t s_refc[25 * REFC_STRIDE];
+	__shared__ __attribute__((aligned(16))) uint8_t s_cur[256];
+	__shared__ __attribute__((aligned(16))) uint8_t s_curc[128];
+	__shared__ __attribute__((aligned(16))) int16_t s_coef[COEF_PER_MB];
+	__shared__ __attribute__((aligned(16))) uint8_t s_recy[256];
+	__shared__ __attribute__((aligned(16))) uint8_t s_recc[128];
+	__shared__ int s_dc[8];
+	__shared__ int s_cdc[8];
+
+	const int lane = threadIdx.x;
+	const int mx = blockIdx.x, my = p.row_first + blockIdx.y, st = blockIdx.z;
+	const int x0 = mx * 16, y0 = my * 16;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
+	const int band_y0 = r0 * 16, band_y1 = r1 * 16;
+
+	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
+	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+	const uint8_t *ref_y = p.ref_y + (size_t)st * p.plane_y_stride;
+	const uint8_t *ref_uv = p.ref_uv + (size_t)st * p.plane_uv_stride;
+	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
+	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
+	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+
+	// ---- stage tiles through LDS with 16-byte loads ----
+	if (lane < 16)
+		*(u32x4 *)(s_cur + lane * 16) = *(const u32x4 *)(src_y + (size_t)(y0 + lane) * p.cw + x0);
+	else if (lane < 24)
+		*(u32x4 *)(s_curc + (lane - 16) * 16) =
+			*(const u32x4 *)(src_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0);
+	for (int idx = lane; idx < 48 * 3; idx += 64) {
+		int row = idx / 3, seg = idx - row * 3;
+		int gy = y0 - 16 + row, gx = x0 - 16 + 16 * seg;
+		u32x4 v = u32x4{ 0, 0, 0, 0 };
+		if (gy >= 0 && gy < p.ch && gx >= 0 && gx < p.cw)
+			v = *(const u32x4 *)(ref_y + (size_t)gy * p.cw + gx);
+		*(u32x4 *)(s_ref + row * REF_STRIDE + 16 * seg) = v;
+	}
+	for (int idx = lane; idx < 25 * 4; idx += 64) {
+		int row = idx >> 2, seg = idx & 3;
+		int gy = my * 8 - 8 + row, gx = x0 - 16 + 16 * seg; // byte offset in the CbCr row
+		u32x4 v = u32x4{ 0, 0, 0, 0 };
+		if (gy >= 0 && gy < (p.ch >> 1) && gx >= 0 && gx < p.cw)
+			v = *(const u32x4 *)(ref_uv + (size_t)gy * p.cw + gx);
+		*(u32x4 *)(s_refc + row * REFC_STRIDE + 16 * seg) = v;
+	}
+	if (lane < 16)
+		*(u32x4 *)(s_ref + 48 * REF_STRIDE + (lane & 3) * 16) = u32x4{ 0, 0, 0, 0 };
+	__syncthreads();
+
+	// ---- motion search: lane task = (dy, group of 4 dx); 33 x 9 = 297 tasks ----
+	uint32_t curd[64];
+#pragma unroll
+	for (int i = 0; i < 64; i++)
+		curd[i] = ((const uint32_t *)s_cur)[i];
+
+	const int R = p.search_range;
+	uint32_t best = 0xffffffffu;
+	for (int round = 0; round < 5; round++) {
+		int t = round * 64 + lane;
+		const bool tvalid = t < 297;
+		t = tvalid ? t : 296;
+		const int dyi = t / 9, g = t - dyi * 9;
+		const int dy = dyi - 16, dx0 = 4 * g - 16;
+		const uint8_t *base = s_ref + dyi * REF_STRIDE + 4 * g;
+		uint64_t acc = 0;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const uint32_t *rp = (const uint32_t *)(base + r * REF_STRIDE);
+			uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3], w4 = rp[4];
+			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w1 << 32) | w0, curd[4 * r + 0], acc);
+			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w2 << 32) | w1, curd[4 * r + 1], acc);
+			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w3 << 32) | w2, curd[4 * r + 2], acc);
+			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w4 << 32) | w3, curd[4 * r + 3], acc);
+		}
+		const bool yok = tvalid && dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
+		const int cost_y = p.lambda * mv_bits(dy);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int dx = dx0 + k;
+			const bool ok = yok && dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
+			const uint32_t sad = (uint32_t)(acc >> (16 * k)) & 0xffffu;
+			const uint32_t cost = sad + (uint32_t)(cost_y + p.lambda * mv_bits(dx));
+			const uint32_t key = (cost << 11) | (uint32_t)((dy + 16) * 33 + dx + 16);
+			best = (ok && key < best) ? key : best;
+		}
+	}
+	best = wave_min_u32(best);
+	const int bidx = (int)(best & 2047u);
+	const int bdy = bidx / 33 - 16, bdx = bidx - (bidx / 33) * 33 - 16;
+
+	// ---- residual, transform, quantisation, reconstruction: one lane per 4x4 block ----
+	for (int i = lane; i < COEF_PER_MB; i += 64)
+		s_coef[i] = 0;
+	__syncthreads();
+
+	int nnz = 0, dc_level_nz = 0;
+	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / 6;
+	if (lane < 16) {
+		const int bx = kBlkX[lane], by = kBlkY[lane];
+		int pred[16], res[16], w[16], lv[16], d[16], out[16];
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+			pred[i] = s_ref[(16 + bdy + y) * REF_STRIDE + 16 + bdx + x];
+			res[i] = (int)s_cur[y * 16 + x] - pred[i];
+		}
+		fdct4x4(res, w);
+		nnz = quant_dequant(w, 0, p.mf, p.dv, f_inter, p.qbits, p.qshift, lv, d);
+		idct4x4_add(d, pred, out);
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			s_coef[COEF_LUMA + lane * 16 + i] = (int16_t)lv[i];
+			s_recy[(4 * by + (i >> 2)) * 16 + 4 * bx + (i & 3)] = (uint8_t)out[i];
+		}
+	}
+	// chroma: lanes 16..23, plane c, block blk (raster 2x2)
+	int cpred[16], cw_[16], clv[16], cd[16];
+	const bool is_c = lane >= 16 && lane < 24;
+	const int c = (lane - 16) >> 2, blk = (lane - 16) & 3;
+	if (is_c) {
+		const int bx = blk & 1, by = blk >> 1;
+		const int ix = bdx >> 1, iy = bdy >> 1, fx = (bdx & 1) * 4, fy = (bdy & 1) * 4;
+		int res[16];
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+			int wr = y + iy + 8, wc = x + ix + 8; // window row / pair index
+			int wr1 = fy ? wr + 1 : wr, wc1 = fx ? wc + 1 : wc;
+			int A = s_refc[wr * REFC_STRIDE + 2 * wc + c], B = s_refc[wr * REFC_STRIDE + 2 * wc1 + c];
+			int C = s_refc[wr1 * REFC_STRIDE + 2 * wc + c], D = s_refc[wr1 * REFC_STRIDE + 2 * wc1 + c];
+			cpred[i] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
+			res[i] = (int)s_curc[y * 16 + 2 * x + c] - cpred[i];
+		}
+		fdct4x4(res, cw_);
+		s_dc[lane - 16] = cw_[0];
+	}
+	__syncthreads();
+	if (is_c) {
+		// forward 2x2 Hadamard: this lane produces output `blk` of plane c
+		const int *dcs = s_dc + 4 * c;
+		const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
+		int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
+		int l = quant1(hd, p.mfc[0], 2 * f_inter_c, p.qbits_c + 1);
+		s_cdc[lane - 16] = l;
+		s_coef[COEF_CDC + 4 * c + blk] = (int16_t)l;
+		dc_level_nz = l != 0;
+	}
+	__syncthreads();
+	if (is_c) {
+		const int bx = blk & 1, by = blk >> 1;
+		const int *ls = s_cdc + 4 * c;
+		const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
+		int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
+		int out[16];
+		nnz = quant_dequant(cw_, 1, p.mfc, p.dvc, f_inter_c, p.qbits_c, p.qshift_c, clv, cd);
+		cd[0] = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
+		idct4x4_add(cd, cpred, out);
+#pragma unroll
+		for (int i = 1; i < 16; i++)
+			s_coef[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)clv[i];
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			s_recc[(4 * by + (i >> 2)) * 16 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
+	}
+	// coded block pattern from wave ballots
+	const uint64_t nzmask = __ballot(nnz != 0);
+	const uint64_t dcmask = __ballot(dc_level_nz != 0);
+	int cbp = 0;
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+		cbp |= ((nzmask >> (4 * q)) & 0xf) ? (1 << q) : 0;
+	cbp |= ((nzmask >> 16) & 0xff) ? 0x20 : (dcmask ? 0x10 : 0);
+	__syncthreads();
+
+	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
+	if (lane < COEF_PER_MB * 2 / 16)
+		*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)s_coef + lane * 16);
+	if (lane < 16)
+		*(u32x4 *)(rec_y + (size_t)(y0 + lane) * p.cw + x0) = *(const u32x4 *)(s_recy + lane * 16);
+	else if (lane < 24)
+		*(u32x4 *)(rec_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
+	if (lane < 16) {
+		p.nnz[mbaddr * NNZ_PER_MB + kBlkX[lane] + 4 * kBlkY[lane]] = (uint8_t)nnz;
+		p.i4modes[mbaddr * 16 + lane] = 2;
+	} else if (lane < 24) {
+		p.nnz[mbaddr * NNZ_PER_MB + lane] = (uint8_t)nnz;
+	}
+	if (lane == 0) {
+		MbInfo m;
+		m.type = MB_P16x16;
+		m.i16_mode = 0;
+		m.chroma_mode = 0;
+		m.cbp = (int8_t)cbp;
+		m.mvx = (int16_t)bdx;
+		m.mvy = (int16_t)bdy;
+		p.mbi[mbaddr] = m;
+	}
+}
+
+int Launch::inter(const Params &p, void *stream)
+{
+	dim3 grid(p.mb_w, p.row_num, p.n_streams);
+	hipLaunchKernelGGL(k_inter, grid, dim3(64), 0, (hipStream_t)stream, p);
+	return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// k_intra_decide: open-loop intra mode decision from SOURCE samples, one wave
+// per macroblock, every macroblock independent (DESIGN.md "decision / recon
+// split"). Tile = source MB plus its top row, left column, top-left and four
+// top-right samples.
+// ------------------------------------------------------------------------
+#define TS 24 // tile stride; tile[ty][tx] = sample (x0 - 1 + tx, y0 - 1 + ty)
+
+__global__ __launch_bounds__(64) void k_intra_decide(Params p)
+{
+	__shared__ uint8_t s_t[17 * TS];       // luma tile with borders
+	__shared__ uint8_t s_c[2][9 * 12];     // chroma tiles with borders, stride 12
+	__shared__ uint8_t s_E[16][16];        // edge arrays per 4x4 block
+	__shared__ int s_dcv[16];              // DC predictor value per block
+	__shared__ uint32_t s_key[16][9];      // sad<<4 | mode per (block, mode)
+
+	const int lane = threadIdx.x;
+	const int mx = blockIdx.x, my = p.row_first + blockIdx.y, st = blockIdx.z;
+	const int x0 = mx * 16, y0 = my * 16;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
+	const bool top_mb = my > r0, left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
+	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
+	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+
+	// load tiles (byte loads; out-of-picture entries are never used)
+	for (int i = lane; i < 17 * 21; i += 64) {
+		int ty = i / 21, tx = i - ty * 21;
+		int gx = x0 - 1 + tx, gy = y0 - 1 + ty;
+		uint8_t v = 128;
+		if (gx >= 0 && gy >= 0 && gx < p.cw && gy < p.ch)
+			v = src_y[(size_t)gy * p.cw + gx];
+		s_t[ty * TS + tx] = v;
+	}
+	for (int i = lane; i < 2 * 81; i += 64) {
+		int c = i / 81, j = i - c * 81, ty = j / 9, tx = j - ty * 9;
+		int gx = mx * 8 - 1 + tx, gy = my * 8 - 1 + ty;
+		uint8_t v = 128;
+		if (gx >= 0 && gy >= 0 && gx < (p.cw >> 1) && gy < (p.ch >> 1))
+			v = src_uv[(size_t)gy * p.cw + 2 * gx + c];
+		s_c[c][ty * 12 + tx] = v;
+	}
+	__syncthreads();
+
+	// edge arrays + DC values, one lane per 4x4 block (coding order)
+	if (lane < 16) {
+		bool ht, hl, htr;
+		blk4_avail(lane, top_mb, left_mb, tr_mb, ht, hl, htr);
+		const int tx = 1 + 4 * kBlkX[lane], ty = 1 + 4 * kBlkY[lane];
+		uint8_t *E = s_E[lane];
+		int st_ = 0, sl = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			uint8_t l = s_t[(ty + k) * TS + tx - 1], t = s_t[(ty - 1) * TS + tx + k];
+			E[4 - k] = l;
+			E[6 + k] = t;
+			sl += l;
+			st_ += t;
+		}
+		E[0] = E[1];
+		E[5] = s_t[(ty - 1) * TS + tx - 1];
+#pragma unroll
+		for (int k = 4; k < 8; k++)
+			E[6 + k] = htr ? s_t[(ty - 1) * TS + tx + k] : E[9];
+		E[14] = E[13];
+		s_dcv[lane] = (ht && hl) ? (st_ + sl + 4) >> 3 : hl ? (sl + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
+	}
+	__syncthreads();
+
+	// I4x4: 144 (mode, block) tasks over three rounds
+	for (int round = 0; round < 3; round++) {
+		const int t = round * 64 + lane;
+		if (t < 144) {
+			const int mode = t >> 4, b = t & 15;
+			bool ht, hl, htr;
+			blk4_avail(b, top_mb, left_mb, tr_mb, ht, hl, htr);
+			uint32_t key = 0xffffffffu;
+			if (mode4_allowed(mode, ht, hl)) {
+				const int tx = 1 + 4 * kBlkX[b], ty = 1 + 4 * kBlkY[b];
+				const uint8_t *E = s_E[b];
+				const int dc = s_dcv[b];
+				int sad = 0;
+#pragma unroll
+				for (int i = 0; i < 16; i++) {
+					int pv = pred4_px(p.pred4_tab[mode * 16 + i], E, dc);
+					sad += iabs((int)s_t[(ty + (i >> 2)) * TS + tx + (i & 3)] - pv);
+				}
+				key = ((uint32_t)sad << 4) | (uint32_t)mode;
+			}
+			s_key[b][mode] = key;
+		}
+	}
+	__syncthreads();
+	int sum4 = 0, best4 = 0;
+	if (lane < 16) {
+		uint32_t k = 0xffffffffu;
+#pragma unroll
+		for (int m = 0; m < 9; m++)
+			k = s_key[lane][m] < k ? s_key[lane][m] : k;
+		best4 = (int)(k & 15u);
+		sum4 = (int)(k >> 4);
+	}
+	sum4 = wave_sum_i32(sum4);
+
+	// I16x16: each lane covers row lane>>2, columns 4*(lane&3)..+3
+	uint32_t best16 = 0xffffffffu;
+	{
+		const int py = lane >> 2, pxb = 4 * (lane & 3);
+		int sadv = 0, sadh = 0, sadd = 0, sadp = 0;
+		int dcsum = 0;
+		// DC
+		for (int k = 0; k < 16; k++)
+			dcsum += (top_mb ? s_t[1 + k] : 0) + (left_mb ? s_t[(1 + k) * TS] : 0);
+		const int dcv = (top_mb && left_mb) ? (dcsum + 16) >> 5 : (top_mb || left_mb) ? (dcsum + 8) >> 4 : 128;
+		// plane parameters
+		int H = 0, V = 0;
+		for (int k = 0; k < 8; k++) {
+			H += (k + 1) * ((int)s_t[1 + 8 + k] - (int)s_t[1 + 6 - k]);
+			V += (k + 1) * ((int)s_t[(1 + 8 + k) * TS] - (int)s_t[(1 + 6 - k) * TS]);
+		}
+		const int a = 16 * ((int)s_t[16 * TS] + (int)s_t[16]);
+		const int b = (5 * H + 32) >> 6, cc = (5 * V + 32) >> 6;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int px = pxb + k;
+			const int s = s_t[(1 + py) * TS + 1 + px];
+			sadv += iabs(s - (int)s_t[1 + px]);
+			sadh += iabs(s - (int)s_t[(1 + py) * TS]);
+			sadd += iabs(s - dcv);
+			sadp += iabs(s - clip255((a + b * (px - 7) + cc * (py - 7) + 16) >> 5));
+		}
+		sadv = wave_sum_i32(sadv);
+		sadh = wave_sum_i32(sadh);
+		sadd = wave_sum_i32(sadd);
+		sadp = wave_sum_i32(sadp);
+		if (top_mb)
+			best16 = ((uint32_t)sadv << 2) | 0u;
+		if (left_mb && (((uint32_t)sadh << 2) | 1u) < best16)
+			best16 = ((uint32_t)sadh << 2) | 1u;
+		if ((((uint32_t)sadd << 2) | 2u) < best16)
+			best16 = ((uint32_t)sadd << 2) | 2u;
+		if (top_mb && left_mb && (((uint32_t)sadp << 2) | 3u) < best16)
+			best16 = ((uint32_t)sadp << 2) | 3u;
+	}
+
+	// chroma: lane = sample (x = lane&7, y = lane>>3), both planes
+	uint32_t bestc = 0xffffffffu;
+	{
+		const int px = lane & 7, py = lane >> 3;
+		int sad[4] = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int c = 0; c < 2; c++) {
+			const uint8_t *T = s_c[c];
+			const int s = T[(1 + py) * 12 + 1 + px];
+			// DC per 4x4 sub-block
+			const int bx = px >> 2, by = py >> 2;
+			int stp = 0, slf = 0;
+			for (int k = 0; k < 4; k++) {
+				stp += T[1 + 4 * bx + k];
+				slf += T[(1 + 4 * by + k) * 12];
+			}
+			bool use_t = top_mb, use_l = left_mb;
+			if (bx == 1 && by == 0 && top_mb)
+				use_l = false;
+			if (bx == 0 && by == 1 && left_mb)
+				use_t = false;
+			const int dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
+			int H = 0, V = 0;
+			for (int k = 0; k < 4; k++) {
+				H += (k + 1) * ((int)T[1 + 4 + k] - (int)T[1 + 2 - k]);
+				V += (k + 1) * ((int)T[(1 + 4 + k) * 12] - (int)T[(1 + 2 - k) * 12]);
+			}
+			const int a = 16 * ((int)T[8 * 12] + (int)T[8]);
+			const int b = (34 * H + 32) >> 6, cc = (34 * V + 32) >> 6;
+			sad[0] += iabs(s - dcv);
+			sad[1] += iabs(s - (int)T[(1 + py) * 12]);
+			sad[2] += iabs(s - (int)T[1 + px]);
+			sad[3] += iabs(s - clip255((a + b * (px - 3) + cc * (py - 3) + 16) >> 5));
+		}
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			sad[m] = wave_sum_i32(sad[m]);
+		bestc = ((uint32_t)sad[0] << 2) | 0u;
+		if (left_mb && (((uint32_t)sad[1] << 2) | 1u) < bestc)
+			bestc = ((uint32_t)sad[1] << 2) | 1u;
+		if (top_mb && (((uint32_t)sad[2] << 2) | 2u) < bestc)
+			bestc = ((uint32_t)sad[2] << 2) | 2u;
+		if (top_mb && left_mb && (((uint32_t)sad[3] << 2) | 3u) < bestc)
+			bestc = ((uint32_t)sad[3] << 2) | 3u;
+	}
+
+	if (lane < 16)
+		p.i4modes[mbaddr * 16 + lane] = (int8_t)best4;
+	if (lane == 0) {
+		MbInfo m;
+		m.type = (sum4 + 32 * p.lambda < (int)(best16 >> 2)) ? MB_I4x4 : MB_I16x16;
+		m.i16_mode = (int8_t)(best16 & 3u);
+		m.chroma_mode = (int8_t)(bestc & 3u);
+		m.cbp = 0;
+		m.mvx = 0;
+		m.mvy = 0;
+		p.mbi[mbaddr] = m;
+	}
+}
+
+int Launch::intra_decide(const Params &p, void *stream)
+{
+	dim3 grid(p.mb_w, p.row_num, p.n_streams);
+	hipLaunchKernelGGL(k_intra_decide, grid, dim3(64), 0, (hipStream_t)stream, p);
+	return (int)hipGetLastError();
+}
+
+} // namespace cedar

@@ -1,0 +1,996 @@
+// cedarx_h264_encoder_amd/csrc/enc_session.cpp
+// Host side of the C-ABI (include/cedar_h264enc.h): what the reference does in
+// its ioctl handlers, minus the register poking.
+//   config validation + buffer manager   kernel/cedar.c:732-866, :605-704
+//   header bit-writer (SPS/PPS/slice)    kernel/cedar.c:187-223, :868-1030
+//   GOP counters, reference ping-pong    kernel/cedar.c:1047-1050, :1193-1201
+//   encode = program + trigger + wait    kernel/cedar.c:1032-1209
+// The "trigger + wait for IRQ" (cedar.c:1176-1180) becomes kernel launches on
+// two HIP streams (analysis/deblock and entropy) and an event wait.
+#include <errno.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/cedar_h264enc.h"
+#include "enc_internal.h"
+
+using namespace cedar;
+
+namespace {
+
+// ---- ITU-T H.264 constants needed on the host (clauses 8.5.9, 8.7.2) ----
+const uint16_t kQuantMF[6][3] = { // class 0 even/even, 1 odd/odd, 2 mixed
+	{ 13107, 5243, 8066 }, { 11916, 4660, 7490 }, { 10082, 4194, 6554 },
+	{ 9362, 3647, 5825 },  { 8192, 3355, 5243 },  { 7282, 2893, 4559 },
+};
+const uint8_t kDequantV[6][3] = {
+	{ 10, 16, 13 }, { 11, 18, 14 }, { 13, 20, 16 }, { 14, 23, 18 }, { 16, 25, 20 }, { 18, 29, 23 },
+};
+const uint8_t kChromaQp[52] = {
+	0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
+	26, 27, 28, 29, 29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39
+};
+const uint8_t kAlpha[52] = {
+	0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13,
+	15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255
+};
+const uint8_t kBeta[52] = {
+	0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+	6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18
+};
+const uint8_t kTc0[52][3] = {
+	{ 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 },
+	{ 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 },
+	{ 0, 0, 0 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 }, { 0, 1, 1 }, { 1, 1, 1 },
+	{ 1, 1, 1 }, { 1, 1, 1 }, { 1, 1, 1 }, { 1, 1, 2 }, { 1, 1, 2 }, { 1, 1, 2 }, { 1, 1, 2 }, { 1, 2, 3 },
+	{ 1, 2, 3 }, { 2, 2, 3 }, { 2, 2, 4 }, { 2, 3, 4 }, { 2, 3, 4 }, { 3, 3, 5 }, { 3, 4, 6 }, { 3, 4, 6 },
+	{ 4, 5, 7 }, { 4, 5, 8 }, { 4, 6, 9 }, { 5, 7, 10 }, { 6, 8, 11 }, { 6, 8, 13 }, { 7, 10, 14 }, { 8, 11, 16 },
+	{ 9, 12, 18 }, { 10, 13, 20 }, { 11, 15, 23 }, { 13, 17, 25 }
+};
+
+// encoder policy: Lagrangian weight round(2^((qp-12)/6)), >= 1
+int lambda_of_qp(int qp)
+{
+	static const uint8_t tab[52] = {
+		1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4,
+		5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91
+	};
+	return tab[qp < 0 ? 0 : qp > 51 ? 51 : qp];
+}
+
+inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// ---- put-bits: cedar_bytestream_write / _expgolomb / _expgolomb_signed ----
+struct BitWriter {
+	std::vector<uint8_t> buf;
+	uint64_t nbits = 0;
+	void put(uint32_t v, int n) // cedar.c:187-207
+	{
+		for (int i = n - 1; i >= 0; i--) {
+			if ((nbits & 7) == 0)
+				buf.push_back(0);
+			if ((v >> i) & 1)
+				buf.back() |= (uint8_t)(0x80 >> (nbits & 7));
+			nbits++;
+		}
+	}
+	void ue(uint32_t v) // cedar.c:209-215
+	{
+		v++;
+		int len = 0;
+		for (uint32_t t = v; t; t >>= 1)
+			len++;
+		put(v, 2 * len - 1);
+	}
+	void se(int32_t v) { ue(v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); } // cedar.c:217-223
+	void trailing() // standard rbsp_trailing_bits; cedar.c:883-890 has a stray-byte quirk
+	{
+		put(1, 1);
+		while (nbits & 7)
+			put(0, 1);
+	}
+};
+
+// NAL with 4-byte start code (cedar.c:868-881) and emulation prevention
+void append_nal(std::vector<uint8_t> &out, int ref_idc, int type, const std::vector<uint8_t> &rbsp)
+{
+	out.push_back(0);
+	out.push_back(0);
+	out.push_back(0);
+	out.push_back(1);
+	out.push_back((uint8_t)(((ref_idc & 3) << 5) | (type & 0x1f)));
+	int zeros = 0;
+	for (uint8_t b : rbsp) {
+		if (zeros == 2 && b <= 3) {
+			out.push_back(3);
+			zeros = 0;
+		}
+		out.push_back(b);
+		zeros = b == 0 ? zeros + 1 : 0;
+	}
+}
+
+struct Timing {
+	hipEvent_t ev[CEDAR_ENC_STAGE_COUNT][2];
+	bool used[CEDAR_ENC_STAGE_COUNT];
+};
+
+struct InFlight {
+	bool active = false;
+	bool idr = false;
+	int host_out = 0;      // which host output buffer receives this frame
+	uint32_t spec_bytes = 0; // bytes copied speculatively with the frame
+	bool with_ps = false;  // SPS+PPS precede this frame's slices
+	hipEvent_t done_main = nullptr, done_ent = nullptr;
+	SliceHdr *h_hdr = nullptr;   // pinned staging for the per-frame slice headers
+	uint32_t *h_prefix = nullptr;
+	Timing tm;
+};
+
+} // namespace
+
+struct cedar_enc {
+	bool configured = false; // cedar.c:744-747
+	int device = 0;
+	struct cedar_enc_config cfg{};
+	struct cedar_enc_config_ext ext{};
+	Params P{};
+	// GOP state (cedar.c:93-95)
+	int frame_count = 0, frame_p_count = 0;
+	int cur = 0; // reconstruction buffer being written (cedar.c:117-119)
+	int parity = 0;
+	int chroma_qp_offset = 4;
+	// device memory
+	uint8_t *d_in_y = nullptr, *d_in_uv = nullptr;
+	uint8_t **d_in_ptrs = nullptr; // [2*n_streams]
+	std::vector<const uint8_t *> h_in_ptrs;
+	bool in_ptrs_dirty = true;
+	uint8_t *d_src_y = nullptr, *d_src_uv = nullptr;
+	uint8_t *d_rec_y[2] = { nullptr, nullptr }, *d_rec_uv[2] = { nullptr, nullptr };
+	MbInfo *d_mbi[2] = { nullptr, nullptr };
+	int8_t *d_i4[2] = { nullptr, nullptr };
+	uint8_t *d_nnz[2] = { nullptr, nullptr };
+	int16_t *d_coef[2] = { nullptr, nullptr };
+	uint32_t *d_slot = nullptr, *d_mb_bits = nullptr;
+	uint8_t *d_skip = nullptr;
+	uint32_t *d_bit_off = nullptr, *d_run = nullptr, *d_unit_bits = nullptr;
+	uint8_t *d_rbsp = nullptr;
+	uint32_t *d_esc = nullptr, *d_nal_off = nullptr, *d_nal_size = nullptr, *d_stream_size = nullptr;
+	uint8_t *d_out = nullptr;
+	SliceHdr *d_hdr = nullptr;
+	uint32_t *d_prefix = nullptr;
+	uint8_t *d_pred4 = nullptr;
+	// pinned host memory
+	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
+	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = { nullptr, nullptr };
+	uint32_t *h_sizes[CEDAR_ENC_PIPELINE_DEPTH] = { nullptr, nullptr };
+	size_t out_cap = 0;
+	// streams / events
+	hipStream_t s_main = nullptr, s_ent = nullptr;
+	hipEvent_t ev_input = nullptr, ev_analysis = nullptr;
+	InFlight fl[CEDAR_ENC_PIPELINE_DEPTH];
+	int fl_head = 0, fl_count = 0; // ring of frames in flight
+	// results of the last collected frame
+	std::vector<uint32_t> res_off, res_size;
+	int res_host = 0;
+	int last_parity = 0, last_rec = 0;
+	std::vector<uint8_t> sps_pps;
+	// stats
+	bool profiling = false;
+	cedar_enc_stats stats{};
+	uint32_t last_total = 0;
+	char err[256] = { 0 };
+};
+
+namespace {
+
+int fail(cedar_enc *e, int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(e->err, sizeof(e->err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(e, call)                                                                  \
+	do {                                                                              \
+		hipError_t _r = (call);                                                   \
+		if (_r != hipSuccess)                                                     \
+			return fail((e), _r == hipErrorOutOfMemory ? -ENOMEM : -EIO, "%s: %s", #call, hipGetErrorString(_r)); \
+	} while (0)
+
+template <typename T>
+int dalloc(cedar_enc *e, T **p, size_t count)
+{
+	hipError_t r = hipMalloc((void **)p, count * sizeof(T) + 64);
+	if (r != hipSuccess)
+		return fail(e, -ENOMEM, "hipMalloc(%zu): %s", count * sizeof(T), hipGetErrorString(r));
+	hipMemset(*p, 0, count * sizeof(T) + 64);
+	return 0;
+}
+
+void free_all(cedar_enc *e)
+{
+	auto F = [](void *p) { if (p) hipFree(p); };
+	auto H = [](void *p) { if (p) hipHostFree(p); };
+	F(e->d_in_y); F(e->d_in_uv); F((void *)e->d_in_ptrs); F(e->d_src_y); F(e->d_src_uv);
+	for (int i = 0; i < 2; i++) {
+		F(e->d_rec_y[i]); F(e->d_rec_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
+	}
+	F(e->d_slot); F(e->d_mb_bits); F(e->d_skip); F(e->d_bit_off); F(e->d_run); F(e->d_unit_bits);
+	F(e->d_rbsp); F(e->d_esc); F(e->d_nal_off); F(e->d_nal_size); F(e->d_stream_size); F(e->d_out);
+	F(e->d_hdr); F(e->d_prefix); F(e->d_pred4);
+	H(e->h_luma); H(e->h_chroma);
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix);
+		if (e->fl[i].done_main)
+			hipEventDestroy(e->fl[i].done_main);
+		if (e->fl[i].done_ent)
+			hipEventDestroy(e->fl[i].done_ent);
+		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
+			for (int k = 0; k < 2; k++)
+				if (e->fl[i].tm.ev[s][k])
+					hipEventDestroy(e->fl[i].tm.ev[s][k]);
+	}
+	if (e->ev_input) hipEventDestroy(e->ev_input);
+	if (e->ev_analysis) hipEventDestroy(e->ev_analysis);
+	if (e->s_main) hipStreamDestroy(e->s_main);
+	if (e->s_ent) hipStreamDestroy(e->s_ent);
+}
+
+// SPS (cedar.c:892-937) + PPS (cedar.c:939-982)
+void build_sps_pps(cedar_enc *e)
+{
+	const struct cedar_enc_config &c = e->cfg;
+	BitWriter sps;
+	sps.put((uint32_t)c.profile, 8);
+	sps.put(0, 8); // constraint flags byte = 0 (cedar.c:898-899)
+	sps.put((uint32_t)c.level, 8);
+	sps.ue(0); // seq_parameter_set_id
+	sps.ue(0); // log2_max_frame_num_minus4
+	sps.ue(2); // pic_order_cnt_type
+	sps.ue(1); // max_num_ref_frames
+	sps.put(0, 1);
+	sps.ue((uint32_t)(c.dst_width / 16 - 1));
+	sps.ue((uint32_t)(c.dst_height / 16 - 1));
+	sps.put(1, 1); // frame_mbs_only_flag
+	sps.put(0, 1); // direct_8x8_inference_flag
+	if (c.dst_width != c.src_width || c.dst_height != c.src_height) {
+		// crop units of 2 luma samples (the reference writes raw pixels, cedar.c:924-931)
+		sps.put(1, 1);
+		sps.ue(0);
+		sps.ue((uint32_t)((c.dst_width - c.src_width) / 2));
+		sps.ue(0);
+		sps.ue((uint32_t)((c.dst_height - c.src_height) / 2));
+	} else {
+		sps.put(0, 1);
+	}
+	sps.put(0, 1); // vui_parameters_present_flag
+	sps.trailing();
+	BitWriter pps;
+	pps.ue(0);
+	pps.ue(0);
+	pps.put(0, 1); // entropy_coding_mode_flag = CAVLC
+	pps.put(0, 1);
+	pps.ue(0);
+	pps.ue(0);
+	pps.ue(0);
+	pps.put(0, 1);
+	pps.put(0, 2);
+	pps.se(c.qp - 26);
+	pps.se(c.qp - 26);
+	pps.se(e->chroma_qp_offset);
+	pps.put(1, 1); // deblocking_filter_control_present_flag
+	pps.put(0, 1);
+	pps.put(0, 1);
+	pps.trailing();
+	e->sps_pps.clear();
+	append_nal(e->sps_pps, 3, 7, sps.buf);
+	append_nal(e->sps_pps, 3, 8, pps.buf);
+}
+
+// slice header bits (cedar.c:984-1030)
+SliceHdr build_slice_header(const cedar_enc *e, bool idr, int frame_num, int idr_pic_id, int first_mb)
+{
+	BitWriter b;
+	b.ue((uint32_t)first_mb);   // reference: always 0 (cedar.c:992-993)
+	b.ue(idr ? 2 : 0);          // slice_type
+	b.ue(0);                    // pic_parameter_set_id
+	b.put((uint32_t)(frame_num & 0x0f), 4);
+	if (idr) {
+		b.ue((uint32_t)idr_pic_id);
+		b.put(0, 1);
+		b.put(0, 1);
+	} else {
+		b.put(0, 1);
+		b.put(0, 1);
+		b.put(0, 1);
+	}
+	b.se(0);                                  // slice_qp_delta
+	b.ue(e->ext.slice_count > 1 ? 2 : 0);     // disable_deblocking_filter_idc
+	b.se(0);
+	b.se(0);
+	SliceHdr h{};
+	h.nbits = (int32_t)b.nbits;
+	uint64_t v = 0;
+	for (uint64_t i = 0; i < b.nbits; i++)
+		v = (v << 1) | ((b.buf[i >> 3] >> (7 - (i & 7))) & 1);
+	h.bits = v;
+	return h;
+}
+
+void fill_static_params(cedar_enc *e)
+{
+	Params &P = e->P;
+	const struct cedar_enc_config &c = e->cfg;
+	P.width = c.src_width;
+	P.height = c.src_height;
+	P.cw = c.dst_width;
+	P.ch = c.dst_height;
+	P.mb_w = P.cw / 16;
+	P.mb_h = P.ch / 16;
+	P.n_mb = P.mb_w * P.mb_h;
+	P.n_streams = e->ext.n_streams;
+	P.slice_count = e->ext.slice_count;
+	P.slice_first = e->ext.slice_first;
+	P.slice_num = e->ext.slice_num;
+	int r0, r1, q0, q1;
+	slice_rows(P.mb_h, P.slice_count, P.slice_first, &r0, &r1);
+	slice_rows(P.mb_h, P.slice_count, P.slice_first + P.slice_num - 1, &q0, &q1);
+	P.row_first = r0;
+	P.row_num = q1 - r0;
+	P.qp = c.qp;
+	int qi = c.qp + e->chroma_qp_offset;
+	P.qpc = kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi];
+	P.search_range = e->ext.search_range;
+	P.lambda = lambda_of_qp(c.qp);
+	for (int k = 0; k < 3; k++) {
+		P.mf[k] = kQuantMF[P.qp % 6][k];
+		P.dv[k] = kDequantV[P.qp % 6][k];
+		P.mfc[k] = kQuantMF[P.qpc % 6][k];
+		P.dvc[k] = kDequantV[P.qpc % 6][k];
+		P.tc0_y[k] = kTc0[P.qp][k];
+		P.tc0_c[k] = kTc0[P.qpc][k];
+	}
+	P.qbits = 15 + P.qp / 6;
+	P.qshift = P.qp / 6;
+	P.qbits_c = 15 + P.qpc / 6;
+	P.qshift_c = P.qpc / 6;
+	P.alpha_y = kAlpha[P.qp];
+	P.beta_y = kBeta[P.qp];
+	P.alpha_c = kAlpha[P.qpc];
+	P.beta_c = kBeta[P.qpc];
+}
+
+double now_ms()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+} // namespace
+
+namespace cedar {
+
+void build_pred4_table(uint8_t tab[9 * 16])
+{
+	// E[0]=E[1]=l3 E[2]=l2 E[3]=l1 E[4]=l0 E[5]=tl E[6..13]=t0..t7 E[14]=t7
+	// kinds: 0 copy E[k]; 1 avg2(E[k],E[k+1]); 2 filt3 centred on E[k]; 3 DC   (clause 8.3.1.2)
+	for (int y = 0; y < 4; y++)
+		for (int x = 0; x < 4; x++) {
+			const int i = 4 * y + x;
+			auto set = [&](int mode, int kind, int k) { tab[mode * 16 + i] = (uint8_t)((kind << 4) | k); };
+			set(0, 0, 6 + x);
+			set(1, 0, 4 - y);
+			set(2, 3, 0);
+			set(3, 2, 7 + x + y);
+			set(4, 2, 5 + x - y);
+			{ // vertical-right
+				int z = 2 * x - y;
+				if (z >= 0 && !(z & 1)) set(5, 1, 5 + x - (y >> 1));
+				else if (z >= 0) set(5, 2, 5 + x - (y >> 1));
+				else if (z == -1) set(5, 2, 5);
+				else set(5, 2, 6 - y);
+			}
+			{ // horizontal-down
+				int z = 2 * y - x;
+				if (z >= 0 && !(z & 1)) set(6, 1, 4 - y + (x >> 1));
+				else if (z >= 0) set(6, 2, 5 - y + (x >> 1));
+				else if (z == -1) set(6, 2, 5);
+				else set(6, 2, 4 + x);
+			}
+			if (!(y & 1)) set(7, 1, 6 + x + (y >> 1));
+			else set(7, 2, 7 + x + (y >> 1));
+			{ // horizontal-up
+				int z = x + 2 * y, k = y + (x >> 1);
+				if (z > 5) set(8, 0, 1);
+				else if (z == 5) set(8, 2, 1);
+				else if (!(z & 1)) set(8, 1, 3 - k);
+				else set(8, 2, 3 - k);
+			}
+		}
+}
+
+} // namespace cedar
+
+// ======================================================================
+// C-ABI
+// ======================================================================
+
+extern "C" const char *cedar_enc_version(void)
+{
+	return "cedar_h264enc 0.1 (gfx950, HIP)";
+}
+
+extern "C" cedar_enc *cedar_enc_open(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+		errno = ENODEV; // no CPU fallback: the encode path exists only as HIP kernels
+		return nullptr;
+	}
+	cedar_enc *e = new (std::nothrow) cedar_enc();
+	if (!e)
+		errno = ENOMEM;
+	return e;
+}
+
+extern "C" const char *cedar_enc_last_error(cedar_enc *e)
+{
+	return e ? e->err : "null session";
+}
+
+extern "C" int cedar_enc_config(cedar_enc *e, struct cedar_enc_config *cfg)
+{
+	return cedar_enc_config_ext(e, cfg, nullptr);
+}
+
+extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
+{
+	if (!e)
+		return -EINVAL;
+	if (!cfg) // cedar.c:738-739
+		return fail(e, -EINVAL, "NULL config");
+	if (e->configured) // cedar.c:744-747
+		return fail(e, -EINVAL, "already configured");
+	struct cedar_enc_config_ext ext{};
+	if (ext_in) {
+		if (ext_in->size != (int)sizeof(struct cedar_enc_config_ext))
+			return fail(e, -EINVAL, "config_ext.size mismatch");
+		ext = *ext_in;
+	}
+	if (ext.n_streams == 0) ext.n_streams = 1;
+	if (ext.slice_count == 0) ext.slice_count = 1;
+	if (ext.slice_num == 0) { ext.slice_first = 0; ext.slice_num = ext.slice_count; }
+	ext.search_range = ext.search_range == 0 ? 16 : ext.search_range < 0 ? 0 : ext.search_range;
+	e->chroma_qp_offset = 4 + ext.chroma_qp_offset_minus4; // cedar.c:971-972
+	// cedar.c:749-789
+	if ((cfg->src_width & 1) || (cfg->src_height & 1) || cfg->src_width <= 0 || cfg->src_height <= 0)
+		return fail(e, -EINVAL, "src width %d, height %d not aligned", cfg->src_width, cfg->src_height);
+	if ((cfg->dst_width & 15) || (cfg->dst_height & 15))
+		return fail(e, -EINVAL, "dst width %d, height %d not aligned", cfg->dst_width, cfg->dst_height);
+	if (cfg->src_width > cfg->dst_width || cfg->src_height > cfg->dst_height)
+		return fail(e, -EINVAL, "src (%d,%d) > dst (%d,%d)", cfg->src_width, cfg->src_height, cfg->dst_width, cfg->dst_height);
+	if (cfg->dst_width != align_up(cfg->src_width, 16) || cfg->dst_height != align_up(cfg->src_height, 16))
+		return fail(e, -EINVAL, "dst must be src rounded up to 16 (no scaler on this path)");
+	if (cfg->qp <= 0 || cfg->qp > 47)
+		return fail(e, -EINVAL, "invalid QP %d", cfg->qp);
+	if (cfg->src_format != CEDAR_ENC_FORMAT_NV12)
+		return fail(e, -EINVAL, "invalid color format (nv12 only)");
+	if (cfg->keyframe_interval <= 0 || cfg->keyframe_interval >= 32)
+		return fail(e, -EINVAL, "invalid keyframe interval %d", cfg->keyframe_interval);
+	if (cfg->entropy_coding_mode != CEDAR_ENC_ENTROPY_CAVLC)
+		return fail(e, -EINVAL, "CABAC not supported: baseline/CAVLC only");
+	const int mb_h = cfg->dst_height / 16, mb_w = cfg->dst_width / 16;
+	if (ext.n_streams < 1 || ext.slice_count < 1 || ext.slice_count > mb_h || ext.slice_first < 0 ||
+	    ext.slice_num < 1 || ext.slice_first + ext.slice_num > ext.slice_count ||
+	    ext.n_streams * ext.slice_num > MAX_UNITS)
+		return fail(e, -EINVAL, "bad stream/slice layout");
+	if (ext.search_range < 0 || ext.search_range > 16)
+		return fail(e, -EINVAL, "search range %d outside 0..16", ext.search_range);
+	if (mb_h > 512 * ext.slice_count)
+		return fail(e, -EINVAL, "picture too tall for one slice");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ext.device < 0 || ext.device >= ndev)
+		return fail(e, -ENODEV, "HIP device %d not available", ext.device);
+	HIP_TRY(e, hipSetDevice(ext.device));
+	e->device = ext.device;
+	e->cfg = *cfg;
+	e->ext = ext;
+	fill_static_params(e);
+	Params &P = e->P;
+	const int S = ext.n_streams;
+	const int n_units = S * ext.slice_num;
+
+	// ---- buffer manager (cedar.c:605-704) ----
+	const int luma_sz = align_up(cfg->src_width * cfg->src_height, 4096);      // cedar.c:612
+	const int chroma_sz = align_up(cfg->src_width * cfg->src_height / 2, 4096); // cedar.c:621
+	// reference: fixed 1 MiB (cedar.c:663), which a 1080p IDR can overflow; size by macroblocks
+	int bs_sz = P.n_mb * 1024 + 4096;
+	if (bs_sz < (1 << 20)) bs_sz = 1 << 20;
+	e->out_cap = (size_t)bs_sz * S;
+	if (e->out_cap > 0x7fffffffULL)
+		return fail(e, -EINVAL, "too many streams for one session");
+	int rc = 0;
+	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S, hipHostMallocDefault));
+	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S, hipHostMallocDefault));
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap, hipHostMallocDefault));
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (S + 2) * sizeof(uint32_t), hipHostMallocDefault));
+	}
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * ext.slice_num, hipHostMallocDefault));
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocDefault));
+	}
+	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
+	P.plane_y_stride = (int64_t)plane_y;
+	P.plane_uv_stride = (int64_t)plane_uv;
+	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S))) return rc;
+	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S))) return rc;
+	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S))) return rc;
+	if ((rc = dalloc(e, &e->d_src_y, plane_y * S))) return rc;
+	if ((rc = dalloc(e, &e->d_src_uv, plane_uv * S))) return rc;
+	for (int i = 0; i < 2; i++) {
+		if ((rc = dalloc(e, &e->d_rec_y[i], plane_y * S))) return rc;
+		if ((rc = dalloc(e, &e->d_rec_uv[i], plane_uv * S))) return rc;
+		if ((rc = dalloc(e, &e->d_mbi[i], (size_t)P.n_mb * S))) return rc;
+		if ((rc = dalloc(e, &e->d_i4[i], (size_t)P.n_mb * S * 16))) return rc;
+		if ((rc = dalloc(e, &e->d_nnz[i], (size_t)P.n_mb * S * NNZ_PER_MB))) return rc;
+		if ((rc = dalloc(e, &e->d_coef[i], (size_t)P.n_mb * S * COEF_PER_MB))) return rc;
+	}
+	if ((rc = dalloc(e, &e->d_slot, (size_t)P.n_mb * S * SLOT_WORDS))) return rc;
+	if ((rc = dalloc(e, &e->d_mb_bits, (size_t)P.n_mb * S))) return rc;
+	if ((rc = dalloc(e, &e->d_skip, (size_t)P.n_mb * S))) return rc;
+	int max_rows = 0;
+	for (int s = ext.slice_first; s < ext.slice_first + ext.slice_num; s++) {
+		int a, b;
+		slice_rows(P.mb_h, P.slice_count, s, &a, &b);
+		if (b - a > max_rows) max_rows = b - a;
+	}
+	P.unit_mb_cap = max_rows * mb_w;
+	P.rbsp_cap = align_up(P.unit_mb_cap * 1024 + 4096, 256);
+	P.esc_chunks_cap = P.rbsp_cap / ESC_CHUNK;
+	P.out_cap = (int32_t)e->out_cap;
+	if ((rc = dalloc(e, &e->d_bit_off, (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
+	if ((rc = dalloc(e, &e->d_run, (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
+	if ((rc = dalloc(e, &e->d_unit_bits, (size_t)n_units))) return rc;
+	if ((rc = dalloc(e, &e->d_rbsp, (size_t)n_units * P.rbsp_cap))) return rc;
+	if ((rc = dalloc(e, &e->d_esc, (size_t)n_units * P.esc_chunks_cap))) return rc;
+	if ((rc = dalloc(e, &e->d_nal_off, (size_t)n_units))) return rc;
+	if ((rc = dalloc(e, &e->d_nal_size, (size_t)n_units))) return rc;
+	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 2))) return rc;
+	if ((rc = dalloc(e, &e->d_out, e->out_cap))) return rc;
+	if ((rc = dalloc(e, &e->d_hdr, (size_t)ext.slice_num))) return rc;
+	if ((rc = dalloc(e, &e->d_prefix, (size_t)S))) return rc;
+	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
+	uint8_t tab[9 * 16];
+	build_pred4_table(tab);
+	HIP_TRY(e, hipMemcpy(e->d_pred4, tab, sizeof(tab), hipMemcpyHostToDevice));
+	e->h_in_ptrs.assign((size_t)2 * S, nullptr);
+	for (int s = 0; s < S; s++) {
+		e->h_in_ptrs[s] = e->d_in_y + (size_t)s * luma_sz;
+		e->h_in_ptrs[S + s] = e->d_in_uv + (size_t)s * chroma_sz;
+	}
+	e->in_ptrs_dirty = true;
+
+	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
+	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming));
+	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis, hipEventDisableTiming));
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
+		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_ent, hipEventDisableTiming));
+		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
+			for (int k = 0; k < 2; k++)
+				HIP_TRY(e, hipEventCreate(&e->fl[i].tm.ev[s][k]));
+	}
+	HIP_TRY(e, hipDeviceSynchronize());
+
+	// static device pointers
+	P.in_luma = (const uint8_t *const *)e->d_in_ptrs;
+	P.in_chroma = (const uint8_t *const *)(e->d_in_ptrs + S);
+	P.src_y = e->d_src_y;
+	P.src_uv = e->d_src_uv;
+	P.slot = e->d_slot;
+	P.mb_bits = e->d_mb_bits;
+	P.skip = e->d_skip;
+	P.mvd = nullptr;
+	P.bit_off = e->d_bit_off;
+	P.run_before = e->d_run;
+	P.unit_bits = e->d_unit_bits;
+	P.rbsp = e->d_rbsp;
+	P.esc_cnt = e->d_esc;
+	P.nal_off = e->d_nal_off;
+	P.nal_size = e->d_nal_size;
+	P.stream_size = e->d_stream_size;
+	P.out = e->d_out;
+	P.hdr = e->d_hdr;
+	P.prefix_len = e->d_prefix;
+	P.pred4_tab = e->d_pred4;
+
+	build_sps_pps(e);
+	e->frame_count = 0; // cedar.c:815-816
+	e->frame_p_count = 0;
+	e->res_off.assign(S, 0);
+	e->res_size.assign(S, 0);
+	e->configured = true;
+
+	// outputs (cedar.c:840-860), host pointers instead of DMA addresses
+	cfg->input_luma = e->h_luma;
+	cfg->input_luma_size = luma_sz;
+	cfg->input_chroma = e->h_chroma;
+	cfg->input_chroma_size = chroma_sz;
+	cfg->bytestream = e->h_out[0];
+	cfg->bytestream_size = bs_sz;
+	cfg->thumbnail = 0;
+	cfg->thumb_luma = nullptr;
+	cfg->thumb_luma_size = 0;
+	cfg->thumb_chroma = nullptr;
+	cfg->thumb_chroma_size = 0;
+	e->cfg = *cfg;
+	return 0;
+}
+
+extern "C" int cedar_enc_set_device_input(cedar_enc *e, int stream, const void *d_luma, const void *d_chroma)
+{
+	if (!e || !e->configured || stream < 0 || stream >= e->ext.n_streams)
+		return -EINVAL;
+	const int S = e->ext.n_streams;
+	if (d_luma && d_chroma) {
+		e->h_in_ptrs[stream] = (const uint8_t *)d_luma;
+		e->h_in_ptrs[S + stream] = (const uint8_t *)d_chroma;
+	} else {
+		e->h_in_ptrs[stream] = e->d_in_y + (size_t)stream * e->cfg.input_luma_size;
+		e->h_in_ptrs[S + stream] = e->d_in_uv + (size_t)stream * e->cfg.input_chroma_size;
+	}
+	e->in_ptrs_dirty = true;
+	return 0;
+}
+
+static void tm_begin(cedar_enc *e, InFlight &f, int stage, hipStream_t s)
+{
+	if (e->profiling) {
+		hipEventRecord(f.tm.ev[stage][0], s);
+		f.tm.used[stage] = true;
+	}
+}
+static void tm_end(cedar_enc *e, InFlight &f, int stage, hipStream_t s)
+{
+	if (e->profiling)
+		hipEventRecord(f.tm.ev[stage][1], s);
+}
+
+extern "C" int cedar_enc_submit(cedar_enc *e)
+{
+	if (!e)
+		return -EINVAL;
+	if (!e->configured) // cedar.c:1039-1043
+		return fail(e, -EINVAL, "CONFIG not run yet");
+	if (e->fl_count >= CEDAR_ENC_PIPELINE_DEPTH)
+		return fail(e, -EBUSY, "pipeline full: collect first");
+	const double t0 = now_ms();
+	HIP_TRY(e, hipSetDevice(e->device));
+	const int S = e->ext.n_streams;
+	const int slot = (e->fl_head + e->fl_count) % CEDAR_ENC_PIPELINE_DEPTH;
+	InFlight &f = e->fl[slot];
+	memset(f.tm.used, 0, sizeof(f.tm.used));
+	// frames in flight were submitted in order, so counters advance at submit
+	const bool idr = e->frame_p_count == 0; // cedar.c:1047-1050
+	const int par = e->parity;
+	Params P = e->P;
+	P.is_idr = idr;
+	P.rec_y = e->d_rec_y[e->cur];
+	P.rec_uv = e->d_rec_uv[e->cur];
+	P.ref_y = e->d_rec_y[e->cur ^ 1];
+	P.ref_uv = e->d_rec_uv[e->cur ^ 1];
+	P.mbi = e->d_mbi[par];
+	P.i4modes = e->d_i4[par];
+	P.nnz = e->d_nnz[par];
+	P.coef = e->d_coef[par];
+	P.nal_ref_idc = idr ? 3 : 2; // cedar.c:987-990
+	P.nal_type = idr ? 5 : 1;
+
+	// ---- input: H2D of the pinned buffers unless the caller supplied device frames ----
+	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, e->s_main);
+	bool any_host = false;
+	for (int s = 0; s < S; s++) {
+		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
+		if (e->h_in_ptrs[s] == own) {
+			any_host = true;
+			HIP_TRY(e, hipMemcpyAsync((void *)own, e->h_luma + (size_t)s * e->cfg.input_luma_size,
+						  (size_t)P.width * P.height, hipMemcpyHostToDevice, e->s_main));
+			HIP_TRY(e, hipMemcpyAsync(e->d_in_uv + (size_t)s * e->cfg.input_chroma_size,
+						  e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
+						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, e->s_main));
+		}
+	}
+	if (e->in_ptrs_dirty) {
+		HIP_TRY(e, hipMemcpyAsync((void *)e->d_in_ptrs, e->h_in_ptrs.data(), sizeof(void *) * 2 * S,
+					  hipMemcpyHostToDevice, e->s_main));
+		e->in_ptrs_dirty = false;
+	}
+	if (any_host)
+		HIP_TRY(e, hipEventRecord(e->ev_input, e->s_main));
+	if (Launch::input(P, e->s_main))
+		return fail(e, -EIO, "k_input launch failed");
+	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, e->s_main);
+
+	// ---- analysis + reconstruction ----
+	if (idr) {
+		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, e->s_main);
+		if (Launch::intra_decide(P, e->s_main))
+			return fail(e, -EIO, "k_intra_decide launch failed");
+		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, e->s_main);
+		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_RECON, e->s_main);
+		if (Launch::intra_recon(P, e->s_main))
+			return fail(e, -EIO, "k_intra_recon launch failed");
+		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_RECON, e->s_main);
+	} else {
+		tm_begin(e, f, CEDAR_ENC_STAGE_INTER, e->s_main);
+		if (Launch::inter(P, e->s_main))
+			return fail(e, -EIO, "k_inter launch failed");
+		tm_end(e, f, CEDAR_ENC_STAGE_INTER, e->s_main);
+	}
+	HIP_TRY(e, hipEventRecord(e->ev_analysis, e->s_main));
+
+	// ---- entropy coding on its own stream, concurrent with deblocking ----
+	const int idr_pic_id = (e->frame_count / e->cfg.keyframe_interval) & 1;
+	for (int k = 0; k < e->ext.slice_num; k++) {
+		int r0, r1;
+		slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
+		f.h_hdr[k] = build_slice_header(e, idr, e->frame_p_count, idr_pic_id, r0 * P.mb_w);
+	}
+	const bool with_ps = e->frame_count == 0 && e->ext.slice_first == 0; // cedar.c:1058-1061
+	f.with_ps = with_ps;
+	for (int s = 0; s < S; s++)
+		f.h_prefix[s] = with_ps ? (uint32_t)e->sps_pps.size() : 0;
+	HIP_TRY(e, hipStreamWaitEvent(e->s_ent, e->ev_analysis, 0));
+	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
+	HIP_TRY(e, hipMemcpyAsync(e->d_hdr, f.h_hdr, sizeof(SliceHdr) * e->ext.slice_num, hipMemcpyHostToDevice, e->s_ent));
+	HIP_TRY(e, hipMemcpyAsync(e->d_prefix, f.h_prefix, sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->s_ent));
+	HIP_TRY(e, hipMemsetAsync(e->d_stream_size, 0, sizeof(uint32_t) * (S + 2), e->s_ent));
+	if (Launch::entropy(P, e->s_ent))
+		return fail(e, -EIO, "entropy launch failed");
+	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
+	f.host_out = e->fl_count; // one frame in flight (plain encode) always lands in buffer 0
+	uint32_t spec = e->last_total ? e->last_total * 2 + 65536 : 262144;
+	if (idr && spec < 1u << 20)
+		spec = 1u << 20;
+	if (spec > e->out_cap)
+		spec = (uint32_t)e->out_cap;
+	f.spec_bytes = spec;
+	HIP_TRY(e, hipMemcpyAsync(e->h_sizes[slot], e->d_stream_size, sizeof(uint32_t) * (S + 2), hipMemcpyDeviceToHost, e->s_ent));
+	HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out], e->d_out, spec, hipMemcpyDeviceToHost, e->s_ent));
+	HIP_TRY(e, hipEventRecord(f.done_ent, e->s_ent));
+
+	// ---- in-loop deblocking: produces the next frame's reference ----
+	tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
+	if (Launch::deblock(P, e->s_main))
+		return fail(e, -EIO, "k_deblock launch failed");
+	tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
+	// the frame is complete when both streams are (collect waits for both events)
+	HIP_TRY(e, hipEventRecord(f.done_main, e->s_main));
+
+	f.active = true;
+	f.idr = idr;
+	e->fl_count++;
+	e->last_parity = par;
+	e->last_rec = e->cur;
+	// cedar.c:1193-1201: advance the GOP counter, swap reference frames
+	e->frame_p_count++;
+	if (e->frame_p_count == e->cfg.keyframe_interval)
+		e->frame_p_count = 0;
+	e->frame_count++;
+	e->cur ^= 1;
+	e->parity ^= 1;
+	if (any_host) // the caller may refill the pinned input buffers once they are on the device
+		HIP_TRY(e, hipEventSynchronize(e->ev_input));
+	e->stats.encode_wall_ms += now_ms() - t0;
+	return 0;
+}
+
+extern "C" int cedar_enc_collect(cedar_enc *e)
+{
+	if (!e || !e->configured)
+		return -EINVAL;
+	if (e->fl_count == 0)
+		return fail(e, -EINVAL, "nothing in flight");
+	const double t0 = now_ms();
+	const int S = e->ext.n_streams;
+	const int slot = e->fl_head;
+	InFlight &f = e->fl[slot];
+	HIP_TRY(e, hipSetDevice(e->device));
+	HIP_TRY(e, hipEventSynchronize(f.done_ent));
+	HIP_TRY(e, hipEventSynchronize(f.done_main));
+	e->fl_head = (e->fl_head + 1) % CEDAR_ENC_PIPELINE_DEPTH;
+	e->fl_count--;
+	f.active = false;
+	const uint32_t *sz = e->h_sizes[slot];
+	const uint32_t total = sz[S], flags = sz[S + 1];
+	if (flags || total > e->out_cap)
+		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
+	if (total > f.spec_bytes) {
+		HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out] + f.spec_bytes, e->d_out + f.spec_bytes,
+					  total - f.spec_bytes, hipMemcpyDeviceToHost, e->s_ent));
+		HIP_TRY(e, hipStreamSynchronize(e->s_ent));
+	}
+	uint32_t off = 0;
+	for (int s = 0; s < S; s++) {
+		e->res_off[s] = off;
+		e->res_size[s] = sz[s];
+		if (f.with_ps)
+			memcpy(e->h_out[f.host_out] + off, e->sps_pps.data(), e->sps_pps.size());
+		off += sz[s];
+	}
+	e->res_host = f.host_out;
+	e->last_total = total;
+	if (e->profiling) {
+		for (int st = 0; st < CEDAR_ENC_STAGE_COUNT; st++)
+			if (f.tm.used[st]) {
+				float ms = 0;
+				if (hipEventElapsedTime(&ms, f.tm.ev[st][0], f.tm.ev[st][1]) == hipSuccess) {
+					e->stats.ms[st] += ms;
+					e->stats.launches[st]++;
+				}
+			}
+	}
+	e->stats.frames++;
+	e->stats.encode_wall_ms += now_ms() - t0;
+	return (int)total; // cedar.c:1207-1208: bytes now valid at bytestream offset 0
+}
+
+extern "C" int cedar_enc_encode(cedar_enc *e)
+{
+	if (!e)
+		return -EINVAL;
+	if (e->fl_count != 0)
+		return fail(e, -EBUSY, "frames in flight: collect them before a synchronous encode");
+	// a failed encode leaves GOP counters and reference frames untouched
+	// (cedar.c:1182-1191 return before :1193-1201)
+	const int fc = e->frame_count, fpc = e->frame_p_count, cur = e->cur, par = e->parity;
+	int r = cedar_enc_submit(e);
+	if (r >= 0)
+		r = cedar_enc_collect(e);
+	if (r < 0) {
+		if (e->configured) {
+			hipDeviceSynchronize();
+			e->fl_count = 0;
+			e->fl_head = 0;
+		}
+		e->frame_count = fc;
+		e->frame_p_count = fpc;
+		e->cur = cur;
+		e->parity = par;
+	}
+	return r;
+}
+
+extern "C" int cedar_enc_stream_output(cedar_enc *e, int stream, const uint8_t **data, int *size)
+{
+	if (!e || !e->configured || stream < 0 || stream >= e->ext.n_streams)
+		return -EINVAL;
+	if (data)
+		*data = e->h_out[e->res_host] + e->res_off[stream];
+	if (size)
+		*size = (int)e->res_size[stream];
+	return 0;
+}
+
+extern "C" void cedar_enc_close(cedar_enc *e)
+{
+	if (!e)
+		return;
+	if (e->configured) {
+		hipSetDevice(e->device);
+		hipDeviceSynchronize();
+	}
+	free_all(e);
+	delete e;
+}
+
+extern "C" int cedar_enc_set_profiling(cedar_enc *e, int on)
+{
+	if (!e)
+		return -EINVAL;
+	e->profiling = on != 0;
+	return 0;
+}
+
+extern "C" int cedar_enc_get_stats(cedar_enc *e, struct cedar_enc_stats *out)
+{
+	if (!e || !out)
+		return -EINVAL;
+	*out = e->stats;
+	return 0;
+}
+
+extern "C" int cedar_enc_reset_stats(cedar_enc *e)
+{
+	if (!e)
+		return -EINVAL;
+	memset(&e->stats, 0, sizeof(e->stats));
+	return 0;
+}
+
+extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *dst, int dst_size)
+{
+	if (!e || !e->configured || !dst || stream < 0 || stream >= e->ext.n_streams)
+		return -EINVAL;
+	if (e->fl_count)
+		return fail(e, -EBUSY, "frames in flight");
+	const Params &P = e->P;
+	const void *src = nullptr;
+	size_t n = 0;
+	const int par = e->last_parity, rec = e->last_rec;
+	switch (what) {
+	case CEDAR_ENC_DBG_MBINFO: src = e->d_mbi[par] + (size_t)stream * P.n_mb; n = sizeof(MbInfo) * P.n_mb; break;
+	case CEDAR_ENC_DBG_I4MODES: src = e->d_i4[par] + (size_t)stream * P.n_mb * 16; n = (size_t)16 * P.n_mb; break;
+	case CEDAR_ENC_DBG_NNZ: src = e->d_nnz[par] + (size_t)stream * P.n_mb * NNZ_PER_MB; n = (size_t)NNZ_PER_MB * P.n_mb; break;
+	case CEDAR_ENC_DBG_COEF: src = e->d_coef[par] + (size_t)stream * P.n_mb * COEF_PER_MB; n = (size_t)2 * COEF_PER_MB * P.n_mb; break;
+	case CEDAR_ENC_DBG_RECON_Y: src = e->d_rec_y[rec] + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
+	case CEDAR_ENC_DBG_RECON_UV: src = e->d_rec_uv[rec] + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
+	case CEDAR_ENC_DBG_SRC_Y: src = e->d_src_y + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
+	case CEDAR_ENC_DBG_SRC_UV: src = e->d_src_uv + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
+	case CEDAR_ENC_DBG_MB_BITS: src = e->d_mb_bits + (size_t)stream * P.n_mb; n = sizeof(uint32_t) * P.n_mb; break;
+	default: return -EINVAL;
+	}
+	if ((size_t)dst_size < n)
+		return fail(e, -ENOSPC, "debug buffer needs %zu bytes", n);
+	HIP_TRY(e, hipSetDevice(e->device));
+	HIP_TRY(e, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+extern "C" void cedar_enc_gen_pattern(int pattern, int w, int h, int frame, unsigned seed_offset,
+				      uint8_t *luma, uint8_t *chroma)
+{
+	// 'A' static thumb-style picture (userspace/thumb.c:139-169 idea),
+	// 'B' moving texture with global motion (3,2), 'C' LCG noise
+	if (pattern == 'A') {
+		for (int y = 0; y < h; y++)
+			for (int x = 0; x < w; x++)
+				luma[(size_t)y * w + x] = (x < 4 || y < 4 || x >= w - 4 || y >= h - 4) ? 0xEB : 0x10;
+		for (int y = 0; y < h / 2; y++)
+			for (int x = 0; x < w / 2; x++) {
+				chroma[(size_t)y * w + 2 * x] = (uint8_t)x;
+				chroma[(size_t)y * w + 2 * x + 1] = (uint8_t)y;
+			}
+	} else if (pattern == 'B') {
+		uint32_t s = 0x5EED0000u + (uint32_t)frame + seed_offset;
+		for (int y = 0; y < h; y++) {
+			const int v = y + 2 * frame;
+			uint8_t *row = luma + (size_t)y * w;
+			for (int x = 0; x < w; x++) {
+				const int u = x + 3 * frame;
+				s = s * 1664525u + 1013904223u;
+				row[x] = (uint8_t)(5 * u + 3 * v + 17 * ((u >> 4) ^ (v >> 4)) + (int)(s >> 29));
+			}
+		}
+		for (int y = 0; y < h / 2; y++)
+			for (int x = 0; x < w / 2; x++) {
+				const int u = 2 * x + 3 * frame, v = 2 * y + 2 * frame;
+				chroma[(size_t)y * w + 2 * x] = (uint8_t)(128 + ((u >> 1) & 63) - 32);
+				chroma[(size_t)y * w + 2 * x + 1] = (uint8_t)(128 + ((v >> 1) & 63) - 32);
+			}
+	} else {
+		uint32_t s = 0xC0FFEE00u + (uint32_t)frame + seed_offset;
+		const size_t n = (size_t)w * h;
+		for (size_t i = 0; i < n; i++) {
+			s = s * 1664525u + 1013904223u;
+			luma[i] = (uint8_t)(s >> 24);
+		}
+		for (size_t i = 0; i < n / 2; i++) {
+			s = s * 1664525u + 1013904223u;
+			chroma[i] = (uint8_t)(s >> 24);
+		}
+	}
+}

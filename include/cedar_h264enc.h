@@ -1,0 +1,181 @@
+/*
+ * include/cedar_h264enc.h -- C-ABI of the MI355X-native H.264 encode path.
+ *
+ * Drop-in boundary for the character-device session of libv/cedarx_h264_encoder
+ * (reference: kernel/cedar_ioctl.h:1-48, kernel/cedar.c:1293-1300, caller
+ * userspace/h264enc.c:47-117, 149, 189). The five verbs of that session
+ *
+ *     open("/dev/cedar_dev")  ioctl(CONFIG)  mmap x3  ioctl(ENCODE)  close
+ *
+ * map one-to-one to the entry points below. Plain C types only; the library
+ * (libcedar_h264enc.so) owns every buffer, exactly as the driver does
+ * (kernel/cedar.c:605-704), and hands back HOST pointers where the driver
+ * hands back DMA addresses to mmap.
+ *
+ * What replaces the silicon (kernel/cedar.c:1176 STARTTRIG=0x08 .. :1178 IRQ
+ * wait) is a per-macroblock HIP pipeline on gfx950; there is no CPU fallback:
+ * every call fails with -ENODEV when no HIP device is usable.
+ */
+#ifndef CEDAR_H264ENC_H
+#define CEDAR_H264ENC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel/cedar_ioctl.h:15-16, 30-31 */
+#define CEDAR_ENC_FORMAT_NV12 0
+#define CEDAR_ENC_FORMAT_NV16 1 /* accepted by the reference's validation, never
+				   programmed (cedar.c:1076); rejected here */
+#define CEDAR_ENC_ENTROPY_CAVLC 0
+#define CEDAR_ENC_ENTROPY_CABAC 1 /* reference default (h264enc.c:66); rejected here
+				     with -EINVAL: north_star fixes baseline + CAVLC */
+
+/*
+ * Replaces struct cedar_ioctl_config (kernel/cedar_ioctl.h:12-46): same
+ * fields, same order, same in/out meaning; the uint32_t *_dma_addr outputs
+ * become host pointers valid until cedar_enc_close().
+ */
+struct cedar_enc_config {
+	/* in */
+	int src_width;          /* even (cedar.c:749)                        */
+	int src_height;         /* even                                      */
+	int src_format;         /* CEDAR_ENC_FORMAT_NV12                     */
+	int dst_width;          /* multiple of 16, >= src (cedar.c:756-769)  */
+	int dst_height;
+	int profile;            /* profile_idc, 66                           */
+	int level;              /* level_idc, 41 / 51                        */
+	int qp;                 /* 1..47 (cedar.c:771)                       */
+	int keyframe_interval;  /* 1..31 (cedar.c:784)                       */
+	int thumbnail;          /* in: ignored; out: always 0 (out of scope) */
+	int thumbnail_downscale;
+	int entropy_coding_mode;/* CEDAR_ENC_ENTROPY_CAVLC                   */
+	/* out (cedar.c:840-860) */
+	uint8_t *input_luma;    /* src_width*src_height bytes per stream, tightly packed */
+	int input_luma_size;    /* bytes per stream, ALIGN(.,4096) (cedar.c:612) */
+	uint8_t *input_chroma;  /* src_width*src_height/2 bytes, interleaved CbCr */
+	int input_chroma_size;
+	uint8_t *bytestream;    /* Annex-B output of the last cedar_enc_encode() */
+	int bytestream_size;    /* capacity per stream (reference: fixed 1 MiB, cedar.c:663) */
+	uint8_t *thumb_luma;    /* always NULL / 0 */
+	int thumb_luma_size;
+	uint8_t *thumb_chroma;
+	int thumb_chroma_size;
+};
+
+/*
+ * Extensions with no counterpart in the reference (which is one device, one
+ * session, one slice). Zero-initialise, set .size = sizeof, fill what you need.
+ */
+struct cedar_enc_config_ext {
+	int size;            /* sizeof(struct cedar_enc_config_ext)                   */
+	int device;          /* HIP device ordinal (default 0)                        */
+	int n_streams;       /* lock-step streams of identical geometry batched into
+				the same kernel launches (default 1). Stream s uses
+				input_luma + s*input_luma_size, etc.                  */
+	int slice_count;     /* slices per picture, bands of MB rows (default 1);
+				> 1 sets disable_deblocking_filter_idc = 2            */
+	int slice_first;     /* this session encodes slices [slice_first,             */
+	int slice_num;       /*   slice_first+slice_num) only (0 = all): lets 4 GPUs
+				each take one slice of a 4K picture, no collective    */
+	int search_range;    /* full-pel motion search radius 1..16; 0 = default (16),
+				-1 = zero-vector only                                 */
+	int chroma_qp_offset_minus4; /* chroma_qp_index_offset - 4: 0 keeps the reference's
+				+4 (cedar.c:971-972, :1165-1168)                      */
+	int reserved[8];
+};
+
+typedef struct cedar_enc cedar_enc;
+
+/* open(CEDAR_DEVICE_PATH, O_RDWR) -- h264enc.c:149, cedar.c:457-474.
+ * Returns NULL when no usable HIP device exists (errno = ENODEV). */
+cedar_enc *cedar_enc_open(void);
+
+/* ioctl(fd, CEDAR_IOCTL_CONFIG, &cfg) -- cedar.c:732-866. Returns 0 or a
+ * negative errno: -EINVAL (bad parameter, NULL, already configured), -ENOMEM,
+ * -ENODEV. One-shot per open (cedar.c:744-747). */
+int cedar_enc_config(cedar_enc *enc, struct cedar_enc_config *cfg);
+int cedar_enc_config_ext(cedar_enc *enc, struct cedar_enc_config *cfg,
+			 const struct cedar_enc_config_ext *ext);
+
+/* ioctl(fd, CEDAR_IOCTL_ENCODE, NULL) -- cedar.c:1032-1209. Encodes the frame
+ * currently in the input buffers (of every stream). Synchronous. Returns the
+ * number of bytes now valid at bytestream offset 0 of stream 0 (n_streams == 1:
+ * the reference contract), or the total over all streams when batching; < 0 is a
+ * negative errno and leaves GOP counters and reference frames untouched
+ * (cedar.c:1182-1191 return before :1193-1201). Output of call n =
+ * [SPS PPS if n == 0] + one slice NAL per encoded slice (cedar.c:1058-1066). */
+int cedar_enc_encode(cedar_enc *enc);
+
+/* close(fd) -- cedar.c:706-730 */
+void cedar_enc_close(cedar_enc *enc);
+
+/* ---- extensions (no reference counterpart) ---- */
+
+/* per-stream result of the last encode: pointer into the bytestream buffer */
+int cedar_enc_stream_output(cedar_enc *enc, int stream, const uint8_t **data, int *size);
+
+/* Use frames already resident in HBM as the next input of `stream` (tightly
+ * packed src_width x src_height nv12, device pointers on the session's device)
+ * instead of copying from the pinned input buffers. NULL restores the default. */
+int cedar_enc_set_device_input(cedar_enc *enc, int stream, const void *d_luma, const void *d_chroma);
+
+/* Pipelined form of encode for throughput: submit queues one frame for every
+ * stream without waiting; collect waits for the oldest submitted frame and
+ * returns its byte count (same meaning as cedar_enc_encode). At most
+ * CEDAR_ENC_PIPELINE_DEPTH frames may be in flight. cedar_enc_encode ==
+ * submit + collect. */
+#define CEDAR_ENC_PIPELINE_DEPTH 2
+int cedar_enc_submit(cedar_enc *enc);
+int cedar_enc_collect(cedar_enc *enc);
+
+/* Timing of the kernels, measured with hipEvents on the stream they run on
+ * (replaces the driver's "Time spent" accounting, cedar.c:715-719, :1203-1205). */
+enum cedar_enc_stage {
+	CEDAR_ENC_STAGE_INPUT = 0,   /* H2D + pad                      */
+	CEDAR_ENC_STAGE_INTRA_DECIDE,
+	CEDAR_ENC_STAGE_INTRA_RECON,
+	CEDAR_ENC_STAGE_INTER,       /* ME + residual + recon          */
+	CEDAR_ENC_STAGE_DEBLOCK,
+	CEDAR_ENC_STAGE_ENTROPY,     /* CAVLC + scan + pack + escape   */
+	CEDAR_ENC_STAGE_COUNT
+};
+struct cedar_enc_stats {
+	uint64_t frames;                         /* frames encoded (per stream)   */
+	uint64_t launches[CEDAR_ENC_STAGE_COUNT];/* kernel launches per stage     */
+	double   ms[CEDAR_ENC_STAGE_COUNT];      /* summed GPU time per stage     */
+	double   encode_wall_ms;                 /* host wall time inside encode  */
+};
+int cedar_enc_set_profiling(cedar_enc *enc, int on); /* event timing on/off (default off) */
+int cedar_enc_get_stats(cedar_enc *enc, struct cedar_enc_stats *out);
+int cedar_enc_reset_stats(cedar_enc *enc);
+
+/* test hook: copy an internal device array of the last encoded frame to host.
+ * Returns bytes copied or negative errno. */
+enum cedar_enc_debug_buf {
+	CEDAR_ENC_DBG_MBINFO = 0, /* struct { int8 type,i16,chroma,cbp; int16 mvx,mvy; } per MB */
+	CEDAR_ENC_DBG_I4MODES,    /* int8[16] per MB, coding-order index                       */
+	CEDAR_ENC_DBG_NNZ,        /* uint8[24] per MB                                          */
+	CEDAR_ENC_DBG_COEF,       /* int16[408] per MB: luma[16][16] dc16[16] cdc[2][4] cac[2][4][16] */
+	CEDAR_ENC_DBG_RECON_Y,    /* deblocked reconstruction, coded size                      */
+	CEDAR_ENC_DBG_RECON_UV,
+	CEDAR_ENC_DBG_SRC_Y,      /* padded source                                             */
+	CEDAR_ENC_DBG_SRC_UV,
+	CEDAR_ENC_DBG_MB_BITS     /* uint32 bits per MB                                        */
+};
+int cedar_enc_debug_read(cedar_enc *enc, int what, int stream, void *dst, int dst_size);
+
+/* synthetic nv12 test patterns 'A','B','C' (SURVEY.md 8(d)); host helper for the
+ * CLI/bench, independent of the oracle's generator */
+void cedar_enc_gen_pattern(int pattern, int width, int height, int frame,
+			   unsigned seed_offset, uint8_t *luma, uint8_t *chroma);
+
+const char *cedar_enc_last_error(cedar_enc *enc);
+const char *cedar_enc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CEDAR_H264ENC_H */
