@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- macroblocks/s of the HIP encode path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: one frame of every stream
+this rank owns (k_input -> intra or inter -> deblock || CAVLC..escape -> bytes on
+the host). Workload = BASELINE.json configs[2] per GPU (1920x1080 nv12, I+P,
+keyint 25, QP 24, synthetic pattern-B); with N GPUs every rank encodes its own
+streams (configs[4]: independent streams shard with no collective), so scaling is
+weak and `value` is total macroblocks of all ranks / max-over-ranks time.
+
+Inputs are resident in HBM before the timed region (device-input entry point of
+the C-ABI); the Annex-B bytes land in pinned host memory inside it.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel: algorithmic bytes per launch / its average
+               launch duration measured with HIP events on the kernel's stream
+  cpu_baseline the scalar C oracle (oracle/, kind "port") timed on this box's
+               host cores on a bounded sample of the same workload (rank 0, N=1)
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic HBM bytes per macroblock per kernel (DESIGN.md "Kernels"): each byte that
+# must cross HBM once. 384 B = one macroblock of nv12.
+KERNEL_BYTES_PER_MB = {
+    "input": 384 + 384,          # read packed frame, write padded planes
+    "intra_decide": 384,         # read source
+    "intra_recon": 384 + 384,    # read source, write reconstruction
+    "inter": 384 + 384 + 384,    # source + reference (each sample once) + reconstruction
+    "deblock": 384 + 384,        # read + write reconstruction in place
+    "entropy": 816 + 24 + 8,     # levels + counts + record read once (bitstream added separately)
+}
+PIPELINE_BYTES_PER_MB = {"I": 768.0, "P": 1152.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--streams", type=int, default=1, help="lock-step streams per GPU")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--qp", type=int, default=24)
+    ap.add_argument("--keyint", type=int, default=25)
+    ap.add_argument("--frames", type=int, default=50, help="distinct synthetic frames per stream (cycled)")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--batched-streams", type=int, default=8,
+                    help="also report throughput with this many streams per GPU (0 = skip)")
+    return ap.parse_args()
+
+
+def run_rank(args, rank, world, local_rank):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cedarx_h264_encoder_amd as ce
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    W, H = args.width, args.height
+    mbs_per_frame = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def make_inputs(S):
+        ins = []
+        for s in range(S):
+            gs = rank * S + s  # global stream id: seed offset s<<8
+            fr = []
+            for f in range(args.frames):
+                y, uv = ce.gen_pattern("B", W, H, f, gs << 8)
+                fr.append((torch.from_numpy(y).to(dev), torch.from_numpy(uv).to(dev)))
+            ins.append(fr)
+        torch.cuda.synchronize()
+        return ins
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(S, steps, warmup, inputs, profile):
+        enc = ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=args.keyint,
+                              n_streams=S, device=local_rank)
+        nbytes = 0
+        first_aus = []
+
+        def feed(i):
+            for s in range(S):
+                y, uv = inputs[s][i % args.frames]
+                enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
+            enc.submit()
+
+        # warmup (synchronous; also keeps the first access units for the parity check)
+        for i in range(warmup):
+            feed(i)
+            enc.collect()
+            if i < args.cpu_frames:
+                first_aus.append(enc.output(0))
+        enc.set_profiling(profile)
+        enc.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        # pipelined: one frame in flight behind the one being submitted
+        feed(warmup)
+        for i in range(warmup + 1, warmup + steps):
+            feed(i)
+            nbytes += enc.collect()
+        nbytes += enc.collect()
+        barrier()
+        dt = time.perf_counter() - t0
+        st = enc.stats()
+        enc.close()
+        return dt, nbytes, st, first_aus
+
+    S = args.streams
+    inputs = make_inputs(max(S, args.batched_streams))
+    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, True)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        nbytes_all = float(b.item())
+    else:
+        dt_max, nbytes_all = dt, float(nbytes)
+
+    total_mbs = world * S * mbs_per_frame * args.steps
+    value = total_mbs / dt_max
+
+    batched = None
+    if args.batched_streams and args.batched_streams != S:
+        SB = args.batched_streams
+        bsteps = max(25, min(args.steps, 50))
+        bdt, _, _, _ = measure(SB, bsteps, args.keyint, inputs, False)
+        if world > 1:
+            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bdt = float(t.item())
+        batched = {"streams_per_gpu": SB, "steps": bsteps,
+                   "value": world * SB * mbs_per_frame * bsteps / bdt,
+                   "ms_per_step": bdt / bsteps * 1e3}
+
+    if rank != 0:
+        return None
+
+    # ---- roofline of the dominant kernel (HIP-event durations from the timed region) ----
+    stage = max(st["ms"], key=lambda k: st["ms"][k])
+    launches = max(1, st["launches"][stage])
+    avg_ms = st["ms"][stage] / launches
+    mb_per_launch = S * mbs_per_frame
+    alg_bytes = KERNEL_BYTES_PER_MB[stage] * mb_per_launch
+    if stage == "entropy":
+        alg_bytes += nbytes / max(1, args.steps)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "%s@%dx%dx%d" % (stage, W, H, S)
+            traffic = tj.get(key)
+        except Exception:  # noqa: BLE001
+            traffic = None
+    n_i = sum(1 for i in range(args.warmup, args.warmup + args.steps) if i % args.keyint == 0)
+    pipe_bytes = (n_i * PIPELINE_BYTES_PER_MB["I"] + (args.steps - n_i) * PIPELINE_BYTES_PER_MB["P"]) \
+        * S * mbs_per_frame * world + nbytes_all
+    roofline = {
+        "bound": "hbm", "kernel": "k_" + stage, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+        "algorithmic_bytes_per_launch": int(alg_bytes),
+        "pipeline_achieved_GBs": round(pipe_bytes / dt_max / 1e9, 3),
+        "pipeline_frac": pipe_bytes / dt_max / 1e9 / HBM_PEAK_GBS,
+        "stage_ms_per_launch": {k: round(st["ms"][k] / max(1, st["launches"][k]), 4) for k in st["ms"]},
+    }
+
+    # ---- CPU baseline: the scalar C oracle on a bounded sample (rank 0, N=1 only) ----
+    cpu = None
+    bitexact = None
+    if world == 1 and args.cpu_frames > 0:
+        from tests import oracle_lib as ol
+        oe = ol.OracleEncoder(ol.default_config(W, H, qp=args.qp, keyint=args.keyint))
+        frames = [ce.gen_pattern("B", W, H, f, 0) for f in range(args.cpu_frames)]
+        t0 = time.perf_counter()
+        cpu_aus = [oe.encode(y, uv) for y, uv in frames]
+        cdt = time.perf_counter() - t0
+        n_cmp = min(len(cpu_aus), len(first_aus))
+        bitexact = n_cmp > 0 and all(cpu_aus[i] == first_aus[i] for i in range(n_cmp))
+        cpu = {"value": args.cpu_frames * mbs_per_frame / cdt, "unit": "macroblocks/s", "cores": 1,
+               "kind": "port",
+               "sample": "%d frames %dx%d pattern-B (1 IDR + %d P), QP %d, single thread, gcc -O2" % (
+                   args.cpu_frames, W, H, args.cpu_frames - 1, args.qp),
+               "seconds": round(cdt, 2),
+               "fnv_sha": hashlib.sha1(b"".join(cpu_aus)).hexdigest()[:16],
+               "gpu_sha": hashlib.sha1(b"".join(first_aus[:n_cmp])).hexdigest()[:16]}
+
+    out = {
+        "metric": "macroblocks/s @ fixed QP, 1080p nv12",
+        "value": value,
+        "unit": "macroblocks/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "%dx%d nv12 I+P keyint %d QP %d, pattern-B, %d stream(s) per GPU "
+                               "(BASELINE configs[2]; N GPUs = independent streams, configs[4])" % (
+                                   W, H, args.keyint, args.qp, S),
+                   "streams_per_gpu": S, "macroblocks_per_frame": mbs_per_frame,
+                   "parallelism": "streams x%d, no collective" % world,
+                   "realtime_4k30_multiple": value / 972000.0,
+                   "bitstream_bytes_per_step": nbytes_all / args.steps},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "bitexact_vs_cpu": bitexact,
+        "batched": batched,
+    }
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        # launched without torchrun: spawn it ourselves so `python bench.py --gpus N` works
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    import torch  # noqa: F401  (first, so the encoder library shares torch's HIP runtime)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    try:
+        out = run_rank(args, rank, world, local_rank)
+        if rank == 0 and out is not None:
+            print(json.dumps(out), flush=True)
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * h264enc -- the reference's command line on the MI355X path.
+ *
+ *   ./h264enc <infile|-> <width> <height> <outfile>
+ *
+ * Same arguments, frame pump, messages and exit codes as userspace/h264enc.c
+ * (lines 134-201); open()/ioctl()/mmap() on /dev/cedar_dev are replaced by the
+ * C-ABI of include/cedar_h264enc.h. Two literals differ from ve_config()
+ * (h264enc.c:61,66): profile 66 and CAVLC, which this path implements.
+ * Optional knobs come from the environment so the four positional arguments
+ * stay: H264ENC_QP, H264ENC_KEYINT, H264ENC_SLICES, H264ENC_SEARCH, H264ENC_DEVICE.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "cedar_h264enc.h"
+
+#define ALIGN(x, a) (((x) + ((a) - 1)) & ~((a) - 1))
+
+static cedar_enc *cedar;
+static struct cedar_enc_config config;
+
+static int env_int(const char *name, int dflt)
+{
+	const char *v = getenv(name);
+
+	return v && *v ? atoi(v) : dflt;
+}
+
+static int ve_config(int width, int height) /* h264enc.c:47-117 */
+{
+	struct cedar_enc_config_ext ext;
+	int ret;
+
+	memset(&config, 0, sizeof(config));
+	memset(&ext, 0, sizeof(ext));
+	config.src_width = width;
+	config.src_height = height;
+	config.src_format = CEDAR_ENC_FORMAT_NV12;
+	config.dst_width = ALIGN(width, 16);
+	config.dst_height = ALIGN(height, 16);
+	config.profile = 66;
+	config.level = (config.dst_width / 16) * (config.dst_height / 16) > 8192 ? 51 : 41;
+	config.qp = env_int("H264ENC_QP", 24);
+	config.keyframe_interval = env_int("H264ENC_KEYINT", 25);
+	config.entropy_coding_mode = CEDAR_ENC_ENTROPY_CAVLC;
+	ext.size = sizeof(ext);
+	ext.device = env_int("H264ENC_DEVICE", 0);
+	ext.slice_count = env_int("H264ENC_SLICES", 1);
+	ext.search_range = env_int("H264ENC_SEARCH", 0);
+
+	ret = cedar_enc_config_ext(cedar, &config, &ext);
+	if (ret) {
+		fprintf(stderr, "%s(): CEDAR_IOCTL_CONFIG failed: %s (%s)\n", __func__, strerror(-ret),
+			cedar_enc_last_error(cedar));
+		return ret;
+	}
+	printf("Input Y: %dbytes -> %p\n", config.input_luma_size, (void *)config.input_luma);
+	printf("Input C: %dbytes -> %p\n", config.input_chroma_size, (void *)config.input_chroma);
+	printf("Bytestream: %dbytes -> %p\n", config.bytestream_size, (void *)config.bytestream);
+	return 0;
+}
+
+static int read_frame(int fd, void *buffer, int size) /* h264enc.c:119-132 */
+{
+	int total = 0, len;
+
+	while (total < size) {
+		len = read(fd, (char *)buffer + total, size - total);
+		if (len <= 0)
+			return -1;
+		total += len;
+	}
+	return total;
+}
+
+int main(int argc, char **argv)
+{
+	unsigned frame_count = 0;
+	int width, height, fd_in, fd_out, luma_size, chroma_size, ret;
+
+	if (argc != 5) {
+		printf("Usage: %s <infile> <width> <height> <outfile>\n", argv[0]);
+		return -1;
+	}
+	width = atoi(argv[2]);
+	height = atoi(argv[3]);
+
+	cedar = cedar_enc_open();
+	if (!cedar) {
+		fprintf(stderr, "%s(): failed to open the HIP encoder: %s\n", __func__, strerror(errno));
+		return -1;
+	}
+	if (strcmp(argv[1], "-")) {
+		fd_in = open(argv[1], O_RDONLY | O_LARGEFILE);
+		if (fd_in == -1) {
+			fprintf(stderr, "%s(): Failed to open input file %s: %s\n", __func__, argv[1], strerror(errno));
+			return -1;
+		}
+	} else {
+		fd_in = 0;
+	}
+	fd_out = open(argv[4], O_CREAT | O_RDWR | O_TRUNC, S_IRUSR | S_IWUSR | S_IRGRP | S_IROTH);
+	if (fd_out == -1) {
+		fprintf(stderr, "%s(): Failed to open output file %s\n", __func__, argv[4]);
+		return -1;
+	}
+	ret = ve_config(width, height);
+	if (ret)
+		return ret;
+
+	luma_size = width * height;
+	chroma_size = luma_size / 2;
+	while (1) {
+		ret = read_frame(fd_in, config.input_luma, luma_size);
+		if (ret != luma_size)
+			break;
+		ret = read_frame(fd_in, config.input_chroma, chroma_size);
+		if (ret != chroma_size)
+			break;
+		ret = cedar_enc_encode(cedar);
+		if (ret < 0) {
+			fprintf(stderr, "%s(): %d: CEDAR_IOCTL_ENCODE failed: %s\n", __func__, frame_count, strerror(-ret));
+		} else {
+			printf("\rFrame %5d: %5dbytes", frame_count, ret);
+			if (write(fd_out, config.bytestream, ret) != ret)
+				fprintf(stderr, "%s(): short write\n", __func__);
+			frame_count++;
+		}
+	}
+	return 0;
+}

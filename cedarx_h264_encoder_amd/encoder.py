@@ -56,6 +56,28 @@ def library_path():
     return _LIB
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime. PyTorch-ROCm ships its own
+    libamdhip64.so.7 (same soname as /opt/rocm's); if this library pulled in the
+    system copy first, a later `import torch` would load a second runtime and
+    see no GPU. So when torch is installed (bench.py and the tests use it for
+    torch.distributed / device buffers) its copy is loaded first and the dynamic
+    linker binds ours to it by soname. The C CLI (no torch) uses /opt/rocm."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("CEDAR_H264ENC_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(hip):
+            ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load_library():
     """Load the native library; build it first if it is missing (hipcc is
     present on the GPU boxes). Fails loudly: there is no other implementation."""
@@ -65,6 +87,7 @@ def load_library():
     if not os.path.exists(_LIB):
         from . import build as _build
         _build.build()
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(_LIB)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.cedar_enc_open.restype = vp

@@ -1,0 +1,214 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs. Integer pipeline => the bar is BIT-EXACT:
+identical Annex-B bytes, identical per-macroblock decisions/levels and
+identical deblocked reconstruction. All tests here need an MI355X."""
+import errno
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ce():
+    import cedarx_h264_encoder_amd as m
+    return m
+
+
+CASES = [
+    # w, h, qp, keyint, frames, pattern, slices
+    (64, 48, 30, 1, 3, "B", 1),      # I only
+    (320, 240, 30, 1, 3, "B", 1),    # BASELINE configs[0] shape
+    (64, 48, 30, 25, 5, "B", 1),
+    (64, 48, 24, 25, 4, "C", 1),     # noise: every block coded, long levels
+    (64, 48, 30, 25, 4, "A", 1),     # static: P pictures are one skip run
+    (70, 50, 24, 25, 4, "B", 1),     # ragged size: padding + SPS cropping
+    (320, 240, 30, 25, 6, "B", 1),
+    (320, 240, 24, 25, 4, "B", 4),   # 4 slices, deblocking idc 2 (configs[3] structure)
+    (48, 80, 24, 4, 6, "B", 5),
+    (64, 48, 5, 3, 4, "C", 1),       # very low QP: escape-coded levels
+    (64, 48, 47, 3, 4, "B", 1),      # highest QP the reference accepts
+    (16, 16, 24, 2, 4, "C", 1),      # single macroblock
+    (432, 32, 24, 3, 4, "B", 1),
+    (854, 480, 30, 25, 3, "B", 1),   # BASELINE configs[1] shape (README's 854x480)
+]
+
+
+def _compare_state(oe, ge):
+    om = oe.mb_array()
+    gm = ge.debug_read("mbinfo")
+    for fld in ("type", "i16_mode", "chroma_mode", "cbp", "mvx", "mvy"):
+        assert np.array_equal(om[fld], gm[fld]), fld
+    assert np.array_equal(om["i4_modes"], ge.debug_read("i4modes"))
+    assert np.array_equal(om["nnz"], ge.debug_read("nnz"))
+    gc = ge.debug_read("coef")
+    n = len(om)
+    assert np.array_equal(om["luma"].reshape(n, 256), gc[:, 0:256])
+    assert np.array_equal(om["dc16"], gc[:, 256:272])
+    assert np.array_equal(om["cdc"].reshape(n, 8), gc[:, 272:280])
+    assert np.array_equal(om["cac"].reshape(n, 8, 16)[:, :, 1:], gc[:, 280:408].reshape(n, 8, 16)[:, :, 1:])
+    ry, ruv = oe.recon()
+    assert np.array_equal(ry, ge.debug_read("recon_y"))
+    assert np.array_equal(ruv, ge.debug_read("recon_uv"))
+
+
+@pytest.mark.parametrize("w,h,qp,keyint,frames,pattern,slices", CASES)
+def test_bitstream_and_state_equal_oracle(ce, w, h, qp, keyint, frames, pattern, slices):
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices))
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices) as ge:
+        for f in range(frames):
+            y, uv = ol.gen_frame(pattern, w, h, f)
+            ref = oe.encode(y, uv)
+            got = ge.encode_frame(y, uv)
+            _compare_state(oe, ge)
+            assert got == ref, "frame %d: bytestream differs" % f
+
+
+def test_1080p_gop_bit_exact_and_decodable(ce):
+    """BASELINE configs[2] at full size (1920x1080 I+P QP 24): a short run against
+    the oracle, then a longer run checked by the size-independent property
+    decode(stream) == in-loop reconstruction."""
+    w, h = 1920, 1080
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=24, keyint=25))
+    dec = ol.OracleDecoder()
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25) as ge:
+        for f in range(8):
+            y, uv = ce.gen_pattern("B", w, h, f)
+            got = ge.encode_frame(y, uv)
+            if f < 3:
+                assert got == oe.encode(y, uv), "frame %d" % f
+            assert dec.decode(got) == 1
+            dy, duv = dec.picture()
+            assert np.array_equal(dy, ge.debug_read("recon_y"))
+            assert np.array_equal(duv, ge.debug_read("recon_uv"))
+        assert dec.crop_size() == (w, h)
+
+
+def test_4k_four_slices_decodable_and_matches_oracle_first_frames(ce):
+    """BASELINE configs[3] structure on one device: 3840x2160 in 4 slices (34/34/34/33 rows)."""
+    w, h = 3840, 2160
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=24, keyint=25, slice_count=4))
+    dec = ol.OracleDecoder()
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25, slice_count=4) as ge:
+        for f in range(3):
+            y, uv = ce.gen_pattern("B", w, h, f)
+            got = ge.encode_frame(y, uv)
+            if f < 2:
+                assert got == oe.encode(y, uv), "frame %d" % f
+            assert dec.decode(got) == 1
+            dy, duv = dec.picture()
+            assert np.array_equal(dy, ge.debug_read("recon_y"))
+            assert np.array_equal(duv, ge.debug_read("recon_uv"))
+
+
+def test_slices_on_separate_sessions_concatenate_to_the_whole(ce):
+    """configs[3] sharding: each 'GPU' encodes one slice with its own session; the
+    host concatenates the NALs. Must equal the single-session 4-slice stream."""
+    w, h, n = 320, 240, 4
+    whole = ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25, slice_count=n)
+    parts = [ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25, slice_count=n,
+                             slice_first=k, slice_num=1) for k in range(n)]
+    try:
+        for f in range(4):
+            y, uv = ol.gen_frame("B", w, h, f)
+            ref = whole.encode_frame(y, uv)
+            cat = b"".join(p.encode_frame(y, uv) for p in parts)
+            assert cat == ref, "frame %d" % f
+    finally:
+        whole.close()
+        for p in parts:
+            p.close()
+
+
+def test_batched_streams_equal_independent_streams(ce):
+    """configs[4] structure: several lock-step streams in one session (same kernel
+    launches) must each produce exactly what a stream encoded alone produces."""
+    w, h, S = 320, 240, 3
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=24, keyint=25)) for _ in range(S)]
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25, n_streams=S) as ge:
+        for f in range(5):
+            refs = []
+            for s in range(S):
+                y, uv = ol.gen_frame("B", w, h, f, seed_offset=s << 8)
+                ge.set_input(y, uv, s)
+                refs.append(oes[s].encode(y, uv))
+            total = ge.encode()
+            assert total == sum(len(r) for r in refs)
+            for s in range(S):
+                assert ge.output(s) == refs[s], "frame %d stream %d" % (f, s)
+
+
+def test_pipelined_submit_collect_equals_synchronous(ce):
+    w, h = 320, 240
+    frames = [ol.gen_frame("B", w, h, f) for f in range(7)]
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=3) as a:
+        sync = [a.encode_frame(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=3) as b:
+        out = []
+        b.set_input(*frames[0])
+        b.submit()
+        for f in range(1, len(frames)):
+            b.set_input(*frames[f])
+            b.submit()           # two frames in flight
+            b.collect()
+            out.append(b.output())
+        b.collect()
+        out.append(b.output())
+    assert out == sync
+
+
+def test_device_resident_input_equals_host_input(ce):
+    torch = pytest.importorskip("torch")
+    w, h = 320, 240
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25) as a, \
+            ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25) as b:
+        for f in range(3):
+            y, uv = ol.gen_frame("B", w, h, f)
+            ref = a.encode_frame(y, uv)
+            ty = torch.from_numpy(y).cuda()
+            tuv = torch.from_numpy(uv).cuda()
+            torch.cuda.synchronize()
+            b.set_device_input(0, ty.data_ptr(), tuv.data_ptr())
+            b.encode()
+            assert b.output() == ref
+
+
+def test_session_contract_errors(ce):
+    """Error behaviour of the reference's ioctls (cedar.c:738-789, :1039-1043)."""
+    e = ce.CedarEncoder()
+    with pytest.raises(ce.EncoderError) as ex:  # ENCODE before CONFIG -> EINVAL
+        e.encode()
+    assert ex.value.errno == errno.EINVAL
+    for bad in (dict(width=321, height=240), dict(width=320, height=240, qp=0),
+                dict(width=320, height=240, qp=48), dict(width=320, height=240, keyframe_interval=0),
+                dict(width=320, height=240, keyframe_interval=32),
+                dict(width=320, height=240, entropy_coding_mode=1),   # CABAC: rejected, never silently CAVLC
+                dict(width=320, height=240, src_format=1),
+                dict(width=320, height=240, dst_width=336)):
+        with pytest.raises(ce.EncoderError) as ex:
+            e.config(ce.EncoderConfig(**bad))
+        assert ex.value.errno == errno.EINVAL, bad
+    e.config(ce.EncoderConfig(width=320, height=240))
+    with pytest.raises(ce.EncoderError) as ex:  # second CONFIG -> EINVAL (cedar.c:744-747)
+        e.config(ce.EncoderConfig(width=320, height=240))
+    assert ex.value.errno == errno.EINVAL
+    e.close()
+
+
+def test_gop_cadence_headers_and_sizes(ce):
+    """SPS+PPS only in front of frame 0 (cedar.c:1058-1061); I P P I ... by keyint;
+    encode() returns the byte count valid at bytestream offset 0 (cedar.c:1207)."""
+    with ce.CedarEncoder(width=64, height=48, qp=30, keyframe_interval=3) as e:
+        y, uv = ol.gen_frame("B", 64, 48, 0)
+        kinds = []
+        for f in range(7):
+            e.set_input(y, uv)
+            n = e.encode()
+            au = e.output()
+            assert n == len(au)
+            kinds.append([au[i + 4] & 0x1f for i in range(len(au) - 4) if au[i:i + 4] == b"\0\0\0\1"])
+        assert kinds[0] == [7, 8, 5]
+        assert kinds[1:] == [[1], [1], [5], [1], [1], [5]]
