@@ -22,6 +22,10 @@ __device__ constexpr uint8_t kPosClass[16] = { 0, 2, 0, 2, 2, 1, 2, 1, 0, 2, 0, 
 __device__ constexpr uint8_t kBlkX[16] = { 0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3 };
 __device__ constexpr uint8_t kBlkY[16] = { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 };
 
+// arithmetic forms of kBlkX / kBlkY (no table load on a dependent chain)
+DEVI int blk_x(int idx) { return ((idx >> 1) & 2) | (idx & 1); }
+DEVI int blk_y(int idx) { return ((idx >> 2) & 2) | ((idx >> 1) & 1); }
+
 DEVI int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 DEVI int iabs(int v) { return v < 0 ? -v : v; }
 DEVI int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -150,7 +154,7 @@ DEVI bool mode4_allowed(int mode, bool has_top, bool has_left)
 // (top-right by the decoding-order rule, clause 6.4.11.4)
 DEVI void blk4_avail(int idx, bool top_mb, bool left_mb, bool tr_mb, bool &ht, bool &hl, bool &htr)
 {
-	const int bx = kBlkX[idx], by = kBlkY[idx];
+	const int bx = blk_x(idx), by = blk_y(idx);
 	// internal top-right availability bitmask over coding index: 2,6,8,9,10,12,14
 	const uint32_t tri = (1u << 2) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12) | (1u << 14);
 	ht = by > 0 || top_mb;

@@ -201,7 +201,7 @@ DEVI void write_residual(BitW &b, const MbInfo &mi, const int16_t *cf, const Nb 
 			continue;
 		for (int i4 = 0; i4 < 4; i4++) {
 			const int idx = 4 * i8 + i4;
-			const int nC = calc_nc(nb, 0, kBlkX[idx], kBlkY[idx]);
+			const int nC = calc_nc(nb, 0, blk_x(idx), blk_y(idx));
 			load_block(cf + COEF_LUMA + idx * 16, lv);
 			if (mi.type == MB_I16x16)
 				cavlc_block(b, lv, 1, 15, nC);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 			bw_ue(b, 0);
 			const int8_t *mo = p.i4modes + mbaddr * 16;
 			for (int idx = 0; idx < 16; idx++) {
-				const int bx = kBlkX[idx], by = kBlkY[idx];
+				const int bx = blk_x(idx), by = blk_y(idx);
 				// predicted mode (8.3.1.1): DC when either neighbour MB is unavailable
 				int ma = 2, mb_ = 2;
 				bool dcflag = false;

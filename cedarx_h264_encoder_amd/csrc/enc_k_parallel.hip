@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	int nnz = 0, dc_level_nz = 0;
 	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / 6;
 	if (lane < 16) {
-		const int bx = kBlkX[lane], by = kBlkY[lane];
+		const int bx = blk_x(lane), by = blk_y(lane);
 		int pred[16], res[16], w[16], lv[16], d[16], out[16];
 #pragma unroll
 		for (int i = 0; i < 16; i++) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	else if (lane < 24)
 		*(u32x4 *)(rec_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
 	if (lane < 16) {
-		p.nnz[mbaddr * NNZ_PER_MB + kBlkX[lane] + 4 * kBlkY[lane]] = (uint8_t)nnz;
+		p.nnz[mbaddr * NNZ_PER_MB + blk_x(lane) + 4 * blk_y(lane)] = (uint8_t)nnz;
 		p.i4modes[mbaddr * 16 + lane] = 2;
 	} else if (lane < 24) {
 		p.nnz[mbaddr * NNZ_PER_MB + lane] = (uint8_t)nnz;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 	if (lane < 16) {
 		bool ht, hl, htr;
 		blk4_avail(lane, top_mb, left_mb, tr_mb, ht, hl, htr);
-		const int tx = 1 + 4 * kBlkX[lane], ty = 1 + 4 * kBlkY[lane];
+		const int tx = 1 + 4 * blk_x(lane), ty = 1 + 4 * blk_y(lane);
 		uint8_t *E = s_E[lane];
 		int st_ = 0, sl = 0;
 #pragma unroll
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 			blk4_avail(b, top_mb, left_mb, tr_mb, ht, hl, htr);
 			uint32_t key = 0xffffffffu;
 			if (mode4_allowed(mode, ht, hl)) {
-				const int tx = 1 + 4 * kBlkX[b], ty = 1 + 4 * kBlkY[b];
+				const int tx = 1 + 4 * blk_x(b), ty = 1 + 4 * blk_y(b);
 				const uint8_t *E = s_E[b];
 				const int dc = s_dcv[b];
 				int sad = 0;

@@ -15,6 +15,8 @@
 // The reference delegates both stages to silicon (kernel/cedar.c:1135-1153
 // programs REC/REF/MBINFO addresses, :1176 triggers); deblocking policy is the
 // slice header's (cedar.c:1024-1029: idc 0, offsets 0).
+#include <stdlib.h>
+
 #include <hip/hip_runtime.h>
 
 #include "enc_device.h"
@@ -23,11 +25,13 @@ namespace cedar {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#define WAVE_SYNC()                                                   \
-	do {                                                          \
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-		__builtin_amdgcn_wave_barrier();                      \
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+// intra-wave hand-off through LDS only: order LDS accesses, leave global loads
+// and stores in flight (a plain fence would drain them with vmcnt(0))
+#define WAVE_SYNC()                                                            \
+	do {                                                                   \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+		__builtin_amdgcn_wave_barrier();                               \
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
 	} while (0)
 
 constexpr int MAX_ROWS = 512; // MB rows of one unit (8K pictures)
@@ -56,36 +60,75 @@ DEVI int hsign(int i, int a)
 }
 
 // ------------------------------------------------------------------------
-// k_intra_recon
+// k_intra_recon: each wave sweeps a band of 4 macroblock rows; lane group
+// g = lane>>4 works on row band+g, two macroblocks behind group g-1 (the same
+// skew as k_deblock), so one instruction stream reconstructs 4 macroblocks.
+//   Intra 4x4:   the 16 lanes of a group are the 16 samples of the current 4x4
+//                block; the block loop is the serial chain the standard imposes.
+//                Transforms run across lanes with DPP (quad_perm / row_mirror),
+//                no LDS round trip: forward leaves coefficient (P[i],P[j]),
+//                P = {0,2,1,3}, on lane (i,j), which is what the inverse wants.
+//   Intra 16x16: the 16 lanes are the 16 4x4 blocks, each transformed in
+//                registers; DC Hadamard through a 16-word LDS scratch.
+//   chroma:      lanes 0..7 of the group = (plane, 4x4 block).
 // ------------------------------------------------------------------------
-#define IT_STRIDE 48 // luma tile: sample (x,y) at [(1+y)*48 + 16 + x], x in [-1,19], y in [-1,15]
-#define IC_STRIDE 32 // chroma tile (nv12): sample (x,y,c) at [(1+y)*32 + 16 + 2x + c]
+#define IT_STRIDE 32 // luma tile: sample (x,y) at [(1+y)*32 + 8 + x], x in [-1,19], y in [-1,15]
+#define IC_STRIDE 32 // chroma tile (nv12): sample (x,y,c) at [(1+y)*32 + 8 + 2x + c], x,y in [-1,7]
 
-struct IntraWaveLds {
+struct IntraGroupLds {
 	uint8_t t[17 * IT_STRIDE];
 	uint8_t c[9 * IC_STRIDE];
 	uint8_t src[256];
 	uint8_t srcc[128];
-	uint8_t pred[256];
-	uint8_t predc[2][64];
-	int16_t coef[COEF_PER_MB];
-	uint8_t E[16];
-	int16_t res4[16];
-	uint8_t pred4[16];
 	int dc[16];
 	int dcl[16];
 	int cdc[8];
 	int cdl[8];
-	uint8_t nnz[24];
-	uint8_t pad[8];
 };
 
-__global__ __launch_bounds__(64 * WF_WAVES) void k_intra_recon(Params p)
+// cross-lane exchanges inside a 16-lane DPP row; lane = 4*i + j
+DEVI int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); } // quad_perm [1,0,3,2]
+DEVI int dpp_xor3(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xf, 0xf, false); } // quad_perm [3,2,1,0]
+DEVI int dpp_xor4(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); } // row_half_mirror, j restored
+DEVI int dpp_xor12(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); } // row_mirror, j restored
+
+// forward 4x4 core transform of the residual held one sample per lane (i = row,
+// j = column). Returns W[P[i]][P[j]], P = {0,2,1,3}.
+DEVI int fdct_lanes(int v, int i, int j)
 {
-	__shared__ __attribute__((aligned(16))) IntraWaveLds s_w[WF_WAVES];
+	int p = dpp_xor3(v);
+	int s = j < 2 ? v + p : p - v;          // a b c d over j
+	int q = dpp_xor1(s);
+	s = j == 0 ? s + q : j == 1 ? q - s : j == 2 ? s + 2 * q : s - 2 * q; // W0 W2 W1 W3
+	p = dpp_xor12(s);
+	s = i < 2 ? s + p : p - s;
+	q = dpp_xor4(s);
+	return i == 0 ? s + q : i == 1 ? q - s : i == 2 ? s + 2 * q : s - 2 * q;
+}
+
+// inverse of the above (rows first, then columns: clause 8.5.12.2); input is the
+// scaled coefficient (P[i],P[j]) on lane (i,j); returns the residual sample (y=i, x=j)
+DEVI int idct_lanes(int d, int i, int j)
+{
+	int q = dpp_xor1(d);
+	int e = j == 0 ? d + q : j == 1 ? q - d : j == 2 ? (d >> 1) - q : q + (d >> 1); // e0 e1 e2 e3
+	int p = dpp_xor3(e);
+	int f = (j == 0 || j == 1) ? e + p : p - e; // f0 f1 f2 f3
+	q = dpp_xor4(f);
+	e = i == 0 ? f + q : i == 1 ? q - f : i == 2 ? (f >> 1) - q : q + (f >> 1);
+	p = dpp_xor12(e);
+	f = (i == 0 || i == 1) ? e + p : p - e;
+	return (f + 32) >> 6;
+}
+
+template <int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
+{
+	__shared__ __attribute__((aligned(16))) IntraGroupLds s_g[NWAVES * 4];
 	__shared__ int s_prog[MAX_ROWS];
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int g = lane >> 4, l = lane & 15;
 	const int unit = blockIdx.x;
 	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
 	int r0, r1;
@@ -94,300 +137,340 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_intra_recon(Params p)
 		s_prog[i] = 0;
 	__syncthreads();
 
-	IntraWaveLds &L = s_w[wave];
+	IntraGroupLds &L = s_g[wave * 4 + g];
 	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
 	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
+	const int nbands = (r1 - r0 + 3) >> 2;
+	const int pi = l >> 2, pj = l & 3;                 // sample / lane position in a 4x4 block
+	const int Pm[4] = { 0, 2, 1, 3 };
+	const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
+	(void)Pm;
+	const int rpos = 4 * kv + kh;                      // raster coefficient position held by this lane
+	const int pclass = kPosClass[rpos];
+	int zz = 0;                                        // its zig-zag scan index
+#pragma unroll
+	for (int z = 0; z < 16; z++)
+		zz = kZigzag[z] == rpos ? z : zz;
+	// this lane's column of the 4x4 predictor table (9 modes), packed in registers
+	uint32_t ptab0 = 0, ptab1 = 0, ptab2 = 0;
+#pragma unroll
+	for (int m = 0; m < 4; m++) {
+		ptab0 |= (uint32_t)p.pred4_tab[m * 16 + l] << (8 * m);
+		ptab1 |= (uint32_t)p.pred4_tab[(4 + m) * 16 + l] << (8 * m);
+	}
+	ptab2 = p.pred4_tab[8 * 16 + l];
+	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
+	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
 
-	for (int my = r0 + wave; my < r1; my += WF_WAVES) {
+	for (int band = wave; band < nbands; band += NWAVES) {
+		const int my = r0 + 4 * band + g;
+		const bool row_ok = my < r1;
 		const bool top_mb = my > r0;
-		for (int mx = 0; mx < p.mb_w; mx++) {
-			const int x0 = mx * 16, y0 = my * 16;
+		for (int step = 0; step < p.mb_w + 6; step++) {
+			const int mx = step - 2 * g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 			const bool left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
-			const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+			const int x0 = mx * 16, y0 = my * 16;
+			const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
 
-			// left neighbours = last column of the previous macroblock, still in the tiles
-			if (left_mb) {
-				if (lane < 16)
-					L.t[(1 + lane) * IT_STRIDE + 15] = L.t[(1 + lane) * IT_STRIDE + 31];
-				else if (lane < 24) {
-					int y = lane - 16;
-					L.c[(1 + y) * IC_STRIDE + 14] = L.c[(1 + y) * IC_STRIDE + 30];
-					L.c[(1 + y) * IC_STRIDE + 15] = L.c[(1 + y) * IC_STRIDE + 31];
+			if (act && left_mb) { // left neighbours = last column of the previous macroblock
+				L.t[(1 + l) * IT_STRIDE + 7] = L.t[(1 + l) * IT_STRIDE + 23];
+				if (l < 8)
+					*(uint16_t *)(L.c + (1 + l) * IC_STRIDE + 6) = *(const uint16_t *)(L.c + (1 + l) * IC_STRIDE + 22);
+			}
+			if (band > 0 && step < p.mb_w)
+				wait_progress(s_prog, 4 * band - 1, step + 2 < p.mb_w ? step + 2 : p.mb_w);
+			MbInfo mi = p.mbi[mbaddr];
+			const int my_i4 = p.i4modes[mbaddr * 16 + l];
+			if (act) {
+				{
+					const u32x4 v = *(const u32x4 *)(src_y + (size_t)(y0 + l) * p.cw + x0);
+					*(u32x4 *)(L.src + l * 16) = v;
+				}
+				if (l < 8)
+					*(u32x4 *)(L.srcc + l * 16) = *(const u32x4 *)(src_uv + (size_t)(my * 8 + l) * p.cw + x0);
+				if (top_mb) {
+					if (l == 8) {
+						const uint64_t *tp = (const uint64_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0);
+						*(uint64_t *)(L.t + 8) = tp[0];
+						*(uint64_t *)(L.t + 16) = tp[1];
+					} else if (l == 9 && tr_mb) {
+						*(uint32_t *)(L.t + 24) = *(const uint32_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0 + 16);
+					} else if (l == 10 && left_mb) {
+						L.t[7] = rec_y[(size_t)(y0 - 1) * p.cw + x0 - 1];
+					} else if (l == 11) {
+						const uint64_t *tp = (const uint64_t *)(rec_uv + (size_t)(my * 8 - 1) * p.cw + x0);
+						*(uint64_t *)(L.c + 8) = tp[0];
+						*(uint64_t *)(L.c + 16) = tp[1];
+					} else if (l == 12 && left_mb) {
+						*(uint16_t *)(L.c + 6) = *(const uint16_t *)(rec_uv + (size_t)(my * 8 - 1) * p.cw + x0 - 2);
+					}
 				}
 			}
-			if (top_mb)
-				wait_progress(s_prog, my - 1 - r0, mx + 2 < p.mb_w ? mx + 2 : p.mb_w);
-			// source macroblock + top neighbours from the (unfiltered) reconstruction
-			if (lane < 16)
-				*(u32x4 *)(L.src + lane * 16) = *(const u32x4 *)(src_y + (size_t)(y0 + lane) * p.cw + x0);
-			else if (lane < 24)
-				*(u32x4 *)(L.srcc + (lane - 16) * 16) = *(const u32x4 *)(src_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0);
-			else if (top_mb) {
-				if (lane == 24)
-					*(u32x4 *)(L.t + 16) = *(const u32x4 *)(rec_y + (size_t)(y0 - 1) * p.cw + x0);
-				else if (lane == 25 && tr_mb)
-					*(uint32_t *)(L.t + 32) = *(const uint32_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0 + 16);
-				else if (lane == 26 && left_mb)
-					L.t[15] = rec_y[(size_t)(y0 - 1) * p.cw + x0 - 1];
-				else if (lane == 27)
-					*(u32x4 *)(L.c + 16) = *(const u32x4 *)(rec_uv + (size_t)(my * 8 - 1) * p.cw + x0);
-				else if (lane == 28 && left_mb)
-					*(uint16_t *)(L.c + 14) = *(const uint16_t *)(rec_uv + (size_t)(my * 8 - 1) * p.cw + x0 - 2);
-			}
-			const MbInfo mi = p.mbi[mbaddr];
-			const int my_i4 = lane < 16 ? p.i4modes[mbaddr * 16 + lane] : 0;
-			for (int i = lane; i < COEF_PER_MB; i += 64)
-				L.coef[i] = 0;
-			if (lane < 24)
-				L.nnz[lane] = 0;
 			WAVE_SYNC();
 
+			int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
+			const bool is4 = act && mi.type == MB_I4x4, is16 = act && mi.type == MB_I16x16;
 			int cbp = 0;
-			if (mi.type == MB_I16x16) {
-				// ---- 16x16 prediction: lane covers row lane>>2, columns 4*(lane&3).. ----
-				{
-					const int py = lane >> 2, pxb = 4 * (lane & 3);
+			uint32_t nzmask16 = 0; // luma blocks with coefficients, bit = raster block
+
+			// ---- Intra 4x4: serial over the 16 blocks, lane = sample ----
+			if (__any(is4)) {
+				if (is4)
+					cf[COEF_DC16 + l] = 0;
+				for (int idx = 0; idx < 16; idx++) {
+					const int bx = blk_x(idx), by = blk_y(idx);
+					int level = 0;
+					if (is4) {
+						const int tx = 8 + 4 * bx, ty = 1 + 4 * by;
+						bool ht, hl, htr;
+						blk4_avail(idx, top_mb, left_mb, tr_mb, ht, hl, htr);
+						const int mode = __shfl(my_i4, idx, 16);
+						const uint8_t *T = L.t;
+						// edge entry k -> tile address. E[0]=E[1]=l3 E[2]=l2 E[3]=l1 E[4]=l0 E[5]=tl
+						// E[6..13]=t0..t7 (t4..7 = t3 when top-right is unavailable) E[14]=t7
+						auto eaddr = [&](int k) {
+							k = k < 1 ? 1 : k > 13 ? 13 : k;
+							int tk = k - 6;
+							tk = (tk > 3 && !htr) ? 3 : tk;
+							return k <= 4 ? (ty + 4 - k) * IT_STRIDE + tx - 1
+							     : k == 5 ? (ty - 1) * IT_STRIDE + tx - 1
+							     : (ty - 1) * IT_STRIDE + tx + tk;
+						};
+						const uint32_t pw = mode < 4 ? ptab0 : mode < 8 ? ptab1 : ptab2;
+						const int ent = (int)((pw >> (8 * (mode & 3))) & 0xffu);
+						const int kind = ent >> 4, k = ent & 15;
+						const int ea = T[eaddr(k - 1)], eb = T[eaddr(k)], ec = T[eaddr(k + 1)];
+						int st_ = 0, sl_ = 0;
+#pragma unroll
+						for (int q = 0; q < 4; q++) {
+							st_ += T[(ty - 1) * IT_STRIDE + tx + q];
+							sl_ += T[(ty + q) * IT_STRIDE + tx - 1];
+						}
+						const int dcv = (ht && hl) ? (st_ + sl_ + 4) >> 3 : hl ? (sl_ + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
+						int pv = eb;
+						pv = kind == 1 ? (eb + ec + 1) >> 1 : pv;
+						pv = kind == 2 ? (ea + 2 * eb + ec + 2) >> 2 : pv;
+						pv = kind == 3 ? dcv : pv;
+						const int res = (int)L.src[(4 * by + pi) * 16 + 4 * bx + pj] - pv;
+						const int w = fdct_lanes(res, pi, pj);
+						level = quant1(w, my_mf, f_intra, p.qbits);
+						cf[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
+						const int d = (level * my_dv) << p.qshift;
+						const int r = idct_lanes(d, pi, pj);
+						L.t[(ty + pi) * IT_STRIDE + tx + pj] = (uint8_t)clip255(pv + r);
+					}
+					const uint64_t bal = __ballot(is4 && level != 0);
+					const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
+					if (is4) {
+						if (l == 0)
+							p.nnz[mbaddr * NNZ_PER_MB + bx + 4 * by] = (uint8_t)nn;
+						cbp |= nn ? (1 << (idx >> 2)) : 0;
+						nzmask16 |= nn ? (1u << (bx + 4 * by)) : 0;
+					}
+					WAVE_SYNC();
+				}
+			}
+
+			// ---- Intra 16x16: lane = 4x4 block (coding order) ----
+			if (__any(is16)) {
+				const int bx = blk_x(l), by = blk_y(l);
+				const uint8_t *T = L.t;
+				int d[16];
+				int nn = 0, dcv = 128, pa = 0, pb = 0, pc = 0;
+				// prediction is recomputed where needed instead of being kept in registers
+				auto pred16 = [&](int x, int y) {
+					return mi.i16_mode == 0 ? (int)T[8 + x]
+					     : mi.i16_mode == 1 ? (int)T[(1 + y) * IT_STRIDE + 7]
+					     : mi.i16_mode == 2 ? dcv
+					     : clip255((pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5);
+				};
+				if (is16) {
 					int dcsum = 0, H = 0, V = 0;
 					for (int k = 0; k < 16; k++)
-						dcsum += (top_mb ? L.t[16 + k] : 0) + (left_mb ? L.t[(1 + k) * IT_STRIDE + 15] : 0);
-					const int dcv = (top_mb && left_mb) ? (dcsum + 16) >> 5 : (top_mb || left_mb) ? (dcsum + 8) >> 4 : 128;
+						dcsum += (top_mb ? T[8 + k] : 0) + (left_mb ? T[(1 + k) * IT_STRIDE + 7] : 0);
+					dcv = (top_mb && left_mb) ? (dcsum + 16) >> 5 : (top_mb || left_mb) ? (dcsum + 8) >> 4 : 128;
 					for (int k = 0; k < 8; k++) {
-						H += (k + 1) * ((int)L.t[16 + 8 + k] - (int)L.t[16 + 6 - k]);
-						V += (k + 1) * ((int)L.t[(1 + 8 + k) * IT_STRIDE + 15] - (int)L.t[(1 + 6 - k) * IT_STRIDE + 15]);
+						H += (k + 1) * ((int)T[8 + 8 + k] - (int)T[8 + 6 - k]);
+						V += (k + 1) * ((int)T[(1 + 8 + k) * IT_STRIDE + 7] - (int)T[(1 + 6 - k) * IT_STRIDE + 7]);
 					}
-					const int a = 16 * ((int)L.t[16 * IT_STRIDE + 15] + (int)L.t[16 + 15]);
-					const int b = (5 * H + 32) >> 6, cc = (5 * V + 32) >> 6;
+					pa = 16 * ((int)T[16 * IT_STRIDE + 7] + (int)T[8 + 15]);
+					pb = (5 * H + 32) >> 6;
+					pc = (5 * V + 32) >> 6;
+					int w[16];
+					{
+						int res[16];
 #pragma unroll
-					for (int k = 0; k < 4; k++) {
-						const int px = pxb + k;
-						int v;
-						if (mi.i16_mode == 0)
-							v = L.t[16 + px];
-						else if (mi.i16_mode == 1)
-							v = L.t[(1 + py) * IT_STRIDE + 15];
-						else if (mi.i16_mode == 2)
-							v = dcv;
-						else
-							v = clip255((a + b * (px - 7) + cc * (py - 7) + 16) >> 5);
-						L.pred[py * 16 + px] = (uint8_t)v;
+						for (int i = 0; i < 16; i++) {
+							const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+							res[i] = (int)L.src[y * 16 + x] - pred16(x, y);
+						}
+						fdct4x4(res, w);
 					}
-				}
-				WAVE_SYNC();
-				int pred[16], w[16], lv[16], d[16], out[16];
-				int nn = 0;
-				const int bx = kBlkX[lane & 15], by = kBlkY[lane & 15];
-				if (lane < 16) {
-					int res[16];
-#pragma unroll
-					for (int i = 0; i < 16; i++) {
-						int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-						pred[i] = L.pred[y * 16 + x];
-						res[i] = (int)L.src[y * 16 + x] - pred[i];
-					}
-					fdct4x4(res, w);
 					L.dc[bx + 4 * by] = w[0];
-					nn = quant_dequant(w, 1, p.mf, p.dv, f_intra, p.qbits, p.qshift, lv, d);
+					cf[COEF_LUMA + l * 16] = 0;
+#pragma unroll
+					for (int i = 1; i < 16; i++) {
+						const int r = kZigzag[i], c = kPosClass[r];
+						const int lq = quant1(w[r], p.mf[c], f_intra, p.qbits);
+						cf[COEF_LUMA + l * 16 + i] = (int16_t)lq;
+						nn += lq != 0;
+						d[r] = (lq * p.dv[c]) << p.qshift;
+					}
 				}
 				WAVE_SYNC();
-				if (lane < 16) { // forward Hadamard output (i,j) = raster lane
-					const int i = lane >> 2, j = lane & 3;
+				if (is16) { // forward Hadamard output (i,j) = raster lane
+					const int i = l >> 2, j = l & 3;
 					int s = 0;
 #pragma unroll
 					for (int a = 0; a < 4; a++)
 #pragma unroll
 						for (int b = 0; b < 4; b++)
 							s += hsign(i, a) * hsign(j, b) * L.dc[4 * a + b];
-					L.dcl[lane] = quant1((s + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
+					L.dcl[l] = quant1((s + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
 				}
 				WAVE_SYNC();
-				if (lane < 16) {
-					// zig-zag position `lane` of the DC block holds raster kZigzag[lane]
-					L.coef[COEF_DC16 + lane] = (int16_t)L.dcl[kZigzag[lane]];
-					// inverse Hadamard + scaling for this lane's own block position
-					const int i = by, j = bx;
+				if (is16) {
+					cf[COEF_DC16 + l] = (int16_t)L.dcl[kZigzag[l]];
 					int s = 0;
 #pragma unroll
 					for (int a = 0; a < 4; a++)
 #pragma unroll
 						for (int b = 0; b < 4; b++)
-							s += hsign(i, a) * hsign(j, b) * L.dcl[4 * a + b];
+							s += hsign(by, a) * hsign(bx, b) * L.dcl[4 * a + b];
 					const int ls = 16 * p.dv[0];
 					d[0] = p.qp >= 36 ? (s * ls) << (p.qshift - 6) : (s * ls + (1 << (5 - p.qshift))) >> (6 - p.qshift);
-					idct4x4_add(d, pred, out);
+					int pred[16], out[16];
 #pragma unroll
-					for (int k = 1; k < 16; k++)
-						L.coef[COEF_LUMA + lane * 16 + k] = (int16_t)lv[k];
+					for (int i = 0; i < 16; i++)
+						pred[i] = pred16(4 * bx + (i & 3), 4 * by + (i >> 2));
+					idct4x4_add(d, pred, out);
+					// all predictions of the group are read before any lane writes the tile
+					__builtin_amdgcn_wave_barrier();
 #pragma unroll
 					for (int k = 0; k < 16; k++)
-						L.t[(1 + 4 * by + (k >> 2)) * IT_STRIDE + 16 + 4 * bx + (k & 3)] = (uint8_t)out[k];
-					L.nnz[bx + 4 * by] = (uint8_t)nn;
+						L.t[(1 + 4 * by + (k >> 2)) * IT_STRIDE + 8 + 4 * bx + (k & 3)] = (uint8_t)out[k];
+					p.nnz[mbaddr * NNZ_PER_MB + bx + 4 * by] = (uint8_t)nn;
 				}
-				cbp = (__ballot(nn != 0) & 0xffffull) ? 15 : 0;
-			} else {
-				// ---- Intra 4x4: blocks strictly in coding order ----
-				for (int idx = 0; idx < 16; idx++) {
-					const int bx = kBlkX[idx], by = kBlkY[idx];
-					const int tx = 16 + 4 * bx, ty = 1 + 4 * by;
-					bool ht, hl, htr;
-					blk4_avail(idx, top_mb, left_mb, tr_mb, ht, hl, htr);
-					if (lane < 15) {
-						// E[0]=E[1]=l3 E[2]=l2 E[3]=l1 E[4]=l0 E[5]=tl E[6..13]=t0..t7 E[14]=t7
-						int v;
-						if (lane <= 4) {
-							int k = lane == 0 ? 3 : 4 - lane; // left row index
-							v = L.t[(ty + k) * IT_STRIDE + tx - 1];
-						} else if (lane == 5) {
-							v = L.t[(ty - 1) * IT_STRIDE + tx - 1];
-						} else {
-							int k = lane - 6; // top index 0..8 (8 = duplicate of 7)
-							k = k > 7 ? 7 : k;
-							k = (k > 3 && !htr) ? 3 : k;
-							v = L.t[(ty - 1) * IT_STRIDE + tx + k];
-						}
-						L.E[lane] = (uint8_t)v;
-					}
-					WAVE_SYNC();
-					const int mode = __shfl(my_i4, idx, 64);
-					if (lane < 16) {
-						const int st_ = L.E[6] + L.E[7] + L.E[8] + L.E[9], sl_ = L.E[1] + L.E[2] + L.E[3] + L.E[4];
-						const int dcv = (ht && hl) ? (st_ + sl_ + 4) >> 3 : hl ? (sl_ + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
-						const int pv = pred4_px(p.pred4_tab[mode * 16 + lane], L.E, dcv);
-						L.pred4[lane] = (uint8_t)pv;
-						L.res4[lane] = (int16_t)((int)L.src[(4 * by + (lane >> 2)) * 16 + 4 * bx + (lane & 3)] - pv);
-					}
-					WAVE_SYNC();
-					if (lane == 0) {
-						int pred[16], res[16], w[16], lv[16], d[16], out[16];
-#pragma unroll
-						for (int i = 0; i < 16; i++) {
-							pred[i] = L.pred4[i];
-							res[i] = L.res4[i];
-						}
-						fdct4x4(res, w);
-						const int nn = quant_dequant(w, 0, p.mf, p.dv, f_intra, p.qbits, p.qshift, lv, d);
-						idct4x4_add(d, pred, out);
-#pragma unroll
-						for (int i = 0; i < 16; i++) {
-							L.coef[COEF_LUMA + idx * 16 + i] = (int16_t)lv[i];
-							L.t[(ty + (i >> 2)) * IT_STRIDE + tx + (i & 3)] = (uint8_t)out[i];
-						}
-						L.nnz[bx + 4 * by] = (uint8_t)nn;
-						cbp |= nn ? (1 << (idx >> 2)) : 0;
-					}
-					WAVE_SYNC();
-				}
-				cbp = __shfl(cbp, 0, 64);
+				const uint64_t bal = __ballot(is16 && nn != 0);
+				if (is16)
+					cbp = ((uint32_t)(bal >> (16 * g)) & 0xffffu) ? 15 : 0;
 			}
 
-			// ---- chroma prediction: lane = sample (x = lane&7, y = lane>>3), both planes ----
-			{
-				const int px = lane & 7, py = lane >> 3;
-#pragma unroll
-				for (int c = 0; c < 2; c++) {
-					const uint8_t *T = L.c;
-#define CT(xx, yy) T[(1 + (yy)) * IC_STRIDE + 16 + 2 * (xx) + c]
-					int v;
-					if (mi.chroma_mode == 0) {
-						const int bx = px >> 2, by = py >> 2;
-						int stp = 0, slf = 0;
-						for (int k = 0; k < 4; k++) {
-							stp += CT(4 * bx + k, -1);
-							slf += CT(-1, 4 * by + k);
-						}
-						bool use_t = top_mb, use_l = left_mb;
-						if (bx == 1 && by == 0 && top_mb)
-							use_l = false;
-						if (bx == 0 && by == 1 && left_mb)
-							use_t = false;
-						v = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
-					} else if (mi.chroma_mode == 1) {
-						v = CT(-1, py);
-					} else if (mi.chroma_mode == 2) {
-						v = CT(px, -1);
-					} else {
-						int H = 0, V = 0;
-						for (int k = 0; k < 4; k++) {
-							H += (k + 1) * ((int)CT(4 + k, -1) - (int)CT(2 - k, -1));
-							V += (k + 1) * ((int)CT(-1, 4 + k) - (int)CT(-1, 2 - k));
-						}
-						const int a = 16 * ((int)CT(-1, 7) + (int)CT(7, -1));
-						const int b = (34 * H + 32) >> 6, cc = (34 * V + 32) >> 6;
-						v = clip255((a + b * (px - 3) + cc * (py - 3) + 16) >> 5);
-					}
-#undef CT
-					L.predc[c][py * 8 + px] = (uint8_t)v;
-				}
-			}
-			WAVE_SYNC();
-			// ---- chroma residual: lanes 16..23 = (plane, block) ----
+			// ---- chroma: lanes 0..7 of the group = (plane c, block blk) ----
 			int cnn = 0, cdcnz = 0;
 			{
-				const bool is_c = lane >= 16 && lane < 24;
-				const int c = (lane - 16) >> 2, blk = (lane - 16) & 3;
+				const bool is_c = act && l < 8;
+				const int c = l >> 2, blk = l & 3;
 				const int bx = blk & 1, by = blk >> 1;
-				int cpred[16], cw_[16], clv[16], cd[16], out[16];
+				const uint8_t *T = L.c;
+				int cd[16];
+				int dcv = 128, pa = 0, pb = 0, pc = 0;
+#define CT(xx, yy) T[(1 + (yy)) * IC_STRIDE + 8 + 2 * (xx) + c]
+				auto predc = [&](int x, int y) {
+					return mi.chroma_mode == 0 ? dcv
+					     : mi.chroma_mode == 1 ? (int)CT(-1, y)
+					     : mi.chroma_mode == 2 ? (int)CT(x, -1)
+					     : clip255((pa + pb * (x - 3) + pc * (y - 3) + 16) >> 5);
+				};
 				if (is_c) {
-					int res[16];
-#pragma unroll
-					for (int i = 0; i < 16; i++) {
-						int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-						cpred[i] = L.predc[c][y * 8 + x];
-						res[i] = (int)L.srcc[y * 16 + 2 * x + c] - cpred[i];
+					int stp = 0, slf = 0, H = 0, V = 0;
+					for (int k = 0; k < 4; k++) {
+						stp += CT(4 * bx + k, -1);
+						slf += CT(-1, 4 * by + k);
+						H += (k + 1) * ((int)CT(4 + k, -1) - (int)CT(2 - k, -1));
+						V += (k + 1) * ((int)CT(-1, 4 + k) - (int)CT(-1, 2 - k));
 					}
-					fdct4x4(res, cw_);
-					L.cdc[lane - 16] = cw_[0];
+					bool use_t = top_mb, use_l = left_mb;
+					if (bx == 1 && by == 0 && top_mb)
+						use_l = false;
+					if (bx == 0 && by == 1 && left_mb)
+						use_t = false;
+					dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
+					pa = 16 * ((int)CT(-1, 7) + (int)CT(7, -1));
+					pb = (34 * H + 32) >> 6;
+					pc = (34 * V + 32) >> 6;
+					int w[16];
+					{
+						int res[16];
+#pragma unroll
+						for (int i = 0; i < 16; i++) {
+							const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+							res[i] = (int)L.srcc[y * 16 + 2 * x + c] - predc(x, y);
+						}
+						fdct4x4(res, w);
+					}
+					L.cdc[l] = w[0];
+					cf[COEF_CAC + (4 * c + blk) * 16] = 0;
+#pragma unroll
+					for (int i = 1; i < 16; i++) {
+						const int r = kZigzag[i], cl = kPosClass[r];
+						const int lq = quant1(w[r], p.mfc[cl], f_intra_c, p.qbits_c);
+						cf[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)lq;
+						cnn += lq != 0;
+						cd[r] = (lq * p.dvc[cl]) << p.qshift_c;
+					}
 				}
 				WAVE_SYNC();
 				if (is_c) {
 					const int *dcs = L.cdc + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
-					const int l = quant1(hd, p.mfc[0], 2 * f_intra_c, p.qbits_c + 1);
-					L.cdl[lane - 16] = l;
-					L.coef[COEF_CDC + 4 * c + blk] = (int16_t)l;
-					cdcnz = l != 0;
+					const int lq = quant1(hd, p.mfc[0], 2 * f_intra_c, p.qbits_c + 1);
+					L.cdl[l] = lq;
+					cf[COEF_CDC + 4 * c + blk] = (int16_t)lq;
+					cdcnz = lq != 0;
 				}
 				WAVE_SYNC();
 				if (is_c) {
 					const int *ls = L.cdl + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
-					cnn = quant_dequant(cw_, 1, p.mfc, p.dvc, f_intra_c, p.qbits_c, p.qshift_c, clv, cd);
 					cd[0] = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
-					idct4x4_add(cd, cpred, out);
-#pragma unroll
-					for (int i = 1; i < 16; i++)
-						L.coef[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)clv[i];
+					int pred[16], out[16];
 #pragma unroll
 					for (int i = 0; i < 16; i++)
-						L.c[(1 + 4 * by + (i >> 2)) * IC_STRIDE + 16 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
-					L.nnz[lane] = (uint8_t)cnn;
+						pred[i] = predc(4 * bx + (i & 3), 4 * by + (i >> 2));
+					idct4x4_add(cd, pred, out);
+#pragma unroll
+					for (int i = 0; i < 16; i++)
+						L.c[(1 + 4 * by + (i >> 2)) * IC_STRIDE + 8 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
+					p.nnz[mbaddr * NNZ_PER_MB + 16 + l] = (uint8_t)cnn;
 				}
+#undef CT
 			}
 			{
 				const uint64_t acm = __ballot(cnn != 0), dcm = __ballot(cdcnz != 0);
-				cbp |= acm ? 0x20 : (dcm ? 0x10 : 0);
+				const uint32_t ac = (uint32_t)(acm >> (16 * g)) & 0xffffu, dcb = (uint32_t)(dcm >> (16 * g)) & 0xffffu;
+				cbp |= ac ? 0x20 : (dcb ? 0x10 : 0);
 			}
 			WAVE_SYNC();
 
-			// ---- write back ----
-			if (lane < COEF_PER_MB * 2 / 16)
-				*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)L.coef + lane * 16);
-			if (lane < 16)
-				*(u32x4 *)(rec_y + (size_t)(y0 + lane) * p.cw + x0) = *(const u32x4 *)(L.t + (1 + lane) * IT_STRIDE + 16);
-			else if (lane < 24)
-				*(u32x4 *)(rec_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0) = *(const u32x4 *)(L.c + (1 + lane - 16) * IC_STRIDE + 16);
-			else if (lane < 48)
-				p.nnz[mbaddr * NNZ_PER_MB + lane - 24] = L.nnz[lane - 24];
-			if (lane == 0) {
-				MbInfo m = mi;
-				m.cbp = (int8_t)cbp;
-				p.mbi[mbaddr] = m;
+			// ---- write back reconstruction rows and the record ----
+			if (act) {
+				{
+					const uint64_t *rp = (const uint64_t *)(L.t + (1 + l) * IT_STRIDE + 8);
+					uint64_t *gp = (uint64_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
+					gp[0] = rp[0];
+					gp[1] = rp[1];
+				}
+				if (l < 8) {
+					const uint64_t *rp = (const uint64_t *)(L.c + (1 + l) * IC_STRIDE + 8);
+					uint64_t *gp = (uint64_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0);
+					gp[0] = rp[0];
+					gp[1] = rp[1];
+				}
+				if (l == 0) {
+					mi.cbp = (int8_t)cbp;
+					p.mbi[mbaddr] = mi;
+				}
 			}
-			publish_progress(s_prog, my - r0, mx + 1);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (act && l == 0)
+				__hip_atomic_store(&s_prog[my - r0], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 }
@@ -395,7 +478,15 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_intra_recon(Params p)
 int Launch::intra_recon(const Params &p, void *stream)
 {
 	dim3 grid(p.n_streams * p.slice_num);
-	hipLaunchKernelGGL(k_intra_recon, grid, dim3(64 * WF_WAVES), 0, (hipStream_t)stream, p);
+	static int waves = 0;
+	if (!waves) {
+		const char *e = getenv("CEDAR_INTRA_WAVES");
+		waves = e ? atoi(e) : 8;
+	}
+	if (waves == 16)
+		hipLaunchKernelGGL(k_intra_recon<16>, grid, dim3(64 * 16), 0, (hipStream_t)stream, p);
+	else
+		hipLaunchKernelGGL(k_intra_recon<8>, grid, dim3(64 * 8), 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 
