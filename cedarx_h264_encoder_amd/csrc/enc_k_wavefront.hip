@@ -483,10 +483,12 @@ int Launch::intra_recon(const Params &p, void *stream)
 		const char *e = getenv("CEDAR_INTRA_WAVES");
 		waves = e ? atoi(e) : 8;
 	}
+	// wavefront workgroups are throughput-bound on their CU: ask for enough (unused)
+	// dynamic LDS that two of them can never share one CU (160 KiB per CU)
 	if (waves == 16)
 		hipLaunchKernelGGL(k_intra_recon<16>, grid, dim3(64 * 16), 0, (hipStream_t)stream, p);
 	else
-		hipLaunchKernelGGL(k_intra_recon<8>, grid, dim3(64 * 8), 0, (hipStream_t)stream, p);
+		hipLaunchKernelGGL(k_intra_recon<8>, grid, dim3(64 * 8), 40 * 1024, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 
@@ -495,7 +497,13 @@ int Launch::intra_recon(const Params &p, void *stream)
 // g = lane>>4 works on row band+g, two macroblocks behind group g-1, so all 64
 // lanes are busy. Within a group the 16 lanes are the 16 sample rows of the
 // macroblock for the vertical edges and its 16 sample columns for the
-// horizontal edges; each lane filters its line in registers.
+// horizontal edges; each lane filters its line in registers (branch-free).
+//   * loads of step s+1 (samples, records) are issued at the start of step s and
+//     consumed at its end: no global latency on the dependency chain
+//   * the bottom rows a macroblock hands to the row below travel through LDS
+//     (`bot`) between groups of one wave; only band boundaries (another wave)
+//     go through memory, under the progress counters
+//   * template on the picture type: P pictures carry no strong-filter code
 // ------------------------------------------------------------------------
 #define DT_STRIDE 32 // luma tile: (x,y) at [(4+y)*32 + 16 + x], x,y in [-4,15]
 #define DC_STRIDE 32 // chroma tile (nv12): (x,y,c) at [(2+y)*32 + 16 + 2x + c], x,y in [-2,7]
@@ -503,67 +511,64 @@ int Launch::intra_recon(const Params &p, void *stream)
 struct DbGroupLds {
 	uint8_t y[20 * DT_STRIDE];
 	uint8_t c[10 * DC_STRIDE];
+	uint8_t bot[2][4 * 16];  // final bottom 4 luma rows of macroblock mx (slot mx&1)
+	uint8_t botc[2][2 * 16]; // final bottom 2 chroma rows
 };
 
-DEVI void filt_luma(int bs, int alpha, int beta, int t0, int t1, int t2,
-		    int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3)
+// normal filter (bS 1..3), branch-free; tc0 = 0 and on = false when bS == 0
+DEVI void filt_luma_n(bool on, int alpha, int beta, int tc0,
+		      int &p2, int &p1, int &p0, int &q0, int &q1, int &q2)
 {
-	if (bs == 0)
-		return;
-	if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta)
-		return;
-	const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
-	if (bs < 4) {
-		const int tc0 = bs == 1 ? t0 : bs == 2 ? t1 : t2;
-		const int tc = tc0 + (ap < beta) + (aq < beta);
-		const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-		const int avg = (p0 + q0 + 1) >> 1;
-		const int np1 = ap < beta ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
-		const int nq1 = aq < beta ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
-		p0 = clip255(p0 + delta);
-		q0 = clip255(q0 - delta);
-		p1 = np1;
-		q1 = nq1;
-	} else {
-		const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
-		int np0, np1 = p1, np2 = p2, nq0, nq1 = q1, nq2 = q2;
-		if (ap < beta && small) {
-			np0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-			np1 = (p2 + p1 + p0 + q0 + 2) >> 2;
-			np2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-		} else {
-			np0 = (2 * p1 + p0 + q1 + 2) >> 2;
-		}
-		if (aq < beta && small) {
-			nq0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-			nq1 = (p0 + q0 + q1 + q2 + 2) >> 2;
-			nq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-		} else {
-			nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-		}
-		p0 = np0; p1 = np1; p2 = np2;
-		q0 = nq0; q1 = nq1; q2 = nq2;
-	}
+	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+	const bool bp = iabs(p2 - p0) < beta, bq = iabs(q2 - q0) < beta;
+	const int tc = tc0 + (int)bp + (int)bq;
+	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+	const int avg = (p0 + q0 + 1) >> 1;
+	const int np1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1);
+	const int nq1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+	const int np0 = clip255(p0 + delta), nq0 = clip255(q0 - delta);
+	p1 = (on && bp) ? np1 : p1;
+	q1 = (on && bq) ? nq1 : q1;
+	p0 = on ? np0 : p0;
+	q0 = on ? nq0 : q0;
 }
 
-DEVI void filt_chroma(int bs, int alpha, int beta, int t0, int t1, int t2, int p1, int &p0, int &q0, int q1)
+// strong filter (bS 4, macroblock edges of intra pictures)
+DEVI void filt_luma_s(bool on, int alpha, int beta, int p3, int &p2, int &p1, int &p0,
+		      int &q0, int &q1, int &q2, int q3)
 {
-	if (bs == 0)
-		return;
-	if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta)
-		return;
-	if (bs < 4) {
-		const int tc = (bs == 1 ? t0 : bs == 2 ? t1 : t2) + 1;
-		const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-		p0 = clip255(p0 + delta);
-		q0 = clip255(q0 - delta);
-	} else {
-		const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-		p0 = np0;
-		q0 = nq0;
-	}
+	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+	const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+	const bool sp = small && iabs(p2 - p0) < beta, sq = small && iabs(q2 - q0) < beta;
+	const int np0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+	const int np1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1;
+	const int np2 = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2;
+	const int nq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+	const int nq1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
+	const int nq2 = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+	p0 = on ? np0 : p0; p1 = on ? np1 : p1; p2 = on ? np2 : p2;
+	q0 = on ? nq0 : q0; q1 = on ? nq1 : q1; q2 = on ? nq2 : q2;
 }
 
+DEVI void filt_chroma_n(bool on, int alpha, int beta, int tc0, int p1, int &p0, int &q0, int q1)
+{
+	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+	const int tc = tc0 + 1;
+	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+	const int np0 = clip255(p0 + delta), nq0 = clip255(q0 - delta);
+	p0 = on ? np0 : p0;
+	q0 = on ? nq0 : q0;
+}
+
+DEVI void filt_chroma_s(bool on, int alpha, int beta, int p1, int &p0, int &q0, int q1)
+{
+	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+	const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+	p0 = on ? np0 : p0;
+	q0 = on ? nq0 : q0;
+}
+
+template <bool IDR>
 __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 {
 	__shared__ __attribute__((aligned(16))) DbGroupLds s_g[WF_WAVES * 4];
@@ -580,158 +585,260 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 	__syncthreads();
 
 	DbGroupLds &L = s_g[wave * 4 + g];
+	const DbGroupLds &LU = s_g[wave * 4 + (g > 0 ? g - 1 : 0)]; // the row above, same wave
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int nbands = (r1 - r0 + 3) >> 2;
+	const int tc_y1 = p.tc0_y[0], tc_y2 = p.tc0_y[1], tc_y3 = p.tc0_y[2];
+	const int tc_c1 = p.tc0_c[0], tc_c2 = p.tc0_c[1], tc_c3 = p.tc0_c[2];
 
 	for (int band = wave; band < nbands; band += WF_WAVES) {
 		const int my = r0 + 4 * band + g;
 		const bool row_ok = my < r1;
 		const bool top_edge = my > r0; // picture top, or slice top with idc 2: not filtered
+		const bool xwave_top = g == 0 && band > 0; // top rows come from another wave, through memory
+		const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
 		uint32_t nz_left = 0;
 		int mvl = 0;
-		bool intra_left = false;
+
+		// prefetch registers: data of the NEXT step's macroblock
+		u32x4 r_in = u32x4{ 0, 0, 0, 0 }, r_c = r_in, r_top = r_in;
+		MbInfo r_mi{}, r_mt{};
+		uint8_t r_nz = 0, r_nzt = 0;
+		bool r_top_ok = false;
+
+		// group 0's column at a given step is `step`; prefetch is called with the
+		// column of THIS group, so the band-boundary test uses g == 0's view
+		auto prefetch_step = [&](int step, bool block) {
+			const int nmx = step - 2 * g;
+			// the readiness test must be wave-uniform: evaluate it for group 0's column
+			const int mx0 = step;
+			const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
+			const int cmx = nact ? nmx : 0;
+			const size_t a = row_mb + cmx;
+			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
+			r_in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
+			r_c = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
+			if (!IDR) {
+				r_mi = p.mbi[a];
+				r_nz = p.nnz[a * NNZ_PER_MB + l];
+				const size_t at = top_edge ? a - p.mb_w : a;
+				r_mt = p.mbi[at];
+				r_nzt = p.nnz[at * NNZ_PER_MB + l];
+			}
+			r_top_ok = true;
+			if (band > 0 && mx0 < p.mb_w) {
+				const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w;
+				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
+				if (!ready && block) {
+					wait_progress(s_prog, 4 * band - 1, need);
+					ready = true;
+				}
+				if (ready)
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				r_top_ok = ready;
+			}
+			if (xwave_top && r_top_ok && nact) {
+				if (l < 4)
+					r_top = *(const u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0);
+				else if (l < 6)
+					r_top = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) - 2 + l - 4) * p.cw + x0);
+			}
+		};
+
+		// stage the data of a step (already in the r_* registers) into the LDS tiles
+		auto stage = [&](int step) {
+			const int mx = step - 2 * g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+			if (!act)
+				return;
+			if (mx > 0) { // previous macroblock's last 4 columns become the left neighbours
+				*(uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 28);
+				if (l < 8)
+					*(uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 28);
+			}
+			*(u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16) = r_in;
+			if (l < 8)
+				*(u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16) = r_c;
+			if (top_edge) {
+				if (g > 0) { // from the group above, through LDS
+					if (l < 4)
+						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 1] + l * 16);
+					else if (l < 6)
+						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 1] + (l - 4) * 16);
+				} else {     // from the wave above, through memory
+					if (l < 4)
+						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = r_top;
+					else if (l < 6)
+						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = r_top;
+				}
+			}
+		};
+
+		// prologue: data of step 0
+		prefetch_step(0, true);
+		WAVE_SYNC();
+		int pending_pub = -1; // macroblock column whose stores are in flight, per group
 
 		for (int step = 0; step < p.mb_w + 6; step++) {
 			const int mx = step - 2 * g;
 			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
-			// group 0 depends on the last row of the previous band (another wave)
-			if (band > 0) {
-				const int mx0 = step; // group 0's column
-				if (mx0 < p.mb_w)
-					wait_progress(s_prog, 4 * band - 1, mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w);
-			}
-			const int x0 = mx * 16, y0 = my * 16;
-			const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
 			const bool left_edge = mx > 0;
-			MbInfo mi = p.mbi[mbaddr];
-			MbInfo mt = mi;
-			uint8_t nzb = p.nnz[mbaddr * NNZ_PER_MB + l], nzt_b = 0;
-			if (act) {
-				// keep the previous macroblock's last 4 columns as this one's left neighbours
-				if (left_edge) {
-					*(uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 28);
-					if (l < 8)
-						*(uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 28);
-				}
-				*(u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16) = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
-				if (l < 8)
-					*(u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16) = *(const u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0);
-				if (top_edge) {
-					if (l < 4)
-						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = *(const u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0);
-					else if (l < 6)
-						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0);
-					mt = p.mbi[mbaddr - p.mb_w];
-					nzt_b = p.nnz[(mbaddr - p.mb_w) * NNZ_PER_MB + l];
-				}
+			const int x0 = mx * 16, y0 = my * 16;
+			// this step's records (prefetched) before the registers are reused
+			const MbInfo mi = r_mi, mt = r_mt;
+			const uint8_t nzb = r_nz, nzt_b = r_nzt;
+			if (!r_top_ok) // band boundary not ready when prefetched: fetch now, blocking
+				prefetch_step(step, true);
+			stage(step);
+			// issue the loads of the next step; they complete while this step computes
+			prefetch_step(step + 1, false);
+
+			uint32_t nz_cur = 0, nz_top = 0;
+			int mvc = 0, mvt = 0;
+			if (!IDR) {
+				const uint64_t bal_c = __ballot(act && nzb != 0), bal_t = __ballot(act && top_edge && nzt_b != 0);
+				nz_cur = (uint32_t)(bal_c >> (16 * g)) & 0xffffu;
+				nz_top = (uint32_t)(bal_t >> (16 * g)) & 0xffffu;
+				mvc = ((int)mi.mvx << 16) ^ ((int)mi.mvy & 0xffff);
+				mvt = ((int)mt.mvx << 16) ^ ((int)mt.mvy & 0xffff);
 			}
-			const uint64_t bal_c = __ballot(act && nzb != 0), bal_t = __ballot(act && nzt_b != 0);
-			const uint32_t nz_cur = (uint32_t)(bal_c >> (16 * g)) & 0xffffu;
-			const uint32_t nz_top = (uint32_t)(bal_t >> (16 * g)) & 0xffffu;
-			const bool intra_cur = mi.type <= MB_I16x16, intra_top = mt.type <= MB_I16x16;
-			const int mvc = ((int)mi.mvx << 16) ^ ((int)mi.mvy & 0xffff);
-			const int mvt = ((int)mt.mvx << 16) ^ ((int)mt.mvy & 0xffff);
 			WAVE_SYNC();
 
+			const int k = l >> 2; // 4-sample segment of this lane's line
 			if (act) {
-				const int k = l >> 2; // 4-sample segment of this lane's line
 				// ---- vertical edges: lane = sample row l ----
-				{
-					int bs[4];
+				int bs[4];
+				if (IDR) {
+					bs[0] = left_edge ? 4 : 0;
+					bs[1] = bs[2] = bs[3] = 3;
+				} else {
 					bs[0] = !left_edge ? 0
-						: (intra_cur || intra_left) ? 4
 						: (((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1) ? 2
 						: (mvc != mvl) ? 1 : 0;
 #pragma unroll
 					for (int e = 1; e < 4; e++)
-						bs[e] = intra_cur ? 3 : (((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1) ? 2 : 0;
-					int px[20];
-					const uint32_t *rowp = (const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
+						bs[e] = (((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1) ? 2 : 0;
+				}
+				int px[20];
+				const uint32_t *rowp = (const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
 #pragma unroll
-					for (int w = 0; w < 5; w++) {
-						uint32_t v = rowp[w];
-						px[4 * w] = v & 0xff;
-						px[4 * w + 1] = (v >> 8) & 0xff;
-						px[4 * w + 2] = (v >> 16) & 0xff;
-						px[4 * w + 3] = v >> 24;
-					}
+				for (int w = 0; w < 5; w++) {
+					const uint32_t v = rowp[w];
+					px[4 * w] = v & 0xff;
+					px[4 * w + 1] = (v >> 8) & 0xff;
+					px[4 * w + 2] = (v >> 16) & 0xff;
+					px[4 * w + 3] = v >> 24;
+				}
 #pragma unroll
-					for (int e = 0; e < 4; e++) {
-						const int q = 4 + 4 * e;
-						filt_luma(bs[e], p.alpha_y, p.beta_y, p.tc0_y[0], p.tc0_y[1], p.tc0_y[2],
-							  px[q - 4], px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2], px[q + 3]);
-					}
-					uint32_t *roww = (uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
+				for (int e = 0; e < 4; e++) {
+					const int q = 4 + 4 * e;
+					if (IDR && e == 0)
+						filt_luma_s(bs[0] != 0, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+							    px[q], px[q + 1], px[q + 2], px[q + 3]);
+					else
+						filt_luma_n(bs[e] != 0, p.alpha_y, p.beta_y,
+							    bs[e] == 1 ? tc_y1 : bs[e] == 2 ? tc_y2 : bs[e] == 3 ? tc_y3 : 0,
+							    px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
+				}
+				uint32_t *roww = (uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
 #pragma unroll
-					for (int w = 0; w < 5; w++)
-						roww[w] = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
-					// chroma: lane = (plane c = l>>3, chroma row r = l&7); edges at chroma x = 0 and 4
-					{
-						const int c = l >> 3, r = l & 7, ks = r >> 1;
-						int bsc0 = !left_edge ? 0
-							: (intra_cur || intra_left) ? 4
+				for (int w = 0; w < 5; w++)
+					roww[w] = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
+				// chroma: lane = (plane c = l>>3, chroma row r = l&7); edges at chroma x = 0 and 4
+				{
+					const int c = l >> 3, r = l & 7, ks = r >> 1;
+					int bsc0, bsc2;
+					if (IDR) {
+						bsc0 = left_edge ? 4 : 0;
+						bsc2 = 3;
+					} else {
+						bsc0 = !left_edge ? 0
 							: (((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1) ? 2
 							: (mvc != mvl) ? 1 : 0;
-						int bsc2 = intra_cur ? 3 : (((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1) ? 2 : 0;
-						uint8_t *cp = L.c + (2 + r) * DC_STRIDE + 16 + c;
-						int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
-						filt_chroma(bsc0, p.alpha_c, p.beta_c, p.tc0_c[0], p.tc0_c[1], p.tc0_c[2], a1, a0, b0, b1);
-						cp[-2] = (uint8_t)a0;
-						cp[0] = (uint8_t)b0;
-						int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
-						filt_chroma(bsc2, p.alpha_c, p.beta_c, p.tc0_c[0], p.tc0_c[1], p.tc0_c[2], c1, c0, d0, d1);
-						cp[6] = (uint8_t)c0;
-						cp[8] = (uint8_t)d0;
+						bsc2 = (((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1) ? 2 : 0;
 					}
+					uint8_t *cp = L.c + (2 + r) * DC_STRIDE + 16 + c;
+					int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
+					int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
+					if (IDR)
+						filt_chroma_s(bsc0 != 0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+					else
+						filt_chroma_n(bsc0 != 0, p.alpha_c, p.beta_c, bsc0 == 1 ? tc_c1 : bsc0 == 2 ? tc_c2 : 0, a1, a0, b0, b1);
+					filt_chroma_n(bsc2 != 0, p.alpha_c, p.beta_c, bsc2 == 2 ? tc_c2 : bsc2 == 3 ? tc_c3 : 0, c1, c0, d0, d1);
+					cp[-2] = (uint8_t)a0;
+					cp[0] = (uint8_t)b0;
+					cp[6] = (uint8_t)c0;
+					cp[8] = (uint8_t)d0;
 				}
 			}
 			WAVE_SYNC();
 			if (act) {
-				const int k = l >> 2;
 				// ---- horizontal edges: lane = sample column l ----
-				{
-					int bs[4];
+				int bs[4];
+				if (IDR) {
+					bs[0] = top_edge ? 4 : 0;
+					bs[1] = bs[2] = bs[3] = 3;
+				} else {
 					bs[0] = !top_edge ? 0
-						: (intra_cur || intra_top) ? 4
 						: (((nz_cur >> k) | (nz_top >> (12 + k))) & 1) ? 2
 						: (mvc != mvt) ? 1 : 0;
 #pragma unroll
 					for (int e = 1; e < 4; e++)
-						bs[e] = intra_cur ? 3 : (((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1) ? 2 : 0;
-					int py[20];
-					uint8_t *colp = L.y + 16 + l;
+						bs[e] = (((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1) ? 2 : 0;
+				}
+				int py[20];
+				uint8_t *colp = L.y + 16 + l;
 #pragma unroll
-					for (int r = 0; r < 20; r++)
-						py[r] = colp[r * DT_STRIDE];
+				for (int r = 0; r < 20; r++)
+					py[r] = colp[r * DT_STRIDE];
 #pragma unroll
-					for (int e = 0; e < 4; e++) {
-						const int q = 4 + 4 * e;
-						filt_luma(bs[e], p.alpha_y, p.beta_y, p.tc0_y[0], p.tc0_y[1], p.tc0_y[2],
-							  py[q - 4], py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2], py[q + 3]);
-					}
+				for (int e = 0; e < 4; e++) {
+					const int q = 4 + 4 * e;
+					if (IDR && e == 0)
+						filt_luma_s(bs[0] != 0, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+							    py[q], py[q + 1], py[q + 2], py[q + 3]);
+					else
+						filt_luma_n(bs[e] != 0, p.alpha_y, p.beta_y,
+							    bs[e] == 1 ? tc_y1 : bs[e] == 2 ? tc_y2 : bs[e] == 3 ? tc_y3 : 0,
+							    py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
+				}
 #pragma unroll
-					for (int r = 1; r < 19; r++)
-						colp[r * DT_STRIDE] = (uint8_t)py[r];
-					// chroma: lane = byte column l of the nv12 row (plane l&1, chroma x = l>>1)
-					{
-						int bsc0 = bs[0];
-						int bsc2 = bs[2];
-						uint8_t *cp = L.c + 16 + l;
-						int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
-						filt_chroma(bsc0, p.alpha_c, p.beta_c, p.tc0_c[0], p.tc0_c[1], p.tc0_c[2], a1, a0, b0, b1);
-						cp[DC_STRIDE] = (uint8_t)a0;
-						cp[2 * DC_STRIDE] = (uint8_t)b0;
-						int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
-						filt_chroma(bsc2, p.alpha_c, p.beta_c, p.tc0_c[0], p.tc0_c[1], p.tc0_c[2], c1, c0, d0, d1);
-						cp[5 * DC_STRIDE] = (uint8_t)c0;
-						cp[6 * DC_STRIDE] = (uint8_t)d0;
-					}
+				for (int r = 1; r < 19; r++)
+					colp[r * DT_STRIDE] = (uint8_t)py[r];
+				// chroma: lane = byte column l of the nv12 row (plane l&1, chroma x = l>>1)
+				{
+					uint8_t *cp = L.c + 16 + l;
+					int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
+					int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
+					if (IDR)
+						filt_chroma_s(bs[0] != 0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+					else
+						filt_chroma_n(bs[0] != 0, p.alpha_c, p.beta_c, bs[0] == 1 ? tc_c1 : bs[0] == 2 ? tc_c2 : 0, a1, a0, b0, b1);
+					filt_chroma_n(bs[2] != 0, p.alpha_c, p.beta_c, bs[2] == 2 ? tc_c2 : bs[2] == 3 ? tc_c3 : 0, c1, c0, d0, d1);
+					cp[DC_STRIDE] = (uint8_t)a0;
+					cp[2 * DC_STRIDE] = (uint8_t)b0;
+					cp[5 * DC_STRIDE] = (uint8_t)c0;
+					cp[6 * DC_STRIDE] = (uint8_t)d0;
 				}
 			}
 			WAVE_SYNC();
+			// everything older (last step's stores, this step's prefetch) has long completed
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (pending_pub >= 0 && l == 0)
+				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			pending_pub = -1;
 			if (act) {
-				// ---- write back: interior, 4 left columns, 4 top rows ----
+				// ---- hand the bottom rows to the row below (LDS), then write back ----
+				if (l >= 12) {
+					*(u32x4 *)(L.bot[mx & 1] + (l - 12) * 16) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
+					if (left_edge) // columns 12..15 of the previous macroblock are final only now
+						*(uint32_t *)(L.bot[(mx - 1) & 1] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
+				} else if (l >= 6 && l < 8) {
+					*(u32x4 *)(L.botc[mx & 1] + (l - 6) * 16) = *(const u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16);
+					if (left_edge)
+						*(uint32_t *)(L.botc[(mx - 1) & 1] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
+				}
 				*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
 				if (left_edge)
 					*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
@@ -748,20 +855,25 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				}
 				nz_left = nz_cur;
 				mvl = mvc;
-				intra_left = intra_cur;
+				pending_pub = mx;
 			}
-			// publish: one lane per group, after this wave's stores have completed
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (act && l == 0)
-				__hip_atomic_store(&s_prog[my - r0], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			WAVE_SYNC();
 		}
+		// drain: publish the last macroblock of every row of the band
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (pending_pub >= 0 && l == 0)
+			__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 }
 
 int Launch::deblock(const Params &p, void *stream)
 {
 	dim3 grid(p.n_streams * p.slice_num);
-	hipLaunchKernelGGL(k_deblock, grid, dim3(64 * WF_WAVES), 0, (hipStream_t)stream, p);
+	const unsigned pad_lds = 12 * 1024; // 74 KiB static + 12 KiB > 80 KiB: one workgroup per CU
+	if (p.is_idr)
+		hipLaunchKernelGGL(k_deblock<true>, grid, dim3(64 * WF_WAVES), pad_lds, (hipStream_t)stream, p);
+	else
+		hipLaunchKernelGGL(k_deblock<false>, grid, dim3(64 * WF_WAVES), pad_lds, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 
