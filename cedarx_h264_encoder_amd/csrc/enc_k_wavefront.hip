@@ -622,7 +622,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			if (!IDR) {
 				r_mi = p.mbi[a];
 				r_nz = p.nnz[a * NNZ_PER_MB + l];
-				const size_t at = top_edge ? a - p.mb_w : a;
+				const size_t at = (top_edge && row_ok) ? a - p.mb_w : a; // inactive row groups stay in bounds
 				r_mt = p.mbi[at];
 				r_nzt = p.nnz[at * NNZ_PER_MB + l];
 			}

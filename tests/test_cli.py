@@ -1,0 +1,95 @@
+"""The reference's command line (userspace/h264enc.c:134-201) on both twins:
+  * oracle/build/h264enc_scalar -- BASELINE configs[0]: 320x240 nv12, I-frame only,
+    QP 30, scalar C macroblock loop, no GPU, no /dev/cedar (runs on CPU here)
+  * cedarx_h264_encoder_amd/lib/h264enc -- the HIP path (GPU only)
+Same argv, stdin pumping, short-read behaviour and exit codes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCALAR = os.path.join(ROOT, "oracle", "build", "h264enc_scalar")
+HIPCLI = os.path.join(ROOT, "cedarx_h264_encoder_amd", "lib", "h264enc")
+
+
+def _raw(pattern, w, h, frames):
+    out = bytearray()
+    for f in range(frames):
+        y, uv = ol.gen_frame(pattern, w, h, f)
+        out += y.tobytes() + uv.tobytes()
+    return bytes(out)
+
+
+def _decode_all(stream, frames):
+    dec = ol.OracleDecoder()
+    starts = [i for i in range(len(stream) - 4) if stream[i:i + 4] == b"\0\0\0\1"]
+    # split into access units at each slice NAL (type 1 or 5) with first_mb == 0 is overkill here:
+    # one slice per picture, so every slice NAL ends an access unit
+    n, au_start = 0, 0
+    for k, s in enumerate(starts):
+        t = stream[s + 4] & 0x1f
+        if t in (1, 5):
+            e = starts[k + 1] if k + 1 < len(starts) else len(stream)
+            assert dec.decode(stream[au_start:e]) == 1
+            au_start = e
+            n += 1
+    assert n == frames
+    return dec
+
+
+def test_scalar_cli_config0_320x240_intra_only(tmp_path):
+    """configs[0]: 320x240 nv12 I-frame-only QP=30 through the scalar C loop, via stdin."""
+    w, h, frames = 320, 240, 4
+    raw = _raw("B", w, h, frames)
+    out = tmp_path / "out.264"
+    env = dict(os.environ, H264ENC_QP="30", H264ENC_KEYINT="1")
+    r = subprocess.run([SCALAR, "-", str(w), str(h), str(out)], input=raw + b"\x00" * 100,  # trailing partial frame is dropped
+                       capture_output=True, env=env, timeout=120)
+    assert r.returncode == 0
+    assert b"Frame     3:" in r.stdout
+    stream = out.read_bytes()
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=1))
+    want = b"".join(enc.encode(*ol.gen_frame("B", w, h, f)) for f in range(frames))
+    assert stream == want
+    dec = _decode_all(stream, frames)
+    assert dec.crop_size() == (w, h)
+    nal_types = [stream[i + 4] & 0x1f for i in range(len(stream) - 4) if stream[i:i + 4] == b"\0\0\0\1"]
+    assert nal_types == [7, 8, 5, 5, 5, 5]
+
+
+def test_scalar_cli_usage_and_errors(tmp_path):
+    r = subprocess.run([SCALAR, "-", "320"], capture_output=True)
+    assert r.returncode == 255 and b"Usage:" in r.stdout      # return -1 (h264enc.c:141-144)
+    r = subprocess.run([SCALAR, str(tmp_path / "missing.yuv"), "320", "240", str(tmp_path / "o.264")], capture_output=True)
+    assert r.returncode == 255 and b"Failed to open input file" in r.stderr
+    r = subprocess.run([SCALAR, "-", "321", "240", str(tmp_path / "o.264")], input=b"", capture_output=True)
+    assert r.returncode != 0 and b"config failed" in r.stderr  # odd width: EINVAL (cedar.c:749)
+
+
+@pytest.mark.gpu
+def test_hip_cli_equals_scalar_cli(tmp_path):
+    """README.md:25-36 use: raw nv12 on stdin, 854x480 (not a multiple of 16), I+P."""
+    w, h, frames = 854, 480, 5
+    raw = _raw("B", w, h, frames)
+    env = dict(os.environ, H264ENC_QP="30", H264ENC_KEYINT="25")
+    a, b = tmp_path / "hip.264", tmp_path / "cpu.264"
+    r = subprocess.run([HIPCLI, "-", str(w), str(h), str(a)], input=raw, capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert b"Frame     4:" in r.stdout
+    r2 = subprocess.run([SCALAR, "-", str(w), str(h), str(b)], input=raw, capture_output=True, env=env, timeout=300)
+    assert r2.returncode == 0
+    assert a.read_bytes() == b.read_bytes()
+    dec = _decode_all(a.read_bytes(), frames)
+    assert dec.crop_size() == (w, h)
+
+
+@pytest.mark.gpu
+def test_hip_cli_usage_and_config_error(tmp_path):
+    r = subprocess.run([HIPCLI, "-", "320"], capture_output=True)
+    assert r.returncode == 255 and b"Usage:" in r.stdout
+    r = subprocess.run([HIPCLI, "-", "321", "240", str(tmp_path / "o.264")], input=b"", capture_output=True)
+    assert r.returncode != 0 and b"CEDAR_IOCTL_CONFIG failed" in r.stderr

@@ -33,6 +33,8 @@ CASES = [
     (64, 48, 47, 3, 4, "B", 1),      # highest QP the reference accepts
     (16, 16, 24, 2, 4, "C", 1),      # single macroblock
     (432, 32, 24, 3, 4, "B", 1),
+    (64, 80, 24, 3, 4, "B", 1),      # 5 macroblock rows: idle row groups in the last band
+    (96, 112, 30, 25, 4, "C", 1),    # 7 rows
     (854, 480, 30, 25, 3, "B", 1),   # BASELINE configs[1] shape (README's 854x480)
 ]
 
@@ -98,6 +100,22 @@ def test_4k_four_slices_decodable_and_matches_oracle_first_frames(ce):
             got = ge.encode_frame(y, uv)
             if f < 2:
                 assert got == oe.encode(y, uv), "frame %d" % f
+            assert dec.decode(got) == 1
+            dy, duv = dec.picture()
+            assert np.array_equal(dy, ge.debug_read("recon_y"))
+            assert np.array_equal(duv, ge.debug_read("recon_uv"))
+
+
+def test_4k_single_slice_row_count_not_multiple_of_four(ce):
+    """3840x2160 as ONE slice: 135 macroblock rows = 33 bands of 4 + 3, so the last
+    band of both wavefront kernels has an idle row group (regression: its prefetch
+    once indexed row -1). Checked by decode(stream) == reconstruction."""
+    w, h = 3840, 2160
+    dec = ol.OracleDecoder()
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25) as ge:
+        for f in range(4):
+            y, uv = ce.gen_pattern("B", w, h, f)
+            got = ge.encode_frame(y, uv)
             assert dec.decode(got) == 1
             dy, duv = dec.picture()
             assert np.array_equal(dy, ge.debug_read("recon_y"))
