@@ -17,6 +17,24 @@ namespace cedar {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// XCD-aware block order. Workgroups are dealt round-robin over the 8 XCDs (each
+// with its own 4 MiB L2), so neighbouring macroblocks, whose reference windows
+// overlap by 8/9, would land on different L2s and every window would be fetched
+// from the memory side (measured: 8x the algorithmic bytes). Renumber so that the
+// blocks sharing an XCD (equal id % 8) own one contiguous run of macroblocks.
+// Bijective for any block count (guide: T1). Speed only, never correctness.
+DEVI void xcd_mb(const Params &p, int &mx, int &my, int &st)
+{
+	const uint32_t nb = gridDim.x, hb = blockIdx.x;
+	const uint32_t xcd = hb & 7u, i = hb >> 3, q = nb >> 3, r = nb & 7u;
+	const uint32_t lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+	const uint32_t per_stream = (uint32_t)(p.mb_w * p.row_num);
+	st = (int)(lb / per_stream);
+	const uint32_t m = lb - (uint32_t)st * per_stream;
+	my = p.row_first + (int)(m / (uint32_t)p.mb_w);
+	mx = (int)(m % (uint32_t)p.mb_w);
+}
+
 // ------------------------------------------------------------------------
 // k_input: tightly packed width x height nv12 -> padded coded-size planes
 // (edge replication right/bottom). One thread per 16 output bytes.
@@ -85,7 +103,8 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	__shared__ int s_cdc[8];
 
 	const int lane = threadIdx.x;
-	const int mx = blockIdx.x, my = p.row_first + blockIdx.y, st = blockIdx.z;
+	int mx, my, st;
+	xcd_mb(p, mx, my, st);
 	const int x0 = mx * 16, y0 = my * 16;
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
@@ -140,16 +159,20 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 		const int dyi = t / 9, g = t - dyi * 9;
 		const int dy = dyi - 16, dx0 = 4 * g - 16;
 		const uint8_t *base = s_ref + dyi * REF_STRIDE + 4 * g;
-		uint64_t acc = 0;
+		// four independent accumulators (one per 4-sample segment) keep the qsad
+		// pipeline full; each lane's 4 x u16 partial SADs are summed afterwards
+		uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
 		for (int r = 0; r < 16; r++) {
 			const uint32_t *rp = (const uint32_t *)(base + r * REF_STRIDE);
 			uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3], w4 = rp[4];
-			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w1 << 32) | w0, curd[4 * r + 0], acc);
-			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w2 << 32) | w1, curd[4 * r + 1], acc);
-			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w3 << 32) | w2, curd[4 * r + 2], acc);
-			acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w4 << 32) | w3, curd[4 * r + 3], acc);
+			a0 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w1 << 32) | w0, curd[4 * r + 0], a0);
+			a1 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w2 << 32) | w1, curd[4 * r + 1], a1);
+			a2 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w3 << 32) | w2, curd[4 * r + 2], a2);
+			a3 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w4 << 32) | w3, curd[4 * r + 3], a3);
 		}
+		// per-u16 sums cannot carry: a full 16x16 SAD is at most 65280
+		const uint64_t acc = (a0 + a1) + (a2 + a3);
 		const bool yok = tvalid && dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
 		const int cost_y = p.lambda * mv_bits(dy);
 #pragma unroll
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 
 int Launch::inter(const Params &p, void *stream)
 {
-	dim3 grid(p.mb_w, p.row_num, p.n_streams);
+	dim3 grid(p.mb_w * p.row_num * p.n_streams);
 	hipLaunchKernelGGL(k_inter, grid, dim3(64), 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
@@ -299,7 +322,8 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 	__shared__ uint32_t s_key[16][9];      // sad<<4 | mode per (block, mode)
 
 	const int lane = threadIdx.x;
-	const int mx = blockIdx.x, my = p.row_first + blockIdx.y, st = blockIdx.z;
+	int mx, my, st;
+	xcd_mb(p, mx, my, st);
 	const int x0 = mx * 16, y0 = my * 16;
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 
 int Launch::intra_decide(const Params &p, void *stream)
 {
-	dim3 grid(p.mb_w, p.row_num, p.n_streams);
+	dim3 grid(p.mb_w * p.row_num * p.n_streams);
 	hipLaunchKernelGGL(k_intra_decide, grid, dim3(64), 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }

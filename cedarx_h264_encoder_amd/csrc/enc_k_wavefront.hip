@@ -515,57 +515,68 @@ struct DbGroupLds {
 	uint8_t botc[2][2 * 16]; // final bottom 2 chroma rows
 };
 
-// normal filter (bS 1..3), branch-free; tc0 = 0 and on = false when bS == 0
-DEVI void filt_luma_n(bool on, int alpha, int beta, int tc0,
+// All filters are pure integer mask arithmetic (a comparison becomes the sign bit
+// of a difference, a select becomes an AND with 0 / -1): hipcc turns `c ? a : b`
+// chains into exec-mask branches, ~80 regions per step, which saturate the CU's
+// one scalar pipe that all 16 waves of the workgroup share.
+DEVI int lt_mask(int a, int b) { return (a - b) >> 31; }          // a < b ? -1 : 0  (|a|,|b| < 2^30)
+DEVI int nz_mask(int v) { return (v | -v) >> 31; }               // v != 0 ? -1 : 0
+DEVI int sel(int m, int a, int b) { return b ^ ((a ^ b) & m); }  // m ? a : b for m in {0,-1}
+
+// normal filter (bS 1..3). tcw = tc0 values for bS 0..3 packed one per byte (byte 0 = 0).
+DEVI void filt_luma_n(int bs, int alpha, int beta, uint32_t tcw,
 		      int &p2, int &p1, int &p0, int &q0, int &q1, int &q2)
 {
-	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
-	const bool bp = iabs(p2 - p0) < beta, bq = iabs(q2 - q0) < beta;
-	const int tc = tc0 + (int)bp + (int)bq;
-	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+	const int tc0 = (int)((tcw >> (8 * bs)) & 0xffu);
+	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
+	m = (m >> 31) & nz_mask(bs);
+	const int mp = lt_mask(iabs(p2 - p0), beta), mq = lt_mask(iabs(q2 - q0), beta);
+	const int tc = tc0 - mp - mq;
+	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3) & m;
 	const int avg = (p0 + q0 + 1) >> 1;
-	const int np1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1);
-	const int nq1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
-	const int np0 = clip255(p0 + delta), nq0 = clip255(q0 - delta);
-	p1 = (on && bp) ? np1 : p1;
-	q1 = (on && bq) ? nq1 : q1;
-	p0 = on ? np0 : p0;
-	q0 = on ? nq0 : q0;
+	const int dp1 = clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) & m & mp;
+	const int dq1 = clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) & m & mq;
+	p0 = clip255(p0 + delta);
+	q0 = clip255(q0 - delta);
+	p1 += dp1;
+	q1 += dq1;
 }
 
-// strong filter (bS 4, macroblock edges of intra pictures)
-DEVI void filt_luma_s(bool on, int alpha, int beta, int p3, int &p2, int &p1, int &p0,
+// strong filter (bS 4, macroblock edges of intra pictures); bs is 0 or 4
+DEVI void filt_luma_s(int bs, int alpha, int beta, int p3, int &p2, int &p1, int &p0,
 		      int &q0, int &q1, int &q2, int q3)
 {
-	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
-	const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
-	const bool sp = small && iabs(p2 - p0) < beta, sq = small && iabs(q2 - q0) < beta;
-	const int np0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-	const int np1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1;
-	const int np2 = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2;
-	const int nq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-	const int nq1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
-	const int nq2 = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
-	p0 = on ? np0 : p0; p1 = on ? np1 : p1; p2 = on ? np2 : p2;
-	q0 = on ? nq0 : q0; q1 = on ? nq1 : q1; q2 = on ? nq2 : q2;
+	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
+	m = (m >> 31) & nz_mask(bs);
+	const int small = lt_mask(iabs(p0 - q0), (alpha >> 2) + 2);
+	const int sp = small & lt_mask(iabs(p2 - p0), beta), sq = small & lt_mask(iabs(q2 - q0), beta);
+	const int np0 = sel(sp, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, (2 * p1 + p0 + q1 + 2) >> 2);
+	const int np1 = sel(sp, (p2 + p1 + p0 + q0 + 2) >> 2, p1);
+	const int np2 = sel(sp, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2);
+	const int nq0 = sel(sq, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, (2 * q1 + q0 + p1 + 2) >> 2);
+	const int nq1 = sel(sq, (p0 + q0 + q1 + q2 + 2) >> 2, q1);
+	const int nq2 = sel(sq, (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3, q2);
+	p0 = sel(m, np0, p0); p1 = sel(m, np1, p1); p2 = sel(m, np2, p2);
+	q0 = sel(m, nq0, q0); q1 = sel(m, nq1, q1); q2 = sel(m, nq2, q2);
 }
 
-DEVI void filt_chroma_n(bool on, int alpha, int beta, int tc0, int p1, int &p0, int &q0, int q1)
+DEVI void filt_chroma_n(int bs, int alpha, int beta, uint32_t tcw, int p1, int &p0, int &q0, int q1)
 {
-	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
-	const int tc = tc0 + 1;
-	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-	const int np0 = clip255(p0 + delta), nq0 = clip255(q0 - delta);
-	p0 = on ? np0 : p0;
-	q0 = on ? nq0 : q0;
+	const int tc = (int)((tcw >> (8 * bs)) & 0xffu) + 1;
+	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
+	m = (m >> 31) & nz_mask(bs);
+	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3) & m;
+	p0 = clip255(p0 + delta);
+	q0 = clip255(q0 - delta);
 }
 
-DEVI void filt_chroma_s(bool on, int alpha, int beta, int p1, int &p0, int &q0, int q1)
+DEVI void filt_chroma_s(int bs, int alpha, int beta, int p1, int &p0, int &q0, int q1)
 {
-	on = on && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
+	m = (m >> 31) & nz_mask(bs);
 	const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-	p0 = on ? np0 : p0;
-	q0 = on ? nq0 : q0;
+	p0 = sel(m, np0, p0);
+	q0 = sel(m, nq0, q0);
 }
 
 template <bool IDR>
@@ -589,8 +600,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int nbands = (r1 - r0 + 3) >> 2;
-	const int tc_y1 = p.tc0_y[0], tc_y2 = p.tc0_y[1], tc_y3 = p.tc0_y[2];
-	const int tc_c1 = p.tc0_c[0], tc_c2 = p.tc0_c[1], tc_c3 = p.tc0_c[2];
+	const uint32_t tcw_y = ((uint32_t)p.tc0_y[0] << 8) | ((uint32_t)p.tc0_y[1] << 16) | ((uint32_t)p.tc0_y[2] << 24);
+	const uint32_t tcw_c = ((uint32_t)p.tc0_c[0] << 8) | ((uint32_t)p.tc0_c[1] << 16) | ((uint32_t)p.tc0_c[2] << 24);
 
 	for (int band = wave; band < nbands; band += WF_WAVES) {
 		const int my = r0 + 4 * band + g;
@@ -713,12 +724,11 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 					bs[0] = left_edge ? 4 : 0;
 					bs[1] = bs[2] = bs[3] = 3;
 				} else {
-					bs[0] = !left_edge ? 0
-						: (((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1) ? 2
-						: (mvc != mvl) ? 1 : 0;
+					const int nzb0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
+					bs[0] = (2 * nzb0 + ((1 - nzb0) & (nz_mask(mvc ^ mvl) & 1))) & -(int)left_edge;
 #pragma unroll
 					for (int e = 1; e < 4; e++)
-						bs[e] = (((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1) ? 2 : 0;
+						bs[e] = 2 * (int)(((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1u);
 				}
 				int px[20];
 				const uint32_t *rowp = (const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
@@ -734,11 +744,10 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				for (int e = 0; e < 4; e++) {
 					const int q = 4 + 4 * e;
 					if (IDR && e == 0)
-						filt_luma_s(bs[0] != 0, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+						filt_luma_s(bs[0], p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
 							    px[q], px[q + 1], px[q + 2], px[q + 3]);
 					else
-						filt_luma_n(bs[e] != 0, p.alpha_y, p.beta_y,
-							    bs[e] == 1 ? tc_y1 : bs[e] == 2 ? tc_y2 : bs[e] == 3 ? tc_y3 : 0,
+						filt_luma_n(bs[e], p.alpha_y, p.beta_y, tcw_y,
 							    px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
 				}
 				uint32_t *roww = (uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
@@ -753,19 +762,18 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 						bsc0 = left_edge ? 4 : 0;
 						bsc2 = 3;
 					} else {
-						bsc0 = !left_edge ? 0
-							: (((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1) ? 2
-							: (mvc != mvl) ? 1 : 0;
-						bsc2 = (((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1) ? 2 : 0;
+						const int nzc0 = (int)(((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1u);
+						bsc0 = (2 * nzc0 + ((1 - nzc0) & (nz_mask(mvc ^ mvl) & 1))) & -(int)left_edge;
+						bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
 					}
 					uint8_t *cp = L.c + (2 + r) * DC_STRIDE + 16 + c;
 					int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
 					int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
 					if (IDR)
-						filt_chroma_s(bsc0 != 0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+						filt_chroma_s(bsc0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
 					else
-						filt_chroma_n(bsc0 != 0, p.alpha_c, p.beta_c, bsc0 == 1 ? tc_c1 : bsc0 == 2 ? tc_c2 : 0, a1, a0, b0, b1);
-					filt_chroma_n(bsc2 != 0, p.alpha_c, p.beta_c, bsc2 == 2 ? tc_c2 : bsc2 == 3 ? tc_c3 : 0, c1, c0, d0, d1);
+						filt_chroma_n(bsc0, p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
+					filt_chroma_n(bsc2, p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
 					cp[-2] = (uint8_t)a0;
 					cp[0] = (uint8_t)b0;
 					cp[6] = (uint8_t)c0;
@@ -780,12 +788,11 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 					bs[0] = top_edge ? 4 : 0;
 					bs[1] = bs[2] = bs[3] = 3;
 				} else {
-					bs[0] = !top_edge ? 0
-						: (((nz_cur >> k) | (nz_top >> (12 + k))) & 1) ? 2
-						: (mvc != mvt) ? 1 : 0;
+					const int nzb0 = (int)(((nz_cur >> k) | (nz_top >> (12 + k))) & 1u);
+					bs[0] = (2 * nzb0 + ((1 - nzb0) & (nz_mask(mvc ^ mvt) & 1))) & -(int)top_edge;
 #pragma unroll
 					for (int e = 1; e < 4; e++)
-						bs[e] = (((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1) ? 2 : 0;
+						bs[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
 				}
 				int py[20];
 				uint8_t *colp = L.y + 16 + l;
@@ -796,11 +803,10 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				for (int e = 0; e < 4; e++) {
 					const int q = 4 + 4 * e;
 					if (IDR && e == 0)
-						filt_luma_s(bs[0] != 0, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+						filt_luma_s(bs[0], p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
 							    py[q], py[q + 1], py[q + 2], py[q + 3]);
 					else
-						filt_luma_n(bs[e] != 0, p.alpha_y, p.beta_y,
-							    bs[e] == 1 ? tc_y1 : bs[e] == 2 ? tc_y2 : bs[e] == 3 ? tc_y3 : 0,
+						filt_luma_n(bs[e], p.alpha_y, p.beta_y, tcw_y,
 							    py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
 				}
 #pragma unroll
@@ -812,10 +818,10 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 					int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
 					int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
 					if (IDR)
-						filt_chroma_s(bs[0] != 0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+						filt_chroma_s(bs[0], p.alpha_c, p.beta_c, a1, a0, b0, b1);
 					else
-						filt_chroma_n(bs[0] != 0, p.alpha_c, p.beta_c, bs[0] == 1 ? tc_c1 : bs[0] == 2 ? tc_c2 : 0, a1, a0, b0, b1);
-					filt_chroma_n(bs[2] != 0, p.alpha_c, p.beta_c, bs[2] == 2 ? tc_c2 : bs[2] == 3 ? tc_c3 : 0, c1, c0, d0, d1);
+						filt_chroma_n(bs[0], p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
+					filt_chroma_n(bs[2], p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
 					cp[DC_STRIDE] = (uint8_t)a0;
 					cp[2 * DC_STRIDE] = (uint8_t)b0;
 					cp[5 * DC_STRIDE] = (uint8_t)c0;
