@@ -680,6 +680,8 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	const double t0 = now_ms();
 	HIP_TRY(e, hipSetDevice(e->device));
 	const int S = e->ext.n_streams;
+	if (e->fl_count == 0)
+		e->fl_head = 0; // an empty pipeline always lands in host buffer 0 (the one CONFIG returned)
 	const int slot = (e->fl_head + e->fl_count) % CEDAR_ENC_PIPELINE_DEPTH;
 	InFlight &f = e->fl[slot];
 	memset(f.tm.used, 0, sizeof(f.tm.used));
@@ -761,7 +763,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	if (Launch::entropy(P, e->s_ent))
 		return fail(e, -EIO, "entropy launch failed");
 	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
-	f.host_out = e->fl_count; // one frame in flight (plain encode) always lands in buffer 0
+	f.host_out = slot; // every frame in flight owns one host buffer until it is collected
 	uint32_t spec = e->last_total ? e->last_total * 2 + 65536 : 262144;
 	if (idr && spec < 1u << 20)
 		spec = 1u << 20;
