@@ -37,6 +37,9 @@ constexpr int SLOT_WORDS = SLOT_BYTES / 4;
 constexpr int ESC_CHUNK = 256;    // bytes of RBSP per emulation-prevention thread
 constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
+constexpr int WF_MAX_SPLIT = 8;   // workgroups sharing one unit's wavefront
+constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress
+constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
 // What one picture-slice header contributes in front of the macroblock data.
 struct SliceHdr {
@@ -92,6 +95,12 @@ struct Params {
 	const SliceHdr *hdr;             // [n_units] (identical across streams per slice)
 	const uint32_t *prefix_len;      // [n_streams] bytes reserved in front (SPS+PPS)
 	const uint8_t *pred4_tab;        // [9][16] intra 4x4 predictor table
+	// wavefront kernels split over wf_split workgroups (CUs) per unit: ticket,
+	// abort flag and per-workgroup progress words (zeroed before every launch),
+	// and the write-through hand-off buffer for the rows crossing a workgroup boundary
+	uint32_t *wf_sync;               // [2][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock
+	uint64_t *wf_hbuf;               // [n_units][wf_split-1][mb_w][WF_HBUF_GRANULES]
+	int32_t wf_split;
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
 	int32_t unit_mb_cap;             // max macroblocks of one unit

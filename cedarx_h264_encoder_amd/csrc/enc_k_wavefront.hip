@@ -50,6 +50,34 @@ DEVI void publish_progress(volatile int *prog, int idx, int value)
 	__hip_atomic_store((int *)&prog[idx], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- hand-off between the workgroups (CUs) that share one unit's wavefront ----
+// Producer: payload as 8-byte write-through (agent-scope relaxed atomic = sc1)
+// stores, every storing wave drains with s_waitcnt vmcnt(0), then ONE lane stores
+// the progress word. Consumer: relaxed agent-scope poll of that ONE word, then
+// sc1 loads of the payload (cdna guide G16, form R1, first row of the validity
+// table). Spins are bounded: a time-out raises the abort word, which every waiter
+// checks, and flags the frame as failed instead of hanging the GPU.
+DEVI uint32_t xload32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVI void xstore32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVI uint64_t xload64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVI void xstore64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// wave-uniform: wait until *word >= need; returns the value seen (or a huge one after abort)
+DEVI uint32_t xwait(const uint32_t *word, uint32_t *abort_word, uint32_t *err_word, uint32_t need)
+{
+	uint32_t v = xload32(word), spins = 0;
+	while (v < need) {
+		if (++spins > (1u << 21) || xload32(abort_word)) {
+			xstore32(abort_word, 1u);
+			atomicOr(err_word, 4u);
+			return 0x7fffffffu;
+		}
+		__builtin_amdgcn_s_sleep(8);
+		v = xload32(word);
+	}
+	return v;
+}
+
 // 4x4 Hadamard sign H[i][a] for rows (1,1,1,1) (1,1,-1,-1) (1,-1,-1,1) (1,-1,1,-1)
 DEVI int hsign(int i, int a)
 {
@@ -126,16 +154,27 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 {
 	__shared__ __attribute__((aligned(16))) IntraGroupLds s_g[NWAVES * 4];
 	__shared__ int s_prog[MAX_ROWS];
+	__shared__ int s_ticket;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int g = lane >> 4, l = lane & 15;
-	const int unit = blockIdx.x;
-	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
-	int r0, r1;
-	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+	const int NWG = p.wf_split; // workgroups sharing this unit's wavefront (see k_deblock)
+	uint32_t *sync = p.wf_sync; // region 0 = intra_recon
+	if (threadIdx.x == 0)
+		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
 	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
 		s_prog[i] = 0;
 	__syncthreads();
+	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
+	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
+	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2;
+	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
+	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint32_t xseen = 0;
 
 	IntraGroupLds &L = s_g[wave * 4 + g];
 	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
@@ -144,6 +183,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
 	const int nbands = (r1 - r0 + 3) >> 2;
+	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
 	const int pi = l >> 2, pj = l & 3;                 // sample / lane position in a 4x4 block
 	const int Pm[4] = { 0, 2, 1, 3 };
 	const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
@@ -165,10 +205,13 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
 	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
 
-	for (int band = wave; band < nbands; band += NWAVES) {
+	for (int band = b_lo + wave; band < b_hi; band += NWAVES) {
 		const int my = r0 + 4 * band + g;
 		const bool row_ok = my < r1;
 		const bool top_mb = my > r0;
+		const bool xwg_band = band == b_lo && b_lo > 0;                    // row above lives in another workgroup
+		const bool xwg_top = g == 0 && xwg_band;
+		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands; // this row feeds the next workgroup
 		for (int step = 0; step < p.mb_w + 6; step++) {
 			const int mx = step - 2 * g;
 			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
@@ -181,8 +224,13 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 				if (l < 8)
 					*(uint16_t *)(L.c + (1 + l) * IC_STRIDE + 6) = *(const uint16_t *)(L.c + (1 + l) * IC_STRIDE + 22);
 			}
-			if (band > 0 && step < p.mb_w)
+			if (band > b_lo && step < p.mb_w)
 				wait_progress(s_prog, 4 * band - 1, step + 2 < p.mb_w ? step + 2 : p.mb_w);
+			else if (xwg_band && step < p.mb_w) {
+				const uint32_t need = (uint32_t)(step + 2 < p.mb_w ? step + 2 : p.mb_w);
+				if (xseen < need)
+					xseen = xwait(&xprog[wj - 1], xabort, xerr, need);
+			}
 			MbInfo mi = p.mbi[mbaddr];
 			const int my_i4 = p.i4modes[mbaddr * 16 + l];
 			if (act) {
@@ -192,7 +240,21 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 				}
 				if (l < 8)
 					*(u32x4 *)(L.srcc + l * 16) = *(const u32x4 *)(src_uv + (size_t)(my * 8 + l) * p.cw + x0);
-				if (top_mb) {
+				if (top_mb && xwg_top) {
+					// neighbours above come from the other workgroup's write-through buffer
+					const uint64_t *hb = hb_in + (size_t)mx * WF_HBUF_GRANULES;
+					if (l == 8 || l == 9) {
+						*(uint64_t *)(L.t + 8 + (l - 8) * 8) = xload64(hb + (l - 8));
+					} else if (l == 10 && tr_mb) {
+						*(uint32_t *)(L.t + 24) = (uint32_t)xload64(hb + WF_HBUF_GRANULES);       // next MB, first 4 samples
+					} else if (l == 11 && left_mb) {
+						L.t[7] = (uint8_t)(xload64(hb - WF_HBUF_GRANULES + 1) >> 56);              // previous MB, last sample
+					} else if (l == 12 || l == 13) {
+						*(uint64_t *)(L.c + 8 + (l - 12) * 8) = xload64(hb + 2 + (l - 12));
+					} else if (l == 14 && left_mb) {
+						*(uint16_t *)(L.c + 6) = (uint16_t)(xload64(hb - WF_HBUF_GRANULES + 3) >> 48); // previous MB, last CbCr pair
+					}
+				} else if (top_mb) {
 					if (l == 8) {
 						const uint64_t *tp = (const uint64_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0);
 						*(uint64_t *)(L.t + 8) = tp[0];
@@ -468,6 +530,15 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 					p.mbi[mbaddr] = mi;
 				}
 			}
+			if (b_hi < nbands && band == b_hi - 1) { // wave-uniform: this band feeds the next workgroup
+				if (is_xprod && act && l < 4) {
+					const uint8_t *src = l < 2 ? L.t + 16 * IT_STRIDE + 8 + l * 8 : L.c + 8 * IC_STRIDE + 8 + (l - 2) * 8;
+					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (is_xprod && act && l == 0)
+					xstore32(&xprog[wj], (uint32_t)(mx + 1));
+			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (act && l == 0)
 				__hip_atomic_store(&s_prog[my - r0], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -477,7 +548,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 
 int Launch::intra_recon(const Params &p, void *stream)
 {
-	dim3 grid(p.n_streams * p.slice_num);
+	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
 	static int waves = 0;
 	if (!waves) {
 		const char *e = getenv("CEDAR_INTRA_WAVES");
@@ -585,29 +656,46 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 	__shared__ __attribute__((aligned(16))) DbGroupLds s_g[WF_WAVES * 4];
 	__shared__ int s_prog[MAX_ROWS];
 
+	__shared__ int s_ticket;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int g = lane >> 4, l = lane & 15;
-	const int unit = blockIdx.x;
-	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
-	int r0, r1;
-	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+	// several workgroups share one unit: tickets hand out (unit, part) in start order,
+	// so the workgroup a part waits for has always started before it
+	const int NWG = p.wf_split;
+	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS; // region 1 = deblock
+	if (threadIdx.x == 0)
+		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
 	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
 		s_prog[i] = 0;
 	__syncthreads();
+	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
+	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
 
 	DbGroupLds &L = s_g[wave * 4 + g];
 	const DbGroupLds &LU = s_g[wave * 4 + (g > 0 ? g - 1 : 0)]; // the row above, same wave
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int nbands = (r1 - r0 + 3) >> 2;
+	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG; // this workgroup's bands
+	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;  // [part]: macroblocks handed to part+1
+	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2; // error word lives in region 0
+	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint32_t xseen = 0; // wave-uniform cache of the producer part's progress
 	const uint32_t tcw_y = ((uint32_t)p.tc0_y[0] << 8) | ((uint32_t)p.tc0_y[1] << 16) | ((uint32_t)p.tc0_y[2] << 24);
 	const uint32_t tcw_c = ((uint32_t)p.tc0_c[0] << 8) | ((uint32_t)p.tc0_c[1] << 16) | ((uint32_t)p.tc0_c[2] << 24);
 
-	for (int band = wave; band < nbands; band += WF_WAVES) {
+	for (int band = b_lo + wave; band < b_hi; band += WF_WAVES) {
 		const int my = r0 + 4 * band + g;
 		const bool row_ok = my < r1;
 		const bool top_edge = my > r0; // picture top, or slice top with idc 2: not filtered
-		const bool xwave_top = g == 0 && band > 0; // top rows come from another wave, through memory
+		const bool xwave_top = g == 0 && band > b_lo;            // rows above: another wave of this workgroup (memory + LDS counter)
+		const bool xwg_band = band == b_lo && b_lo > 0;          // rows above: another workgroup (hand-off buffer)
+		const bool xwg_top = g == 0 && xwg_band;
+		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands; // this row feeds the next workgroup
+		uint64_t r_topx = 0;
 		const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
 		uint32_t nz_left = 0;
 		int mvl = 0;
@@ -638,7 +726,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				r_nzt = p.nnz[at * NNZ_PER_MB + l];
 			}
 			r_top_ok = true;
-			if (band > 0 && mx0 < p.mb_w) {
+			if (band > b_lo && mx0 < p.mb_w) {
 				const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w;
 				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
 				if (!ready && block) {
@@ -648,6 +736,14 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				if (ready)
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				r_top_ok = ready;
+			} else if (xwg_band && mx0 < p.mb_w) {
+				// the producer part publishes the count of macroblocks whose bottom rows are final
+				const uint32_t need = (uint32_t)mx0 + 1u;
+				if (xseen < need)
+					xseen = xload32(&xprog[wj - 1]);
+				if (xseen < need && block)
+					xseen = xwait(&xprog[wj - 1], xabort, xerr, need);
+				r_top_ok = xseen >= need;
 			}
 			if (xwave_top && r_top_ok && nact) {
 				if (l < 4)
@@ -655,6 +751,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				else if (l < 6)
 					r_top = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) - 2 + l - 4) * p.cw + x0);
 			}
+			if (xwg_top && r_top_ok && nact && l < WF_HBUF_GRANULES)
+				r_topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
 		};
 
 		// stage the data of a step (already in the r_* registers) into the LDS tiles
@@ -677,6 +775,11 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 1] + l * 16);
 					else if (l < 6)
 						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 1] + (l - 4) * 16);
+				} else if (xwg_top) { // from the workgroup above: 8 luma + 4 chroma granules
+					if (l < 8)
+						*(uint64_t *)(L.y + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = r_topx;
+					else if (l < 12)
+						*(uint64_t *)(L.c + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = r_topx;
 				} else {     // from the wave above, through memory
 					if (l < 4)
 						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = r_top;
@@ -690,6 +793,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 		prefetch_step(0, true);
 		WAVE_SYNC();
 		int pending_pub = -1; // macroblock column whose stores are in flight, per group
+		int pending_x = -1;   // macroblocks handed to the next workgroup, not yet published
 
 		for (int step = 0; step < p.mb_w + 6; step++) {
 			const int mx = step - 2 * g;
@@ -834,6 +938,12 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			if (pending_pub >= 0 && l == 0)
 				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			pending_pub = -1;
+			if (b_hi < nbands && band == b_hi - 1) { // wave-uniform: this band feeds the next workgroup
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through payload stores have landed
+				if (is_xprod && l == 0 && pending_x >= 0)
+					xstore32(&xprog[wj], (uint32_t)pending_x);
+				pending_x = -1;
+			}
 			if (act) {
 				// ---- hand the bottom rows to the row below (LDS), then write back ----
 				if (l >= 12) {
@@ -845,10 +955,14 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 					if (left_edge)
 						*(uint32_t *)(L.botc[(mx - 1) & 1] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
 				}
-				*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
-				if (left_edge)
-					*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
-				if (l < 8) {
+				// a row that feeds another workgroup leaves its last 4 luma / 2 chroma rows to
+				// that workgroup (single writer: it stores them after filtering its top edge)
+				if (!(is_xprod && l >= 12)) {
+					*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
+					if (left_edge)
+						*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
+				}
+				if (l < 8 && !(is_xprod && l >= 6)) {
 					*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16);
 					if (left_edge)
 						*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
@@ -864,17 +978,37 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				pending_pub = mx;
 			}
 			WAVE_SYNC();
+			if (is_xprod && act) {
+				// bottom rows of macroblock mx-1 are final now (its columns 12..15 were just
+				// patched); the last macroblock of the row is final at once
+				if (left_edge && l < WF_HBUF_GRANULES) {
+					const uint8_t *src = l < 8 ? L.bot[(mx - 1) & 1] + (l >> 1) * 16 + (l & 1) * 8
+								   : L.botc[(mx - 1) & 1] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
+					xstore64(hb_out + (size_t)(mx - 1) * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+				}
+				if (mx == p.mb_w - 1 && l < WF_HBUF_GRANULES) {
+					const uint8_t *src = l < 8 ? L.bot[mx & 1] + (l >> 1) * 16 + (l & 1) * 8
+								   : L.botc[mx & 1] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
+					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+				}
+				pending_x = mx == p.mb_w - 1 ? p.mb_w : mx;
+			}
 		}
 		// drain: publish the last macroblock of every row of the band
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		if (pending_pub >= 0 && l == 0)
 			__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (b_hi < nbands && band == b_hi - 1) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (is_xprod && l == 0 && pending_x >= 0)
+				xstore32(&xprog[wj], (uint32_t)pending_x);
+		}
 	}
 }
 
 int Launch::deblock(const Params &p, void *stream)
 {
-	dim3 grid(p.n_streams * p.slice_num);
+	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
 	const unsigned pad_lds = 12 * 1024; // 74 KiB static + 12 KiB > 80 KiB: one workgroup per CU
 	if (p.is_idr)
 		hipLaunchKernelGGL(k_deblock<true>, grid, dim3(64 * WF_WAVES), pad_lds, (hipStream_t)stream, p);
