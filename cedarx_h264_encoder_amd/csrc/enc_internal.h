@@ -98,7 +98,7 @@ struct Params {
 	// wavefront kernels split over wf_split workgroups (CUs) per unit: ticket,
 	// abort flag and per-workgroup progress words (zeroed before every launch),
 	// and the write-through hand-off buffer for the rows crossing a workgroup boundary
-	uint32_t *wf_sync;               // [2][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock
+	uint32_t *wf_sync;               // [3][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock (luma), 2 deblock chroma
 	uint64_t *wf_hbuf;               // [n_units][wf_split-1][mb_w][WF_HBUF_GRANULES]
 	int32_t wf_split;
 	// strides (elements of the respective type)
@@ -141,7 +141,7 @@ struct Launch {
 	static int intra_decide(const Params &p, void *stream);
 	static int intra_recon(const Params &p, void *stream);
 	static int inter(const Params &p, void *stream);
-	static int deblock(const Params &p, void *stream);
+	static int deblock(const Params &p, void *stream, int planes); // 1 luma, 2 chroma, 3 both
 	static int entropy(const Params &p, void *stream); // cavlc, scan, pack, escape
 };
 

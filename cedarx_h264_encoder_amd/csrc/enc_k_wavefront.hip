@@ -650,9 +650,13 @@ DEVI void filt_chroma_s(int bs, int alpha, int beta, int p1, int &p0, int &q0, i
 	q0 = sel(m, nq0, q0);
 }
 
-template <bool IDR>
+// PL: planes this launch filters (1 = luma, 2 = chroma, 3 = both). Luma and chroma
+// are independent given the boundary strengths, so they run as two concurrent
+// wavefronts on different CUs; the luma step (the critical path) gets shorter.
+template <bool IDR, int PL>
 __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 {
+	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
 	__shared__ __attribute__((aligned(16))) DbGroupLds s_g[WF_WAVES * 4];
 	__shared__ int s_prog[MAX_ROWS];
 
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 	// several workgroups share one unit: tickets hand out (unit, part) in start order,
 	// so the workgroup a part waits for has always started before it
 	const int NWG = p.wf_split;
-	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS; // region 1 = deblock
+	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1); // region 1 = deblock (luma), 2 = chroma
 	if (threadIdx.x == 0)
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
 	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
@@ -716,8 +720,10 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			const int cmx = nact ? nmx : 0;
 			const size_t a = row_mb + cmx;
 			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
-			r_in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
-			r_c = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
+			if (DO_Y)
+				r_in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
+			if (DO_C)
+				r_c = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
 			if (!IDR) {
 				r_mi = p.mbi[a];
 				r_nz = p.nnz[a * NNZ_PER_MB + l];
@@ -746,12 +752,12 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				r_top_ok = xseen >= need;
 			}
 			if (xwave_top && r_top_ok && nact) {
-				if (l < 4)
+				if (DO_Y && l < 4)
 					r_top = *(const u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0);
-				else if (l < 6)
+				else if (DO_C && l >= 4 && l < 6)
 					r_top = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) - 2 + l - 4) * p.cw + x0);
 			}
-			if (xwg_top && r_top_ok && nact && l < WF_HBUF_GRANULES)
+			if (xwg_top && r_top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
 				r_topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
 		};
 
@@ -762,28 +768,30 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			if (!act)
 				return;
 			if (mx > 0) { // previous macroblock's last 4 columns become the left neighbours
-				*(uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 28);
-				if (l < 8)
+				if (DO_Y)
+					*(uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 28);
+				if (DO_C && l < 8)
 					*(uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 28);
 			}
-			*(u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16) = r_in;
-			if (l < 8)
+			if (DO_Y)
+				*(u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16) = r_in;
+			if (DO_C && l < 8)
 				*(u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16) = r_c;
 			if (top_edge) {
 				if (g > 0) { // from the group above, through LDS
-					if (l < 4)
+					if (DO_Y && l < 4)
 						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 1] + l * 16);
-					else if (l < 6)
+					else if (DO_C && l >= 4 && l < 6)
 						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 1] + (l - 4) * 16);
 				} else if (xwg_top) { // from the workgroup above: 8 luma + 4 chroma granules
-					if (l < 8)
+					if (DO_Y && l < 8)
 						*(uint64_t *)(L.y + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = r_topx;
-					else if (l < 12)
+					else if (DO_C && l >= 8 && l < 12)
 						*(uint64_t *)(L.c + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = r_topx;
 				} else {     // from the wave above, through memory
-					if (l < 4)
+					if (DO_Y && l < 4)
 						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = r_top;
-					else if (l < 6)
+					else if (DO_C && l >= 4 && l < 6)
 						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = r_top;
 				}
 			}
@@ -834,6 +842,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 					for (int e = 1; e < 4; e++)
 						bs[e] = 2 * (int)(((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1u);
 				}
+				if (DO_Y) {
 				int px[20];
 				const uint32_t *rowp = (const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
 #pragma unroll
@@ -858,8 +867,9 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 #pragma unroll
 				for (int w = 0; w < 5; w++)
 					roww[w] = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
+				}
 				// chroma: lane = (plane c = l>>3, chroma row r = l&7); edges at chroma x = 0 and 4
-				{
+				if (DO_C) {
 					const int c = l >> 3, r = l & 7, ks = r >> 1;
 					int bsc0, bsc2;
 					if (IDR) {
@@ -898,6 +908,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 					for (int e = 1; e < 4; e++)
 						bs[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
 				}
+				if (DO_Y) {
 				int py[20];
 				uint8_t *colp = L.y + 16 + l;
 #pragma unroll
@@ -916,8 +927,9 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 #pragma unroll
 				for (int r = 1; r < 19; r++)
 					colp[r * DT_STRIDE] = (uint8_t)py[r];
+				}
 				// chroma: lane = byte column l of the nv12 row (plane l&1, chroma x = l>>1)
-				{
+				if (DO_C) {
 					uint8_t *cp = L.c + 16 + l;
 					int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
 					int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
@@ -946,31 +958,31 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			}
 			if (act) {
 				// ---- hand the bottom rows to the row below (LDS), then write back ----
-				if (l >= 12) {
+				if (DO_Y && l >= 12) {
 					*(u32x4 *)(L.bot[mx & 1] + (l - 12) * 16) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
 					if (left_edge) // columns 12..15 of the previous macroblock are final only now
 						*(uint32_t *)(L.bot[(mx - 1) & 1] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
-				} else if (l >= 6 && l < 8) {
+				} else if (DO_C && l >= 6 && l < 8) {
 					*(u32x4 *)(L.botc[mx & 1] + (l - 6) * 16) = *(const u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16);
 					if (left_edge)
 						*(uint32_t *)(L.botc[(mx - 1) & 1] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
 				}
 				// a row that feeds another workgroup leaves its last 4 luma / 2 chroma rows to
 				// that workgroup (single writer: it stores them after filtering its top edge)
-				if (!(is_xprod && l >= 12)) {
+				if (DO_Y && !(is_xprod && l >= 12)) {
 					*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
 					if (left_edge)
 						*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
 				}
-				if (l < 8 && !(is_xprod && l >= 6)) {
+				if (DO_C && l < 8 && !(is_xprod && l >= 6)) {
 					*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16);
 					if (left_edge)
 						*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
 				}
 				if (top_edge) {
-					if (l < 4)
+					if (DO_Y && l < 4)
 						*(u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0) = *(const u32x4 *)(L.y + l * DT_STRIDE + 16);
-					else if (l < 6)
+					else if (DO_C && l >= 4 && l < 6)
 						*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16);
 				}
 				nz_left = nz_cur;
@@ -981,12 +993,13 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			if (is_xprod && act) {
 				// bottom rows of macroblock mx-1 are final now (its columns 12..15 were just
 				// patched); the last macroblock of the row is final at once
-				if (left_edge && l < WF_HBUF_GRANULES) {
+				const bool my_gran = (DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES);
+				if (left_edge && my_gran) {
 					const uint8_t *src = l < 8 ? L.bot[(mx - 1) & 1] + (l >> 1) * 16 + (l & 1) * 8
 								   : L.botc[(mx - 1) & 1] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
 					xstore64(hb_out + (size_t)(mx - 1) * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
 				}
-				if (mx == p.mb_w - 1 && l < WF_HBUF_GRANULES) {
+				if (mx == p.mb_w - 1 && my_gran) {
 					const uint8_t *src = l < 8 ? L.bot[mx & 1] + (l >> 1) * 16 + (l & 1) * 8
 								   : L.botc[mx & 1] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
 					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
@@ -1006,14 +1019,20 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 	}
 }
 
-int Launch::deblock(const Params &p, void *stream)
+int Launch::deblock(const Params &p, void *stream, int planes)
 {
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
 	const unsigned pad_lds = 12 * 1024; // 74 KiB static + 12 KiB > 80 KiB: one workgroup per CU
-	if (p.is_idr)
-		hipLaunchKernelGGL(k_deblock<true>, grid, dim3(64 * WF_WAVES), pad_lds, (hipStream_t)stream, p);
-	else
-		hipLaunchKernelGGL(k_deblock<false>, grid, dim3(64 * WF_WAVES), pad_lds, (hipStream_t)stream, p);
+	hipStream_t s = (hipStream_t)stream;
+	if (p.is_idr) {
+		if (planes == 1) hipLaunchKernelGGL((k_deblock<true, 1>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+		else if (planes == 2) hipLaunchKernelGGL((k_deblock<true, 2>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+		else hipLaunchKernelGGL((k_deblock<true, 3>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+	} else {
+		if (planes == 1) hipLaunchKernelGGL((k_deblock<false, 1>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+		else if (planes == 2) hipLaunchKernelGGL((k_deblock<false, 2>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+		else hipLaunchKernelGGL((k_deblock<false, 3>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+	}
 	return (int)hipGetLastError();
 }
 

@@ -177,7 +177,9 @@ struct cedar_enc {
 	uint32_t *h_sizes[CEDAR_ENC_PIPELINE_DEPTH] = { nullptr, nullptr };
 	size_t out_cap = 0;
 	// streams / events
-	hipStream_t s_main = nullptr, s_ent = nullptr;
+	hipStream_t s_main = nullptr, s_ent = nullptr, s_aux = nullptr;
+	hipEvent_t ev_chroma = nullptr;
+	bool split_planes = true;
 	hipEvent_t ev_input = nullptr, ev_analysis = nullptr;
 	InFlight fl[CEDAR_ENC_PIPELINE_DEPTH];
 	int fl_head = 0, fl_count = 0; // ring of frames in flight
@@ -248,6 +250,8 @@ void free_all(cedar_enc *e)
 	if (e->ev_analysis) hipEventDestroy(e->ev_analysis);
 	if (e->s_main) hipStreamDestroy(e->s_main);
 	if (e->s_ent) hipStreamDestroy(e->s_ent);
+	if (e->s_aux) hipStreamDestroy(e->s_aux);
+	if (e->ev_chroma) hipEventDestroy(e->ev_chroma);
 }
 
 // SPS (cedar.c:892-937) + PPS (cedar.c:939-982)
@@ -596,7 +600,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		if (split < 1) split = 1;
 		e->wf_split = split;
 	}
-	if ((rc = dalloc(e, &e->d_wf_sync, (size_t)2 * WF_SYNC_WORDS))) return rc;
+	if ((rc = dalloc(e, &e->d_wf_sync, (size_t)3 * WF_SYNC_WORDS))) return rc;
 	if ((rc = dalloc(e, &e->d_wf_hbuf, (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc;
 	uint8_t tab[9 * 16];
 	build_pred4_table(tab);
@@ -610,6 +614,12 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
+	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_aux, hipStreamNonBlocking));
+	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_chroma, hipEventDisableTiming));
+	{
+		const char *env = getenv("CEDAR_DEBLOCK_PLANES");
+		e->split_planes = env ? atoi(env) != 0 : n_units <= 32; // two concurrent wavefronts while CUs are spare
+	}
 	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming));
 	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis, hipEventDisableTiming));
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
@@ -752,7 +762,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	if (any_host)
 		HIP_TRY(e, hipEventRecord(e->ev_input, e->s_main));
 	if (e->wf_split > 1) // ticket / abort / progress words of both wavefront kernels start at zero
-		HIP_TRY(e, hipMemsetAsync(e->d_wf_sync, 0, sizeof(uint32_t) * 2 * WF_SYNC_WORDS, e->s_main));
+		HIP_TRY(e, hipMemsetAsync(e->d_wf_sync, 0, sizeof(uint32_t) * 3 * WF_SYNC_WORDS, e->s_main));
 	if (Launch::input(P, e->s_main))
 		return fail(e, -EIO, "k_input launch failed");
 	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, e->s_main);
@@ -807,8 +817,16 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 
 	// ---- in-loop deblocking: produces the next frame's reference ----
 	tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
-	if (Launch::deblock(P, e->s_main))
+	if (e->split_planes) {
+		// luma and chroma are independent wavefronts: chroma on its own stream / CUs
+		HIP_TRY(e, hipStreamWaitEvent(e->s_aux, e->ev_analysis, 0));
+		if (Launch::deblock(P, e->s_aux, 2) || Launch::deblock(P, e->s_main, 1))
+			return fail(e, -EIO, "k_deblock launch failed");
+		HIP_TRY(e, hipEventRecord(e->ev_chroma, e->s_aux));
+		HIP_TRY(e, hipStreamWaitEvent(e->s_main, e->ev_chroma, 0));
+	} else if (Launch::deblock(P, e->s_main, 3)) {
 		return fail(e, -EIO, "k_deblock launch failed");
+	}
 	tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
 	*f.h_wf_err = 0;
 	if (e->wf_split > 1)
