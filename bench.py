@@ -161,7 +161,12 @@ def run_rank(args, rank, world, local_rank):
     launches = max(1, st["launches"][stage])
     avg_ms = st["ms"][stage] / launches
     mb_per_launch = S * mbs_per_frame
-    alg_bytes = KERNEL_BYTES_PER_MB[stage] * mb_per_launch
+    kname, tkey, per_mb = "k_" + stage, stage, KERNEL_BYTES_PER_MB[stage]
+    if stage == "deblock" and st.get("deblock_planes_split"):
+        # luma and chroma run as two concurrent kernels; the timed one (critical path) is luma:
+        # 256 B read + 256 B written per macroblock
+        kname, tkey, per_mb = "k_deblock<planes=luma>", "deblock_luma", 512
+    alg_bytes = per_mb * mb_per_launch
     if stage == "entropy":
         alg_bytes += nbytes / max(1, args.steps)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -170,7 +175,7 @@ def run_rank(args, rank, world, local_rank):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = "%s@%dx%dx%d" % (stage, W, H, S)
+            key = "%s@%dx%dx%d" % (tkey, W, H, S)
             traffic = tj.get(key)
         except Exception:  # noqa: BLE001
             traffic = None
@@ -178,7 +183,8 @@ def run_rank(args, rank, world, local_rank):
     pipe_bytes = (n_i * PIPELINE_BYTES_PER_MB["I"] + (args.steps - n_i) * PIPELINE_BYTES_PER_MB["P"]) \
         * S * mbs_per_frame * world + nbytes_all
     roofline = {
-        "bound": "hbm", "kernel": "k_" + stage, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "wf_split": st.get("wf_split"),
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "avg_launch_ms": round(avg_ms, 4), "launches": launches,
         "algorithmic_bytes_per_launch": int(alg_bytes),

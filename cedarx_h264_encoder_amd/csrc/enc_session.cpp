@@ -966,6 +966,8 @@ extern "C" int cedar_enc_get_stats(cedar_enc *e, struct cedar_enc_stats *out)
 	if (!e || !out)
 		return -EINVAL;
 	*out = e->stats;
+	out->wf_split = e->wf_split;
+	out->deblock_planes_split = e->split_planes ? 1 : 0;
 	return 0;
 }
 

@@ -46,7 +46,8 @@ class _ConfigExt(ctypes.Structure):
 
 class _Stats(ctypes.Structure):
     _fields_ = [("frames", ctypes.c_uint64), ("launches", ctypes.c_uint64 * 6),
-                ("ms", ctypes.c_double * 6), ("encode_wall_ms", ctypes.c_double)]
+                ("ms", ctypes.c_double * 6), ("encode_wall_ms", ctypes.c_double),
+                ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int)]
 
 
 _lib = None
@@ -235,7 +236,8 @@ class CedarEncoder:
     def stats(self):
         s = _Stats()
         self._L.cedar_enc_get_stats(self._h, ctypes.byref(s))
-        return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms,
+        return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms, "wf_split": s.wf_split,
+                "deblock_planes_split": bool(s.deblock_planes_split),
                 "ms": {n: s.ms[i] for i, n in enumerate(STAGES)},
                 "launches": {n: s.launches[i] for i, n in enumerate(STAGES)}}
 

@@ -147,6 +147,8 @@ struct cedar_enc_stats {
 	uint64_t launches[CEDAR_ENC_STAGE_COUNT];/* kernel launches per stage     */
 	double   ms[CEDAR_ENC_STAGE_COUNT];      /* summed GPU time per stage     */
 	double   encode_wall_ms;                 /* host wall time inside encode  */
+	int      wf_split;                       /* workgroups (CUs) per unit in the wavefront kernels */
+	int      deblock_planes_split;           /* 1: luma and chroma deblock run as two kernels      */
 };
 int cedar_enc_set_profiling(cedar_enc *enc, int on); /* event timing on/off (default off) */
 int cedar_enc_get_stats(cedar_enc *enc, struct cedar_enc_stats *out);

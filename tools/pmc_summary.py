@@ -38,14 +38,13 @@ def main():
         wr_bytes = wr * 1024.0
         rows.append((k, n, fr, wr, rd_bytes, wr_bytes, rd_bytes + wr_bytes))
         stage = k.replace("cedar::k_", "").split("<")[0]
+        if stage == "deblock" and "<" in k:   # k_deblock<IDR, planes>: 1 luma, 2 chroma, 3 both
+            planes = k.split(",")[1].strip(" >")
+            stage = {"1": "deblock_luma", "2": "deblock_chroma"}.get(planes, "deblock")
         key = "%s@%s" % (stage, geom)
-        traffic[key] = traffic.get(key, 0.0) + 0.0  # placeholder so every stage has a key
-        if "<" in k:   # templated variants: keep the per-launch value of the most frequent one
-            if n >= traffic.get("_n_" + key, 0):
-                traffic[key] = rd_bytes + wr_bytes
-                traffic["_n_" + key] = n
-        else:
+        if n >= traffic.get("_n_" + key, 0):  # IDR / P variants: keep the most frequent one
             traffic[key] = rd_bytes + wr_bytes
+            traffic["_n_" + key] = n
     traffic = {k: round(v) for k, v in traffic.items() if not k.startswith("_n_")}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     out_csv = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.csv" % tag)
