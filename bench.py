@@ -68,8 +68,13 @@ def run_rank(args, rank, world, local_rank):
     import torch.distributed as dist
     import cedarx_h264_encoder_amd as ce
 
+    # BENCH_FORCE_DEVICE lets several ranks share one GPU (rehearsal of the N > 1 path on a
+    # one-GPU box, together with BENCH_DIST_BACKEND=gloo); the driver's runs never set it
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    rdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
     W, H = args.width, args.height
     mbs_per_frame = ((W + 15) // 16) * ((H + 15) // 16)
 
@@ -128,10 +133,10 @@ def run_rank(args, rank, world, local_rank):
     inputs = make_inputs(max(S, args.batched_streams))
     dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, True)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_max = float(t.item())
-        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=dev)
+        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=rdev)
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         nbytes_all = float(b.item())
     else:
@@ -146,7 +151,7 @@ def run_rank(args, rank, world, local_rank):
         bsteps = max(25, min(args.steps, 50))
         bdt, _, _, _ = measure(SB, bsteps, args.keyint, inputs, False)
         if world > 1:
-            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            t = torch.tensor([bdt], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bdt = float(t.item())
         batched = {"streams_per_gpu": SB, "steps": bsteps,
@@ -257,7 +262,11 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     try:
         out = run_rank(args, rank, world, local_rank)
         if rank == 0 and out is not None:

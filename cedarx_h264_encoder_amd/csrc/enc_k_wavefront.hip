@@ -78,6 +78,10 @@ DEVI uint32_t xwait(const uint32_t *word, uint32_t *abort_word, uint32_t *err_wo
 	return v;
 }
 
+DEVI int lt_mask(int a, int b) { return (a - b) >> 31; }          // a < b ? -1 : 0  (|a|,|b| < 2^30)
+DEVI int nz_mask(int v) { return (v | -v) >> 31; }               // v != 0 ? -1 : 0
+DEVI int sel(int m, int a, int b) { return b ^ ((a ^ b) & m); }  // m ? a : b for m in {0,-1}
+
 // 4x4 Hadamard sign H[i][a] for rows (1,1,1,1) (1,1,-1,-1) (1,-1,-1,1) (1,-1,1,-1)
 DEVI int hsign(int i, int a)
 {
@@ -120,32 +124,55 @@ DEVI int dpp_xor3(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xf, 0
 DEVI int dpp_xor4(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); } // row_half_mirror, j restored
 DEVI int dpp_xor12(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); } // row_mirror, j restored
 
+// Per-lane constants of the butterflies below (k = position 0..3 along the axis).
+// Selecting with `k == 0 ? .. : k == 1 ? ..` makes hipcc emit exec-mask if/else
+// chains (half of the serial loop was scalar mask juggling); multiplying by lane
+// constants keeps the chain pure VALU.
+struct LaneK {
+	int s1;      // stage-1 sign of own value: +1 for k < 2, -1 otherwise        (forward and inverse stage 2)
+	int fa, fb;  // forward stage 2: out = fa * s + fb * q   -> (1,1) (-1,1) (1,2) (1,-2)
+	int sh;      // inverse stage 1: own value >> sh, sh = 1 for k >= 2
+	int ia, ib;  // inverse stage 1: e = ia * (d >> sh) + ib * q -> (1,1) (-1,1) (1,-1) (1,1)
+};
+
+DEVI LaneK lane_consts(int k)
+{
+	LaneK c;
+	c.s1 = 1 - 2 * (k >> 1);
+	c.fa = 1 - 2 * (int)(k == 1);
+	c.fb = k < 2 ? 1 : (k == 2 ? 2 : -2);
+	c.sh = k >> 1;
+	c.ia = 1 - 2 * (int)(k == 1);
+	c.ib = 1 - 2 * (int)(k == 2);
+	return c;
+}
+
 // forward 4x4 core transform of the residual held one sample per lane (i = row,
 // j = column). Returns W[P[i]][P[j]], P = {0,2,1,3}.
-DEVI int fdct_lanes(int v, int i, int j)
+DEVI int fdct_lanes(int v, const LaneK &ci, const LaneK &cj)
 {
 	int p = dpp_xor3(v);
-	int s = j < 2 ? v + p : p - v;          // a b c d over j
+	int s = p + cj.s1 * v;                  // a b c d over j
 	int q = dpp_xor1(s);
-	s = j == 0 ? s + q : j == 1 ? q - s : j == 2 ? s + 2 * q : s - 2 * q; // W0 W2 W1 W3
+	s = cj.fa * s + cj.fb * q;              // W0 W2 W1 W3
 	p = dpp_xor12(s);
-	s = i < 2 ? s + p : p - s;
+	s = p + ci.s1 * s;
 	q = dpp_xor4(s);
-	return i == 0 ? s + q : i == 1 ? q - s : i == 2 ? s + 2 * q : s - 2 * q;
+	return ci.fa * s + ci.fb * q;
 }
 
 // inverse of the above (rows first, then columns: clause 8.5.12.2); input is the
 // scaled coefficient (P[i],P[j]) on lane (i,j); returns the residual sample (y=i, x=j)
-DEVI int idct_lanes(int d, int i, int j)
+DEVI int idct_lanes(int d, const LaneK &ci, const LaneK &cj)
 {
 	int q = dpp_xor1(d);
-	int e = j == 0 ? d + q : j == 1 ? q - d : j == 2 ? (d >> 1) - q : q + (d >> 1); // e0 e1 e2 e3
+	int e = cj.ia * (d >> cj.sh) + cj.ib * q; // e0 e1 e2 e3
 	int p = dpp_xor3(e);
-	int f = (j == 0 || j == 1) ? e + p : p - e; // f0 f1 f2 f3
+	int f = p + cj.s1 * e;                    // f0 f1 f2 f3
 	q = dpp_xor4(f);
-	e = i == 0 ? f + q : i == 1 ? q - f : i == 2 ? (f >> 1) - q : q + (f >> 1);
+	e = ci.ia * (f >> ci.sh) + ci.ib * q;
 	p = dpp_xor12(e);
-	f = (i == 0 || i == 1) ? e + p : p - e;
+	f = p + ci.s1 * e;
 	return (f + 32) >> 6;
 }
 
@@ -202,6 +229,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 		ptab1 |= (uint32_t)p.pred4_tab[(4 + m) * 16 + l] << (8 * m);
 	}
 	ptab2 = p.pred4_tab[8 * 16 + l];
+	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
 	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
 	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
 
@@ -232,7 +260,16 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 					xseen = xwait(&xprog[wj - 1], xabort, xerr, need);
 			}
 			MbInfo mi = p.mbi[mbaddr];
-			const int my_i4 = p.i4modes[mbaddr * 16 + l];
+			// all 16 Intra4x4 modes of this macroblock, one nibble each (no cross-lane
+			// shuffle on the serial chain)
+			uint64_t modes64 = 0;
+			{
+				const u32x4 mv = *(const u32x4 *)(p.i4modes + mbaddr * 16);
+				const uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+					modes64 |= (uint64_t)((mw[k >> 2] >> (8 * (k & 3))) & 15u) << (4 * k);
+			}
 			if (act) {
 				{
 					const u32x4 v = *(const u32x4 *)(src_y + (size_t)(y0 + l) * p.cw + x0);
@@ -275,6 +312,8 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 			WAVE_SYNC();
 
 			int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
+			int16_t *cf_lane = cf + COEF_LUMA + zz;         // this lane's level slot of block 0
+			uint8_t *nnz_mb = p.nnz + mbaddr * NNZ_PER_MB;
 			const bool is4 = act && mi.type == MB_I4x4, is16 = act && mi.type == MB_I16x16;
 			int cbp = 0;
 			uint32_t nzmask16 = 0; // luma blocks with coefficients, bit = raster block
@@ -290,17 +329,16 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 						const int tx = 8 + 4 * bx, ty = 1 + 4 * by;
 						bool ht, hl, htr;
 						blk4_avail(idx, top_mb, left_mb, tr_mb, ht, hl, htr);
-						const int mode = __shfl(my_i4, idx, 16);
+						const int mode = (int)((modes64 >> (4 * idx)) & 15u);
 						const uint8_t *T = L.t;
 						// edge entry k -> tile address. E[0]=E[1]=l3 E[2]=l2 E[3]=l1 E[4]=l0 E[5]=tl
 						// E[6..13]=t0..t7 (t4..7 = t3 when top-right is unavailable) E[14]=t7
-						auto eaddr = [&](int k) {
-							k = k < 1 ? 1 : k > 13 ? 13 : k;
-							int tk = k - 6;
-							tk = (tk > 3 && !htr) ? 3 : tk;
-							return k <= 4 ? (ty + 4 - k) * IT_STRIDE + tx - 1
-							     : k == 5 ? (ty - 1) * IT_STRIDE + tx - 1
-							     : (ty - 1) * IT_STRIDE + tx + tk;
+						const int tkmax = htr ? 7 : 3;
+						auto eaddr = [&](int k) { // min/max arithmetic only
+							k = max(1, min(13, k));
+							const int row = ty - 1 + max(0, 5 - k);
+							const int col = tx - 1 + max(0, min(k - 6, tkmax) + 1);
+							return row * IT_STRIDE + col;
 						};
 						const uint32_t pw = mode < 4 ? ptab0 : mode < 8 ? ptab1 : ptab2;
 						const int ent = (int)((pw >> (8 * (mode & 3))) & 0xffu);
@@ -313,23 +351,23 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 							sl_ += T[(ty + q) * IT_STRIDE + tx - 1];
 						}
 						const int dcv = (ht && hl) ? (st_ + sl_ + 4) >> 3 : hl ? (sl_ + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
-						int pv = eb;
-						pv = kind == 1 ? (eb + ec + 1) >> 1 : pv;
-						pv = kind == 2 ? (ea + 2 * eb + ec + 2) >> 2 : pv;
-						pv = kind == 3 ? dcv : pv;
+						const int pv = sel(nz_mask(kind ^ 3), // kind 3 = DC
+								   sel(nz_mask(kind ^ 2), sel(nz_mask(kind ^ 1), eb, (eb + ec + 1) >> 1),
+								       (ea + 2 * eb + ec + 2) >> 2),
+								   dcv);
 						const int res = (int)L.src[(4 * by + pi) * 16 + 4 * bx + pj] - pv;
-						const int w = fdct_lanes(res, pi, pj);
+						const int w = fdct_lanes(res, ci, cj);
 						level = quant1(w, my_mf, f_intra, p.qbits);
-						cf[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
+						cf_lane[idx * 16] = (int16_t)level;
 						const int d = (level * my_dv) << p.qshift;
-						const int r = idct_lanes(d, pi, pj);
+						const int r = idct_lanes(d, ci, cj);
 						L.t[(ty + pi) * IT_STRIDE + tx + pj] = (uint8_t)clip255(pv + r);
 					}
 					const uint64_t bal = __ballot(is4 && level != 0);
 					const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
 					if (is4) {
 						if (l == 0)
-							p.nnz[mbaddr * NNZ_PER_MB + bx + 4 * by] = (uint8_t)nn;
+							nnz_mb[bx + 4 * by] = (uint8_t)nn;
 						cbp |= nn ? (1 << (idx >> 2)) : 0;
 						nzmask16 |= nn ? (1u << (bx + 4 * by)) : 0;
 					}
@@ -590,9 +628,6 @@ struct DbGroupLds {
 // of a difference, a select becomes an AND with 0 / -1): hipcc turns `c ? a : b`
 // chains into exec-mask branches, ~80 regions per step, which saturate the CU's
 // one scalar pipe that all 16 waves of the workgroup share.
-DEVI int lt_mask(int a, int b) { return (a - b) >> 31; }          // a < b ? -1 : 0  (|a|,|b| < 2^30)
-DEVI int nz_mask(int v) { return (v | -v) >> 31; }               // v != 0 ? -1 : 0
-DEVI int sel(int m, int a, int b) { return b ^ ((a ^ b) & m); }  // m ? a : b for m in {0,-1}
 
 // normal filter (bS 1..3). tcw = tc0 values for bS 0..3 packed one per byte (byte 0 = 0).
 DEVI void filt_luma_n(int bs, int alpha, int beta, uint32_t tcw,
