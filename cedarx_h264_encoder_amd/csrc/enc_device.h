@@ -162,6 +162,70 @@ DEVI void blk4_avail(int idx, bool top_mb, bool left_mb, bool tr_mb, bool &ht, b
 	htr = by == 0 ? (bx < 3 ? top_mb : tr_mb) : ((tri >> idx) & 1);
 }
 
+// comparisons and selects as integer masks: `c ? a : b` chains make hipcc emit
+// exec-mask branches, which the single scalar pipe of a CU pays for
+DEVI int lt_mask(int a, int b) { return (a - b) >> 31; }          // a < b ? -1 : 0  (|a|,|b| < 2^30)
+DEVI int nz_mask(int v) { return (v | -v) >> 31; }               // v != 0 ? -1 : 0
+DEVI int sel(int m, int a, int b) { return b ^ ((a ^ b) & m); }  // m ? a : b for m in {0,-1}
+
+// cross-lane exchanges inside a 16-lane DPP row; lane = 4*i + j
+DEVI int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); } // quad_perm [1,0,3,2]
+DEVI int dpp_xor3(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xf, 0xf, false); } // quad_perm [3,2,1,0]
+DEVI int dpp_xor4(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); } // row_half_mirror, j restored
+DEVI int dpp_xor12(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); } // row_mirror, j restored
+
+// Per-lane constants of the butterflies below (k = position 0..3 along the axis).
+// Selecting with `k == 0 ? .. : k == 1 ? ..` makes hipcc emit exec-mask if/else
+// chains (half of the serial loop was scalar mask juggling); multiplying by lane
+// constants keeps the chain pure VALU.
+struct LaneK {
+	int s1;      // stage-1 sign of own value: +1 for k < 2, -1 otherwise        (forward and inverse stage 2)
+	int fa, fb;  // forward stage 2: out = fa * s + fb * q   -> (1,1) (-1,1) (1,2) (1,-2)
+	int sh;      // inverse stage 1: own value >> sh, sh = 1 for k >= 2
+	int ia, ib;  // inverse stage 1: e = ia * (d >> sh) + ib * q -> (1,1) (-1,1) (1,-1) (1,1)
+};
+
+DEVI LaneK lane_consts(int k)
+{
+	LaneK c;
+	c.s1 = 1 - 2 * (k >> 1);
+	c.fa = 1 - 2 * (int)(k == 1);
+	c.fb = k < 2 ? 1 : (k == 2 ? 2 : -2);
+	c.sh = k >> 1;
+	c.ia = 1 - 2 * (int)(k == 1);
+	c.ib = 1 - 2 * (int)(k == 2);
+	return c;
+}
+
+// forward 4x4 core transform of the residual held one sample per lane (i = row,
+// j = column). Returns W[P[i]][P[j]], P = {0,2,1,3}.
+DEVI int fdct_lanes(int v, const LaneK &ci, const LaneK &cj)
+{
+	int p = dpp_xor3(v);
+	int s = p + cj.s1 * v;                  // a b c d over j
+	int q = dpp_xor1(s);
+	s = cj.fa * s + cj.fb * q;              // W0 W2 W1 W3
+	p = dpp_xor12(s);
+	s = p + ci.s1 * s;
+	q = dpp_xor4(s);
+	return ci.fa * s + ci.fb * q;
+}
+
+// inverse of the above (rows first, then columns: clause 8.5.12.2); input is the
+// scaled coefficient (P[i],P[j]) on lane (i,j); returns the residual sample (y=i, x=j)
+DEVI int idct_lanes(int d, const LaneK &ci, const LaneK &cj)
+{
+	int q = dpp_xor1(d);
+	int e = cj.ia * (d >> cj.sh) + cj.ib * q; // e0 e1 e2 e3
+	int p = dpp_xor3(e);
+	int f = p + cj.s1 * e;                    // f0 f1 f2 f3
+	q = dpp_xor4(f);
+	e = ci.ia * (f >> ci.sh) + ci.ib * q;
+	p = dpp_xor12(e);
+	f = p + ci.s1 * e;
+	return (f + 32) >> 6;
+}
+
 DEVI int mv_bits(int d)
 {
 	int a = iabs(d);

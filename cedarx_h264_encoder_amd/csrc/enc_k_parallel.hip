@@ -150,15 +150,26 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	for (int i = 0; i < 64; i++)
 		curd[i] = ((const uint32_t *)s_cur)[i];
 
+	// lane task: dx group g = lane % 9 (fixed for the lane, so its 4 dx costs and their
+	// validity are computed once), dy = 7 * round + lane / 9 - 16; lane 63 idles.
 	const int R = p.search_range;
 	uint32_t best = 0xffffffffu;
+	const int g9 = lane % 9, dsub = lane / 9;
+	const int dx0 = 4 * g9 - 16;
+	uint32_t cost_x[4];
+	bool ok_x[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int dx = dx0 + k;
+		ok_x[k] = lane < 63 && dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
+		cost_x[k] = (uint32_t)(p.lambda * mv_bits(dx)) << 11 | (uint32_t)(dx + 16);
+	}
 	for (int round = 0; round < 5; round++) {
-		int t = round * 64 + lane;
-		const bool tvalid = t < 297;
-		t = tvalid ? t : 296;
-		const int dyi = t / 9, g = t - dyi * 9;
-		const int dy = dyi - 16, dx0 = 4 * g - 16;
-		const uint8_t *base = s_ref + dyi * REF_STRIDE + 4 * g;
+		const int dyi_raw = 7 * round + dsub;
+		const bool tvalid = dyi_raw < 33;
+		const int dyi = tvalid ? dyi_raw : 32;
+		const int dy = dyi - 16;
+		const uint8_t *base = s_ref + dyi * REF_STRIDE + 4 * g9;
 		// four independent accumulators (one per 4-sample segment) keep the qsad
 		// pipeline full; each lane's 4 x u16 partial SADs are summed afterwards
 		uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -174,103 +185,120 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 		// per-u16 sums cannot carry: a full 16x16 SAD is at most 65280
 		const uint64_t acc = (a0 + a1) + (a2 + a3);
 		const bool yok = tvalid && dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
-		const int cost_y = p.lambda * mv_bits(dy);
+		// key = cost << 11 | candidate index, index = (dy+16)*33 + dx+16
+		const uint32_t key_y = ((uint32_t)(p.lambda * mv_bits(dy)) << 11) + (uint32_t)((dy + 16) * 33);
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
-			const int dx = dx0 + k;
-			const bool ok = yok && dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
 			const uint32_t sad = (uint32_t)(acc >> (16 * k)) & 0xffffu;
-			const uint32_t cost = sad + (uint32_t)(cost_y + p.lambda * mv_bits(dx));
-			const uint32_t key = (cost << 11) | (uint32_t)((dy + 16) * 33 + dx + 16);
-			best = (ok && key < best) ? key : best;
+			const uint32_t key = (sad << 11) + key_y + cost_x[k];
+			best = (yok && ok_x[k] && key < best) ? key : best;
 		}
 	}
 	best = wave_min_u32(best);
 	const int bidx = (int)(best & 2047u);
 	const int bdy = bidx / 33 - 16, bdx = bidx - (bidx / 33) * 33 - 16;
 
-	// ---- residual, transform, quantisation, reconstruction: one lane per 4x4 block ----
+	// ---- residual, transform, quantisation, reconstruction: one lane per SAMPLE ----
+	// 16-lane group = one 4x4 block, transforms across lanes with DPP (enc_device.h):
+	// 4 passes cover the 16 luma blocks, 2 passes the 8 chroma blocks, all 64 lanes busy.
 	for (int i = lane; i < COEF_PER_MB; i += 64)
 		s_coef[i] = 0;
 	__syncthreads();
 
-	int nnz = 0, dc_level_nz = 0;
 	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / 6;
-	if (lane < 16) {
-		const int bx = blk_x(lane), by = blk_y(lane);
-		int pred[16], res[16], w[16], lv[16], d[16], out[16];
+	const int gq = lane >> 4, l = lane & 15;
+	const int pi = l >> 2, pj = l & 3;
+	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
+	const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
+	const int rpos = 4 * kv + kh;             // coefficient (raster) this lane ends up holding
+	const int pclass = (kv & 1) == (kh & 1) ? (kv & 1) : 2;
+	int zz = 0;
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-			pred[i] = s_ref[(16 + bdy + y) * REF_STRIDE + 16 + bdx + x];
-			res[i] = (int)s_cur[y * 16 + x] - pred[i];
-		}
-		fdct4x4(res, w);
-		nnz = quant_dequant(w, 0, p.mf, p.dv, f_inter, p.qbits, p.qshift, lv, d);
-		idct4x4_add(d, pred, out);
+	for (int z = 0; z < 16; z++)
+		zz = kZigzag[z] == rpos ? z : zz;
+	const int mf_y = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
+	const int dv_y = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
+	const int mf_c = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
+	const int dv_c = pclass == 0 ? p.dvc[0] : pclass == 1 ? p.dvc[1] : p.dvc[2];
+
+	uint32_t nz_luma = 0; // bit = coding-order block index
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			s_coef[COEF_LUMA + lane * 16 + i] = (int16_t)lv[i];
-			s_recy[(4 * by + (i >> 2)) * 16 + 4 * bx + (i & 3)] = (uint8_t)out[i];
-		}
+	for (int pass = 0; pass < 4; pass++) {
+		const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
+		const int x = 4 * bx + pj, y = 4 * by + pi;
+		const int pv = s_ref[(16 + bdy + y) * REF_STRIDE + 16 + bdx + x];
+		const int res = (int)s_cur[y * 16 + x] - pv;
+		const int w = fdct_lanes(res, ci, cj);
+		const int level = quant1(w, mf_y, f_inter, p.qbits);
+		s_coef[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
+		const int r = idct_lanes((level * dv_y) << p.qshift, ci, cj);
+		s_recy[y * 16 + x] = (uint8_t)clip255(pv + r);
+		const uint64_t bal = __ballot(level != 0);
+		const int nn = __popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
+		if (l == 0)
+			p.nnz[mbaddr * NNZ_PER_MB + bx + 4 * by] = (uint8_t)nn;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			nz_luma |= ((uint32_t)(bal >> (16 * k)) & 0xffffu) ? (1u << (4 * pass + k)) : 0u;
 	}
-	// chroma: lanes 16..23, plane c, block blk (raster 2x2)
-	int cpred[16], cw_[16], clv[16], cd[16];
-	const bool is_c = lane >= 16 && lane < 24;
-	const int c = (lane - 16) >> 2, blk = (lane - 16) & 3;
-	if (is_c) {
-		const int bx = blk & 1, by = blk >> 1;
-		const int ix = bdx >> 1, iy = bdy >> 1, fx = (bdx & 1) * 4, fy = (bdy & 1) * 4;
-		int res[16];
+	// chroma: pass = plane, group = block (raster 2x2)
+	const int ix = bdx >> 1, iy = bdy >> 1, fx = (bdx & 1) * 4, fy = (bdy & 1) * 4;
+	int cpv[2], cdq[2];
+	uint32_t nz_cac = 0;
 #pragma unroll
-		for (int i = 0; i < 16; i++) {
-			int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-			int wr = y + iy + 8, wc = x + ix + 8; // window row / pair index
-			int wr1 = fy ? wr + 1 : wr, wc1 = fx ? wc + 1 : wc;
-			int A = s_refc[wr * REFC_STRIDE + 2 * wc + c], B = s_refc[wr * REFC_STRIDE + 2 * wc1 + c];
-			int C = s_refc[wr1 * REFC_STRIDE + 2 * wc + c], D = s_refc[wr1 * REFC_STRIDE + 2 * wc1 + c];
-			cpred[i] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
-			res[i] = (int)s_curc[y * 16 + 2 * x + c] - cpred[i];
-		}
-		fdct4x4(res, cw_);
-		s_dc[lane - 16] = cw_[0];
+	for (int c = 0; c < 2; c++) {
+		const int bx = gq & 1, by = gq >> 1;
+		const int x = 4 * bx + pj, y = 4 * by + pi;
+		const int wr = y + iy + 8, wc = x + ix + 8; // window row / pair index
+		const int wr1 = fy ? wr + 1 : wr, wc1 = fx ? wc + 1 : wc;
+		const int A = s_refc[wr * REFC_STRIDE + 2 * wc + c], B = s_refc[wr * REFC_STRIDE + 2 * wc1 + c];
+		const int C = s_refc[wr1 * REFC_STRIDE + 2 * wc + c], D = s_refc[wr1 * REFC_STRIDE + 2 * wc1 + c];
+		cpv[c] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
+		const int res = (int)s_curc[y * 16 + 2 * x + c] - cpv[c];
+		const int w = fdct_lanes(res, ci, cj);
+		if (l == 0)
+			s_dc[4 * c + gq] = w; // lane (0,0) holds the DC coefficient
+		const int level = l == 0 ? 0 : quant1(w, mf_c, f_inter_c, p.qbits_c);
+		if (l != 0)
+			s_coef[COEF_CAC + (4 * c + gq) * 16 + zz] = (int16_t)level;
+		cdq[c] = (level * dv_c) << p.qshift_c;
+		const uint64_t bal = __ballot(level != 0);
+		const int nn = __popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
+		if (l == 0)
+			p.nnz[mbaddr * NNZ_PER_MB + 16 + 4 * c + gq] = (uint8_t)nn;
+		nz_cac |= bal ? 1u : 0u;
 	}
 	__syncthreads();
-	if (is_c) {
-		// forward 2x2 Hadamard: this lane produces output `blk` of plane c
+	int dc_level_nz = 0;
+	if (lane < 8) { // 2x2 Hadamard of the chroma DCs: lane = (plane, output index)
+		const int c = lane >> 2, blk = lane & 3;
 		const int *dcs = s_dc + 4 * c;
 		const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
-		int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
-		int l = quant1(hd, p.mfc[0], 2 * f_inter_c, p.qbits_c + 1);
-		s_cdc[lane - 16] = l;
-		s_coef[COEF_CDC + 4 * c + blk] = (int16_t)l;
-		dc_level_nz = l != 0;
+		const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
+		const int lq = quant1(hd, p.mfc[0], 2 * f_inter_c, p.qbits_c + 1);
+		s_cdc[lane] = lq;
+		s_coef[COEF_CDC + lane] = (int16_t)lq;
+		dc_level_nz = lq != 0;
 	}
 	__syncthreads();
-	if (is_c) {
-		const int bx = blk & 1, by = blk >> 1;
+#pragma unroll
+	for (int c = 0; c < 2; c++) {
+		const int bx = gq & 1, by = gq >> 1;
+		const int x = 4 * bx + pj, y = 4 * by + pi;
 		const int *ls = s_cdc + 4 * c;
-		const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
-		int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
-		int out[16];
-		nnz = quant_dequant(cw_, 1, p.mfc, p.dvc, f_inter_c, p.qbits_c, p.qshift_c, clv, cd);
-		cd[0] = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
-		idct4x4_add(cd, cpred, out);
-#pragma unroll
-		for (int i = 1; i < 16; i++)
-			s_coef[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)clv[i];
-#pragma unroll
-		for (int i = 0; i < 16; i++)
-			s_recc[(4 * by + (i >> 2)) * 16 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
+		const int s1 = (gq & 1) ? -1 : 1, s2 = (gq & 2) ? -1 : 1;
+		const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
+		const int dcr = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
+		const int r = idct_lanes(l == 0 ? dcr : cdq[c], ci, cj);
+		s_recc[y * 16 + 2 * x + c] = (uint8_t)clip255(cpv[c] + r);
 	}
-	// coded block pattern from wave ballots
-	const uint64_t nzmask = __ballot(nnz != 0);
+	// coded block pattern
 	const uint64_t dcmask = __ballot(dc_level_nz != 0);
 	int cbp = 0;
 #pragma unroll
 	for (int q = 0; q < 4; q++)
-		cbp |= ((nzmask >> (4 * q)) & 0xf) ? (1 << q) : 0;
-	cbp |= ((nzmask >> 16) & 0xff) ? 0x20 : (dcmask ? 0x10 : 0);
+		cbp |= ((nz_luma >> (4 * q)) & 0xfu) ? (1 << q) : 0;
+	cbp |= nz_cac ? 0x20 : (dcmask ? 0x10 : 0);
 	__syncthreads();
 
 	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
@@ -280,12 +308,8 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 		*(u32x4 *)(rec_y + (size_t)(y0 + lane) * p.cw + x0) = *(const u32x4 *)(s_recy + lane * 16);
 	else if (lane < 24)
 		*(u32x4 *)(rec_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
-	if (lane < 16) {
-		p.nnz[mbaddr * NNZ_PER_MB + blk_x(lane) + 4 * blk_y(lane)] = (uint8_t)nnz;
+	if (lane < 16)
 		p.i4modes[mbaddr * 16 + lane] = 2;
-	} else if (lane < 24) {
-		p.nnz[mbaddr * NNZ_PER_MB + lane] = (uint8_t)nnz;
-	}
 	if (lane == 0) {
 		MbInfo m;
 		m.type = MB_P16x16;
