@@ -802,8 +802,17 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 			}
 			WAVE_SYNC();
 
+			// content fast path: when no macroblock of the wave has any non-zero boundary
+			// strength (skipped / zero-residual regions with uniform motion), both filter
+			// phases are the identity; staging, hand-off and write-back still run
+			bool work = act;
+			if (!IDR)
+				work = act && (nz_cur != 0 || (left_edge && ((nz_left & 0x8888u) != 0 || mvc != mvl)) ||
+					       (top_edge && ((nz_top & 0xf000u) != 0 || mvc != mvt)));
+			const bool any_work = __any(work);
+
 			const int k = l >> 2; // 4-sample segment of this lane's line
-			if (act) {
+			if (act && any_work) {
 				// ---- vertical edges: lane = sample row l ----
 				int bs[4];
 				if (IDR) {
@@ -869,7 +878,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 				}
 			}
 			WAVE_SYNC();
-			if (act) {
+			if (act && any_work) {
 				// ---- horizontal edges: lane = sample column l ----
 				int bs[4];
 				if (IDR) {
