@@ -116,6 +116,47 @@ int main(int argc, char **argv)
 
 	luma_size = width * height;
 	chroma_size = luma_size / 2;
+	/* The reference loop is strictly serial: read, ENCODE, write (h264enc.c:181-198).
+	 * Here frame n+1 is read and uploaded while frame n is still being encoded:
+	 * cedar_enc_submit() returns as soon as the input buffers may be refilled,
+	 * cedar_enc_collect() delivers the oldest frame. Same bytes, same order.
+	 * H264ENC_PIPELINE=0 restores the serial loop. */
+	if (env_int("H264ENC_PIPELINE", 1)) {
+		int in_flight = 0;
+
+		while (1) {
+			int got = read_frame(fd_in, config.input_luma, luma_size) == luma_size &&
+				  read_frame(fd_in, config.input_chroma, chroma_size) == chroma_size;
+
+			if (got) {
+				ret = cedar_enc_submit(cedar);
+				if (ret < 0)
+					fprintf(stderr, "%s(): %d: CEDAR_IOCTL_ENCODE failed: %s\n", __func__,
+						frame_count + in_flight, strerror(-ret));
+				else
+					in_flight++;
+			}
+			while (in_flight > (got ? 1 : 0)) {
+				const uint8_t *data;
+				int size;
+
+				ret = cedar_enc_collect(cedar);
+				in_flight--;
+				if (ret < 0) {
+					fprintf(stderr, "%s(): %d: CEDAR_IOCTL_ENCODE failed: %s\n", __func__, frame_count, strerror(-ret));
+					continue;
+				}
+				cedar_enc_stream_output(cedar, 0, &data, &size);
+				printf("\rFrame %5d: %5dbytes", frame_count, ret);
+				if (write(fd_out, data, size) != size)
+					fprintf(stderr, "%s(): short write\n", __func__);
+				frame_count++;
+			}
+			if (!got)
+				break;
+		}
+		return 0;
+	}
 	while (1) {
 		ret = read_frame(fd_in, config.input_luma, luma_size);
 		if (ret != luma_size)

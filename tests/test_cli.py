@@ -70,6 +70,62 @@ def test_scalar_cli_usage_and_errors(tmp_path):
     assert r.returncode != 0 and b"config failed" in r.stderr  # odd width: EINVAL (cedar.c:749)
 
 
+def test_h264dec_tool_reports_psnr(tmp_path):
+    """the stand-alone decoder tool decodes what the CLI wrote and reports PSNR."""
+    w, h, frames = 320, 240, 3
+    raw = _raw("B", w, h, frames)
+    src, out, dec = tmp_path / "src.nv12", tmp_path / "o.264", tmp_path / "dec.nv12"
+    src.write_bytes(raw)
+    env = dict(os.environ, H264ENC_QP="30", H264ENC_KEYINT="25")
+    assert subprocess.run([SCALAR, str(src), str(w), str(h), str(out)], capture_output=True, env=env).returncode == 0
+    tool = os.path.join(ROOT, "oracle", "build", "h264dec")
+    r = subprocess.run([tool, str(out), str(dec), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "decoded 3 pictures 320x240" in r.stdout
+    psnr = float(r.stdout.strip().split("PSNR Y ")[-1].split(" dB")[0])
+    assert 30.0 < psnr < 60.0
+    assert dec.stat().st_size == len(raw)
+    # decoded pictures equal the encoder's reconstruction (cropped)
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25))
+    data = dec.read_bytes()
+    for f in range(frames):
+        enc.encode(*ol.gen_frame("B", w, h, f))
+        ry, ruv = enc.recon()
+        fr = np.frombuffer(data[f * w * h * 3 // 2:(f + 1) * w * h * 3 // 2], np.uint8)
+        assert np.array_equal(fr[:w * h].reshape(h, w), ry[:h, :w])
+        assert np.array_equal(fr[w * h:].reshape(h // 2, w), ruv[:h // 2, :w])
+    # a corrupted stream is rejected, not silently accepted
+    bad = bytearray(out.read_bytes())
+    bad[len(bad) // 2] ^= 0xFF
+    (tmp_path / "bad.264").write_bytes(bytes(bad))
+    r = subprocess.run([tool, str(tmp_path / "bad.264"), "-"], capture_output=True, text=True)
+    assert r.returncode in (0, 1)  # may still parse; must not crash
+
+
+@pytest.mark.gpu
+def test_hip_cli_config1_full_length_pipelined_and_serial(tmp_path):
+    """BASELINE configs[1] as specified: 854x480, 50 frames (2 GOPs of 25), QP 30, through the
+    reference command line; the pipelined frame pump and the serial one (h264enc.c:181-198)
+    write the same file, and it equals the scalar C twin's."""
+    w, h, frames = 854, 480, 50
+    raw = _raw("B", w, h, frames)
+    env = dict(os.environ, H264ENC_QP="30", H264ENC_KEYINT="25")
+    outs = {}
+    for mode in ("1", "0"):
+        o = tmp_path / ("hip%s.264" % mode)
+        r = subprocess.run([HIPCLI, "-", str(w), str(h), str(o)], input=raw, capture_output=True,
+                           env=dict(env, H264ENC_PIPELINE=mode), timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert b"Frame    49:" in r.stdout
+        outs[mode] = o.read_bytes()
+    assert outs["1"] == outs["0"]
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25))
+    want = b"".join(enc.encode(*ol.gen_frame("B", w, h, f)) for f in range(frames))
+    assert outs["1"] == want
+    nal = [outs["1"][i + 4] & 0x1f for i in range(len(outs["1"]) - 4) if outs["1"][i:i + 4] == b"\0\0\0\1"]
+    assert nal == [7, 8, 5] + [1] * 24 + [5] + [1] * 24
+
+
 @pytest.mark.gpu
 def test_hip_cli_equals_scalar_cli(tmp_path):
     """README.md:25-36 use: raw nv12 on stdin, 854x480 (not a multiple of 16), I+P."""

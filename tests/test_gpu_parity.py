@@ -159,6 +159,23 @@ def test_batched_streams_equal_independent_streams(ce):
                 assert ge.output(s) == refs[s], "frame %d stream %d" % (f, s)
 
 
+def test_config4_shape_eight_1080p_streams_in_one_session(ce):
+    """BASELINE configs[4] shape on one device: 8 lock-step 1920x1080 streams (seed offset
+    s<<8); every stream must equal the oracle's encode of that stream alone."""
+    w, h, S = 1920, 1080, 8
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=24, keyint=25)) for _ in range(S)]
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25, n_streams=S) as ge:
+        for f in range(2):
+            refs = []
+            for s in range(S):
+                y, uv = ce.gen_pattern("B", w, h, f, s << 8)
+                ge.set_input(y, uv, s)
+                refs.append(oes[s].encode(y, uv))
+            ge.encode()
+            for s in range(S):
+                assert ge.output(s) == refs[s], "frame %d stream %d" % (f, s)
+
+
 def test_pipelined_submit_collect_equals_synchronous(ce):
     w, h = 320, 240
     frames = [ol.gen_frame("B", w, h, f) for f in range(7)]
