@@ -792,7 +792,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
 		f.h_hdr[k] = build_slice_header(e, idr, e->frame_p_count, idr_pic_id, r0 * P.mb_w);
 	}
-	const bool with_ps = e->frame_count == 0 && e->ext.slice_first == 0; // cedar.c:1058-1061
+	const bool with_ps = (e->frame_count == 0 || (idr && e->ext.repeat_headers)) && e->ext.slice_first == 0; // cedar.c:1058-1061
 	f.with_ps = with_ps;
 	for (int s = 0; s < S; s++)
 		f.h_prefix[s] = with_ps ? (uint32_t)e->sps_pps.size() : 0;

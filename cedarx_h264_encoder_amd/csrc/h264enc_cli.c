@@ -53,6 +53,7 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.device = env_int("H264ENC_DEVICE", 0);
 	ext.slice_count = env_int("H264ENC_SLICES", 1);
 	ext.search_range = env_int("H264ENC_SEARCH", 0);
+	ext.repeat_headers = env_int("H264ENC_REPEAT_HEADERS", 0);
 
 	ret = cedar_enc_config_ext(cedar, &config, &ext);
 	if (ret) {

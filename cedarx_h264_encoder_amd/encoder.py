@@ -41,7 +41,7 @@ class _Config(ctypes.Structure):
 class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
-        "chroma_qp_offset_minus4")] + [("reserved", ctypes.c_int * 8)]
+        "chroma_qp_offset_minus4", "repeat_headers")] + [("reserved", ctypes.c_int * 7)]
 
 
 class _Stats(ctypes.Structure):
@@ -146,6 +146,7 @@ class EncoderConfig:
     slice_num: int = 0
     search_range: int = 0
     chroma_qp_offset_minus4: int = 0
+    repeat_headers: int = 0
 
 
 class CedarEncoder:
@@ -173,7 +174,7 @@ class CedarEncoder:
         x = _ConfigExt()
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
-                  "chroma_qp_offset_minus4"):
+                  "chroma_qp_offset_minus4", "repeat_headers"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")

@@ -84,7 +84,10 @@ struct cedar_enc_config_ext {
 				-1 = zero-vector only                                 */
 	int chroma_qp_offset_minus4; /* chroma_qp_index_offset - 4: 0 keeps the reference's
 				+4 (cedar.c:971-972, :1165-1168)                      */
-	int reserved[8];
+	int repeat_headers;  /* 1: SPS+PPS in front of every IDR, so closed GOPs encoded by
+				different sessions / GPUs can be concatenated; 0: only
+				before the very first frame (cedar.c:1058-1061)          */
+	int reserved[7];
 };
 
 typedef struct cedar_enc cedar_enc;

@@ -76,6 +76,7 @@ int main(int argc, char **argv)
 	cfg.keyint = env_int("H264ENC_KEYINT", cfg.keyint);
 	cfg.slice_count = env_int("H264ENC_SLICES", cfg.slice_count);
 	cfg.search_range = env_int("H264ENC_SEARCH", cfg.search_range);
+	cfg.repeat_headers = env_int("H264ENC_REPEAT_HEADERS", 0);
 	enc = h264o_open(&cfg, &err);
 	if (!enc) {
 		fprintf(stderr, "%s(): config failed: %s\n", __func__, strerror(-err));

@@ -41,6 +41,7 @@ typedef struct h264o_config {
 	int search_range;     /* full-pel, 0..16                   */
 	int slice_count;      /* >= 1, bands of MB rows            */
 	int chroma_qp_offset; /* 4 (cedar.c:971, :1167)            */
+	int repeat_headers;   /* 1: SPS+PPS in front of every IDR (reference: frame 0 only, cedar.c:1058) */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */

@@ -1728,7 +1728,7 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 
 	pad_source(e, luma, chroma);
 
-	if (e->frame_count == 0) { /* cedar.c:1058-1061 */
+	if (e->frame_count == 0 || (idr && e->cfg.repeat_headers)) { /* cedar.c:1058-1061 */
 		r = h264o_write_sps(&e->cfg, out + o, out_cap - o);
 		if (r < 0)
 			return r;

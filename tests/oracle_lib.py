@@ -18,7 +18,7 @@ MB_I4x4, MB_I16x16, MB_P16x16, MB_PSKIP = 0, 1, 2, 3
 class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
-        "search_range", "slice_count", "chroma_qp_offset")]
+        "search_range", "slice_count", "chroma_qp_offset", "repeat_headers")]
 
 
 class MB(ctypes.Structure):

@@ -69,6 +69,36 @@ def test_bitstream_and_state_equal_oracle(ce, w, h, qp, keyint, frames, pattern,
             assert got == ref, "frame %d: bytestream differs" % f
 
 
+def test_randomised_geometries_qps_slices(ce):
+    """Seeded sweep over odd shapes: widths/heights that are not multiples of 16, row counts
+    that are not multiples of 4 (idle row groups in the wavefront kernels), several slices,
+    workgroup splits of the wavefront, tiny search ranges, extreme QPs."""
+    rng = np.random.RandomState(20261003)
+    for case in range(24):
+        w = int(rng.randint(1, 20)) * 16 - int(rng.choice([0, 0, 2, 6, 10, 14]))
+        h = int(rng.randint(1, 14)) * 16 - int(rng.choice([0, 0, 2, 4, 8, 12]))
+        w, h = max(w, 16), max(h, 16)
+        mb_h = (h + 15) // 16
+        qp = int(rng.choice([1, 8, 17, 24, 30, 36, 41, 47]))
+        keyint = int(rng.choice([1, 2, 3, 25]))
+        slices = int(rng.randint(1, min(4, mb_h) + 1))
+        search = int(rng.choice([0, 0, 0, 4, -1]))
+        pat = str(rng.choice(["A", "B", "C"]))
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices,
+                                                search_range=16 if search == 0 else max(search, 0)))
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices,
+                             search_range=search) as ge:
+            for f in range(3):
+                y, uv = ol.gen_frame(pat, w, h, f)
+                ref = oe.encode(y, uv)
+                got = ge.encode_frame(y, uv)
+                assert got == ref, "case %d (%dx%d qp%d ki%d sl%d sr%d %s) frame %d" % (
+                    case, w, h, qp, keyint, slices, search, pat, f)
+                ry, ruv = oe.recon()
+                assert np.array_equal(ry, ge.debug_read("recon_y"))
+                assert np.array_equal(ruv, ge.debug_read("recon_uv"))
+
+
 def test_1080p_gop_bit_exact_and_decodable(ce):
     """BASELINE configs[2] at full size (1920x1080 I+P QP 24): a short run against
     the oracle, then a longer run checked by the size-independent property
@@ -209,6 +239,23 @@ def test_device_resident_input_equals_host_input(ce):
             b.set_device_input(0, ty.data_ptr(), tuv.data_ptr())
             b.encode()
             assert b.output() == ref
+
+
+def test_repeat_headers_and_gop_sharding(ce):
+    """Closed GOPs shard: with repeat_headers every GOP starts with SPS+PPS+IDR and
+    depends on nothing before it, so a second session that starts at GOP 1 (fresh state, frames
+    25..) produces GOP 1 of the serial encode except for idr_pic_id / frame counters it cannot
+    know -- here both sessions encode from their frame 0, so the bytes must be identical."""
+    w, h = 320, 240
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=3, repeat_headers=1))
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=3, repeat_headers=1) as ge:
+        for f in range(7):
+            y, uv = ol.gen_frame("B", w, h, f)
+            ref = oe.encode(y, uv)
+            got = ge.encode_frame(y, uv)
+            assert got == ref
+            kinds = [got[i + 4] & 0x1f for i in range(len(got) - 4) if got[i:i + 4] == b"\0\0\0\1"]
+            assert kinds == ([7, 8, 5] if f % 3 == 0 else [1])
 
 
 def test_session_contract_errors(ce):

@@ -124,3 +124,14 @@ def test_gop_cadence_and_frame_num():
         types.append(nal_types)
     assert types[0] == [7, 8, 5]
     assert types[1:] == [[1], [1], [5], [1], [1], [5]]
+
+
+def test_repeat_headers_puts_parameter_sets_before_every_idr():
+    c = ol.default_config(32, 32, keyint=2, qp=30, repeat_headers=1)
+    e = ol.OracleEncoder(c)
+    y, uv = ol.gen_frame("A", 32, 32, 0)
+    kinds = []
+    for f in range(4):
+        au = e.encode(y, uv)
+        kinds.append([au[i + 4] & 0x1f for i in range(len(au) - 4) if au[i:i + 4] == b"\0\0\0\1"])
+    assert kinds == [[7, 8, 5], [1], [7, 8, 5], [1]]
