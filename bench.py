@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--keyint", type=int, default=25)
     ap.add_argument("--frames", type=int, default=50, help="distinct synthetic frames per stream (cycled)")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--batched-streams", type=int, default=8,
-                    help="also report throughput with this many streams per GPU (0 = skip)")
+    ap.add_argument("--batched-streams", type=str, default="8,32",
+                    help="also report throughput with these many lock-step streams per GPU (0 = skip)")
     return ap.parse_args()
 
 
@@ -103,7 +103,7 @@ def run_rank(args, rank, world, local_rank):
 
         def feed(i):
             for s in range(S):
-                y, uv = inputs[s][i % args.frames]
+                y, uv = inputs[s % len(inputs)][i % args.frames]
                 enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
             enc.submit()
 
@@ -130,7 +130,9 @@ def run_rank(args, rank, world, local_rank):
         return dt, nbytes, st, first_aus
 
     S = args.streams
-    inputs = make_inputs(max(S, args.batched_streams))
+    sweep = [int(x) for x in str(args.batched_streams).split(",") if x.strip() and int(x) > 0 and int(x) != S]
+    # at most 8 distinct synthetic streams are generated; larger batches reuse them cyclically
+    inputs = make_inputs(max(S, min(8, max(sweep + [1]))))
     dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, True)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
@@ -145,18 +147,17 @@ def run_rank(args, rank, world, local_rank):
     total_mbs = world * S * mbs_per_frame * args.steps
     value = total_mbs / dt_max
 
-    batched = None
-    if args.batched_streams and args.batched_streams != S:
-        SB = args.batched_streams
+    batched = []
+    for SB in sweep:
         bsteps = max(25, min(args.steps, 50))
         bdt, _, _, _ = measure(SB, bsteps, args.keyint, inputs, False)
         if world > 1:
             t = torch.tensor([bdt], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bdt = float(t.item())
-        batched = {"streams_per_gpu": SB, "steps": bsteps,
-                   "value": world * SB * mbs_per_frame * bsteps / bdt,
-                   "ms_per_step": bdt / bsteps * 1e3}
+        v = world * SB * mbs_per_frame * bsteps / bdt
+        batched.append({"streams_per_gpu": SB, "steps": bsteps, "value": v, "ms_per_step": bdt / bsteps * 1e3,
+                        "pipeline_frac_of_hbm_peak": v * 1136.64 / 1e9 / HBM_PEAK_GBS})
 
     if rank != 0:
         return None
