@@ -1002,11 +1002,502 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 	}
 }
 
+// ------------------------------------------------------------------------
+// #define DB2_TIMING 1
+// k_deblock2: the same wavefront with SPECIALISED WAVES. One wave's step used to be
+// ~1400 instructions of which ~550 filter samples; the rest stages tiles, derives
+// boundary strengths, writes results back and hands rows on. A wave alone on its
+// SIMD issues one instruction per ~4.5 cycles whatever their dependencies, so the
+// step time is the instruction count. Here every band is served by a PAIR:
+//   filter wave  per step: copy left columns / top rows inside LDS, 4 vertical +
+//                4 horizontal edges on the staged tile, save the bottom rows (`bot`)
+//   mover wave   one step ahead: loads of step t+2 in flight, stages step t+1
+//                (samples + packed boundary strengths) into the next of 3 tile
+//                slots, and behind: writes step t-1 back to memory, feeds the next
+//                workgroup, publishes progress
+// They meet only through two monotonic LDS counters (staged / filtered).
+// ------------------------------------------------------------------------
+constexpr int DB2_PAIRS = WF_WAVES / 2;
+
+struct Db2GroupLds {
+	uint8_t y[3][20 * DT_STRIDE];
+	uint8_t c[3][10 * DC_STRIDE];
+	uint8_t bot[4][4 * 16];
+	uint8_t botc[4][2 * 16];
+	uint32_t bsw[3][16];  // per lane: luma V bS (4 x 4 bit) | luma H bS << 16
+	uint32_t bsc[3][16];  // per lane: chroma V bS (2 x 4 bit)
+};
+
+DEVI void lds_wait_ge(const int *word, int need, uint32_t *err)
+{
+	// bounded like every spin here: a lost partner ends in -EIO at collect, not in a hung grid
+	for (int spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spins++) {
+		if (spins > (1 << 22)) {
+			__hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			break;
+		}
+		__builtin_amdgcn_s_sleep(0);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+DEVI void lds_signal(int *word, int value, int lane)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0)
+		__hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool IDR, int PL>
+__global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
+{
+	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
+	__shared__ __attribute__((aligned(16))) Db2GroupLds s_g[DB2_PAIRS * 4];
+	__shared__ int s_prog[MAX_ROWS];
+	__shared__ int s_staged[DB2_PAIRS], s_filtered[DB2_PAIRS];
+	__shared__ int s_ticket;
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// waves land on SIMD wave%4: filter k on SIMD k%4, its mover on SIMD (k+2)%4, so the
+	// busy filter waves of a workgroup (bands come in pair order) never share a SIMD early
+	const bool is_mover = wave >= DB2_PAIRS;
+	const int pair = is_mover ? (wave + 6) & (DB2_PAIRS - 1) : wave;
+	const int g = lane >> 4, l = lane & 15;
+	const int NWG = p.wf_split;
+	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
+	if (threadIdx.x == 0)
+		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
+	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
+		s_prog[i] = 0;
+	if (threadIdx.x < DB2_PAIRS) {
+		s_staged[threadIdx.x] = 0;
+		s_filtered[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
+	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+
+	Db2GroupLds &L = s_g[pair * 4 + g];
+	const Db2GroupLds &LU = s_g[pair * 4 + (g > 0 ? g - 1 : 0)];
+	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
+	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
+	const int nbands = (r1 - r0 + 3) >> 2;
+	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
+	const int nsteps = p.mb_w + 6;
+	const uint32_t tcw_y = ((uint32_t)p.tc0_y[0] << 8) | ((uint32_t)p.tc0_y[1] << 16) | ((uint32_t)p.tc0_y[2] << 24);
+	const uint32_t tcw_c = ((uint32_t)p.tc0_c[0] << 8) | ((uint32_t)p.tc0_c[1] << 16) | ((uint32_t)p.tc0_c[2] << 24);
+	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
+	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2;
+	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint32_t xseen = 0;
+
+	int iter = 0;
+	for (int band = b_lo + pair; band < b_hi; band += DB2_PAIRS, iter++) {
+		const int base = iter * (nsteps + 2); // absolute step numbering of this pair's counters
+		const int my = r0 + 4 * band + g;
+		const bool row_ok = my < r1;
+		const bool top_edge = my > r0;
+		const bool xwave_top = g == 0 && band > b_lo;
+		const bool xwg_band = band == b_lo && b_lo > 0;
+		const bool xwg_top = g == 0 && xwg_band;
+		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands;
+
+		if (!is_mover) {
+			// =========================== filter wave ===========================
+#ifdef DB2_TIMING
+			long long tw = 0, tv = 0, th = 0, tt0 = __builtin_readcyclecounter();
+#endif
+			for (int t = 0; t < nsteps; t++) {
+				const int mx = t - 2 * g;
+				const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+				const bool left_edge = mx > 0;
+				const int slot = t % 3, pslot = (t + 2) % 3;
+#ifdef DB2_TIMING
+				long long c0 = __builtin_readcyclecounter();
+#endif
+				lds_wait_ge(&s_staged[pair], base + t + 1, xerr);
+#ifdef DB2_TIMING
+				long long c1 = __builtin_readcyclecounter();
+				tw += c1 - c0;
+#endif
+				if (act) {
+					if (left_edge) { // previous tile's last 4 columns (final) become the left neighbours
+						if (DO_Y)
+							*(uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y[pslot] + (4 + l) * DT_STRIDE + 28);
+						if (DO_C && l < 8)
+							*(uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12) = *(const uint32_t *)(L.c[pslot] + (2 + l) * DC_STRIDE + 28);
+					}
+					if (top_edge && g > 0) { // rows above: the group above saved them two steps ago
+						if (DO_Y && l < 4)
+							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 3] + l * 16);
+						else if (DO_C && l >= 4 && l < 6)
+							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 3] + (l - 4) * 16);
+					}
+				}
+				WAVE_SYNC();
+				const uint32_t bw = L.bsw[slot][l], bc = L.bsc[slot][l];
+				const bool any_work = __any(act && (bw | bc) != 0);
+				if (act && any_work) {
+					// ---- vertical edges: lane = sample row l ----
+					if (DO_Y) {
+						int px[20];
+						const uint32_t *rowp = (const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+#pragma unroll
+						for (int w = 0; w < 5; w++) {
+							const uint32_t v = rowp[w];
+							px[4 * w] = v & 0xff;
+							px[4 * w + 1] = (v >> 8) & 0xff;
+							px[4 * w + 2] = (v >> 16) & 0xff;
+							px[4 * w + 3] = v >> 24;
+						}
+#pragma unroll
+						for (int e = 0; e < 4; e++) {
+							const int q = 4 + 4 * e;
+							const int bs = (int)((bw >> (4 * e)) & 15u);
+							if (IDR && e == 0)
+								filt_luma_s(bs, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+									    px[q], px[q + 1], px[q + 2], px[q + 3]);
+							else
+								filt_luma_n(bs, p.alpha_y, p.beta_y, tcw_y,
+									    px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
+						}
+						uint32_t *roww = (uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+#pragma unroll
+						for (int w = 0; w < 5; w++)
+							roww[w] = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
+					}
+					if (DO_C) { // lane = (plane c = l>>3, chroma row r = l&7); edges at chroma x = 0 and 4
+						const int c = l >> 3, r = l & 7;
+						const int bsc0 = (int)(bc & 15u), bsc2 = (int)((bc >> 4) & 15u);
+						uint8_t *cp = L.c[slot] + (2 + r) * DC_STRIDE + 16 + c;
+						int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
+						int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
+						if (IDR)
+							filt_chroma_s(bsc0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+						else
+							filt_chroma_n(bsc0, p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
+						filt_chroma_n(bsc2, p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
+						cp[-2] = (uint8_t)a0;
+						cp[0] = (uint8_t)b0;
+						cp[6] = (uint8_t)c0;
+						cp[8] = (uint8_t)d0;
+					}
+				}
+				WAVE_SYNC();
+#ifdef DB2_TIMING
+				long long c2 = __builtin_readcyclecounter();
+				tv += c2 - c1;
+#endif
+				if (act && any_work) {
+					// ---- horizontal edges: lane = sample column l ----
+					if (DO_Y) {
+						int py[20];
+						uint8_t *colp = L.y[slot] + 16 + l;
+#pragma unroll
+						for (int r = 0; r < 20; r++)
+							py[r] = colp[r * DT_STRIDE];
+#pragma unroll
+						for (int e = 0; e < 4; e++) {
+							const int q = 4 + 4 * e;
+							const int bs = (int)((bw >> (16 + 4 * e)) & 15u);
+							if (IDR && e == 0)
+								filt_luma_s(bs, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+									    py[q], py[q + 1], py[q + 2], py[q + 3]);
+							else
+								filt_luma_n(bs, p.alpha_y, p.beta_y, tcw_y,
+									    py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
+						}
+#pragma unroll
+						for (int r = 1; r < 19; r++)
+							colp[r * DT_STRIDE] = (uint8_t)py[r];
+					}
+					if (DO_C) { // lane = byte column l of the nv12 row
+						const int bs0 = (int)((bw >> 16) & 15u), bs2 = (int)((bw >> 24) & 15u);
+						uint8_t *cp = L.c[slot] + 16 + l;
+						int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
+						int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
+						if (IDR)
+							filt_chroma_s(bs0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+						else
+							filt_chroma_n(bs0, p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
+						filt_chroma_n(bs2, p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
+						cp[DC_STRIDE] = (uint8_t)a0;
+						cp[2 * DC_STRIDE] = (uint8_t)b0;
+						cp[5 * DC_STRIDE] = (uint8_t)c0;
+						cp[6 * DC_STRIDE] = (uint8_t)d0;
+					}
+				}
+				WAVE_SYNC();
+				if (act) { // bottom rows for the row below; columns 12..15 of the previous MB are final now
+					if (DO_Y && l >= 12) {
+						*(u32x4 *)(L.bot[mx & 3] + (l - 12) * 16) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
+						if (left_edge)
+							*(uint32_t *)(L.bot[(mx - 1) & 3] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+					} else if (DO_C && l >= 6 && l < 8) {
+						*(u32x4 *)(L.botc[mx & 3] + (l - 6) * 16) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
+						if (left_edge)
+							*(uint32_t *)(L.botc[(mx - 1) & 3] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+					}
+				}
+				lds_signal(&s_filtered[pair], base + t + 1, lane);
+#ifdef DB2_TIMING
+				th += __builtin_readcyclecounter() - c2;
+#endif
+			}
+#ifdef DB2_TIMING
+			if (lane == 0 && s_ticket == 1 && pair == 1 && iter == 0 && !IDR)
+				printf("filter PL%d: total %lld wait %lld V %lld H %lld per step over %d steps\n", PL,
+				       (__builtin_readcyclecounter() - tt0) / nsteps, tw / nsteps, tv / nsteps, th / nsteps, nsteps);
+#endif
+			continue;
+		}
+
+		// ============================== mover wave ==============================
+		const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
+		// two register sets: the loads of step t+3 are issued while step t+1 is staged (memory
+		// latency here is about one whole step)
+		struct MoverRegs {
+			u32x4 in, c, top;
+			uint64_t topx;
+			uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
+			uint8_t nz, nzt;
+			bool top_ok;
+		};
+		MoverRegs RA{}, RB{};
+		uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
+		int mvl = 0;
+		int pending_pub = -1, pending_x = -1;
+
+		auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t into the r_* registers
+			const int nmx = t - 2 * g, mx0 = t;
+			const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
+			const int cmx = nact ? nmx : 0;
+			const size_t a = row_mb + cmx;
+			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
+			// readiness of the rows above first: its acquire must not sit behind this step's own loads
+			R.top_ok = true;
+			if (band > b_lo && mx0 < p.mb_w) {
+				const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w;
+				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
+				if (!ready && block) {
+					wait_progress(s_prog, 4 * band - 1, need);
+					ready = true;
+				}
+				if (ready)
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				R.top_ok = ready;
+			} else if (xwg_band && mx0 < p.mb_w) {
+				const uint32_t need = (uint32_t)mx0 + 1u;
+				if (xseen < need)
+					xseen = xload32(&xprog[wj - 1]);
+				if (xseen < need && block)
+					xseen = xwait(&xprog[wj - 1], xabort, xerr, need);
+				R.top_ok = xseen >= need;
+			}
+			if (DO_Y)
+				R.in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
+			if (DO_C)
+				R.c = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
+			if (!IDR) {
+				R.mv = ((const uint32_t *)&p.mbi[a])[1];
+				R.nz = p.nnz[a * NNZ_PER_MB + l];
+				const size_t at = (top_edge && row_ok) ? a - p.mb_w : a;
+				R.mvt = ((const uint32_t *)&p.mbi[at])[1];
+				R.nzt = p.nnz[at * NNZ_PER_MB + l];
+			}
+			if (xwave_top && R.top_ok && nact) {
+				if (DO_Y && l < 4)
+					R.top = *(const u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0);
+				else if (DO_C && l >= 4 && l < 6)
+					R.top = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) - 2 + l - 4) * p.cw + x0);
+			}
+			if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
+				R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
+		};
+
+		auto stage_step = [&](int t, const MoverRegs &R) { // r_* registers -> tile slot t%3 + packed boundary strengths
+			const int mx = t - 2 * g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+			const bool left_edge = mx > 0;
+			const int slot = t % 3;
+			uint32_t nz_cur = 0, nz_top = 0;
+			int mvc = 0, mvt = 0;
+			if (!IDR) {
+				const uint64_t bal_c = __ballot(act && R.nz != 0), bal_t = __ballot(act && top_edge && R.nzt != 0);
+				nz_cur = (uint32_t)(bal_c >> (16 * g)) & 0xffffu;
+				nz_top = (uint32_t)(bal_t >> (16 * g)) & 0xffffu;
+				mvc = (int)R.mv;
+				mvt = (int)R.mvt;
+			}
+			uint32_t bw = 0, bc = 0;
+			if (act) {
+				if (DO_Y)
+					*(u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16) = R.in;
+				if (DO_C && l < 8)
+					*(u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16) = R.c;
+				if (top_edge && g == 0) {
+					if (xwg_top) {
+						if (DO_Y && l < 8)
+							*(uint64_t *)(L.y[slot] + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = R.topx;
+						else if (DO_C && l >= 8 && l < 12)
+							*(uint64_t *)(L.c[slot] + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = R.topx;
+					} else {
+						if (DO_Y && l < 4)
+							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = R.top;
+						else if (DO_C && l >= 4 && l < 6)
+							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = R.top;
+					}
+				}
+				const int k = l >> 2, ks = (l & 7) >> 1;
+				int bv[4], bh[4], bsc0, bsc2;
+				if (IDR) {
+					bv[0] = left_edge ? 4 : 0;
+					bh[0] = top_edge ? 4 : 0;
+					bv[1] = bv[2] = bv[3] = bh[1] = bh[2] = bh[3] = 3;
+					bsc0 = bv[0];
+					bsc2 = 3;
+				} else {
+					const int mvd_l = nz_mask(mvc ^ mvl) & 1, mvd_t = nz_mask(mvc ^ mvt) & 1;
+					const int nzv0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
+					bv[0] = (2 * nzv0 + ((1 - nzv0) & mvd_l)) & -(int)left_edge;
+					const int nzh0 = (int)(((nz_cur >> k) | (nz_top >> (12 + k))) & 1u);
+					bh[0] = (2 * nzh0 + ((1 - nzh0) & mvd_t)) & -(int)top_edge;
+#pragma unroll
+					for (int e = 1; e < 4; e++) {
+						bv[e] = 2 * (int)(((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1u);
+						bh[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
+					}
+					const int nzc0 = (int)(((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1u);
+					bsc0 = (2 * nzc0 + ((1 - nzc0) & mvd_l)) & -(int)left_edge;
+					bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
+				}
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+					bw |= (uint32_t)bv[e] << (4 * e) | (uint32_t)bh[e] << (16 + 4 * e);
+				bc = (uint32_t)bsc0 | (uint32_t)bsc2 << 4;
+				nz_left = nz_cur;
+				mvl = mvc;
+			}
+			L.bsw[slot][l] = bw;
+			L.bsc[slot][l] = bc;
+		};
+
+		auto writeback_step = [&](int t) { // filtered tile of step t -> memory, next workgroup
+			const int mx = t - 2 * g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+			const bool left_edge = mx > 0;
+			const int slot = t % 3;
+			const int x0 = mx * 16, y0 = my * 16;
+			if (!act)
+				return;
+			if (DO_Y && !(is_xprod && l >= 12)) {
+				*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
+				if (left_edge)
+					*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+			}
+			if (DO_C && l < 8 && !(is_xprod && l >= 6)) {
+				*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
+				if (left_edge)
+					*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+			}
+			if (top_edge) {
+				if (DO_Y && l < 4)
+					*(u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + l * DT_STRIDE + 16);
+				else if (DO_C && l >= 4 && l < 6)
+					*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16);
+			}
+			pending_pub = mx;
+			if (is_xprod) {
+				const bool my_gran = (DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES);
+				if (left_edge && my_gran) {
+					const uint8_t *src = l < 8 ? L.bot[(mx - 1) & 3] + (l >> 1) * 16 + (l & 1) * 8
+								   : L.botc[(mx - 1) & 3] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
+					xstore64(hb_out + (size_t)(mx - 1) * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+				}
+				if (mx == p.mb_w - 1 && my_gran) {
+					const uint8_t *src = l < 8 ? L.bot[mx & 3] + (l >> 1) * 16 + (l & 1) * 8
+								   : L.botc[mx & 3] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
+					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+				}
+				pending_x = mx == p.mb_w - 1 ? p.mb_w : mx;
+			}
+		};
+
+		auto publish = [&]() { // everything issued an iteration ago has completed by now
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (pending_pub >= 0 && l == 0)
+				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			pending_pub = -1;
+			if (b_hi < nbands && band == b_hi - 1) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (is_xprod && l == 0 && pending_x >= 0)
+					xstore32(&xprog[wj], (uint32_t)pending_x);
+				pending_x = -1;
+			}
+		};
+
+		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
+			if (t >= 1)
+				lds_wait_ge(&s_filtered[pair], base + t, xerr); // step t-1 filtered
+			publish();
+			if (t + 1 < nsteps) {
+				if (!R.top_ok)
+					load_step(t + 1, true, R);
+				stage_step(t + 1, R);
+				load_step(t + 3, false, R);
+				lds_signal(&s_staged[pair], base + t + 2, lane);
+			}
+			if (t >= 1)
+				writeback_step(t - 1);
+		};
+		// prologue: step 0 staged, loads of steps 1 and 2 in flight
+		load_step(0, true, RA);
+		load_step(1, false, RB);
+		stage_step(0, RA);
+		load_step(2, false, RA);
+		lds_signal(&s_staged[pair], base + 1, lane);
+#ifdef DB2_TIMING
+		long long mt0 = __builtin_readcyclecounter();
+#endif
+		for (int t = 0; t <= nsteps; t += 2) {
+			mover_iter(t, RB);
+			if (t + 1 <= nsteps)
+				mover_iter(t + 1, RA);
+		}
+		publish();
+#ifdef DB2_TIMING
+		if (lane == 0 && s_ticket == 1 && pair == 1 && iter == 0 && !IDR)
+			printf("mover PL%d: total %lld\n", PL, (__builtin_readcyclecounter() - mt0) / nsteps);
+#endif
+	}
+}
+
 int Launch::deblock(const Params &p, void *stream, int planes)
 {
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
 	const unsigned pad_lds = 12 * 1024; // 74 KiB static + 12 KiB > 80 KiB: one workgroup per CU
 	hipStream_t s = (hipStream_t)stream;
+	static int version = 0;
+	if (!version) {
+		const char *e = getenv("CEDAR_DEBLOCK_V");
+		version = e ? atoi(e) : 2;
+	}
+	if (version == 2) { // specialised filter / mover waves (110 KiB LDS: one workgroup per CU by itself)
+		if (p.is_idr) {
+			if (planes == 1) hipLaunchKernelGGL((k_deblock2<true, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
+			else if (planes == 2) hipLaunchKernelGGL((k_deblock2<true, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
+			else hipLaunchKernelGGL((k_deblock2<true, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
+		} else {
+			if (planes == 1) hipLaunchKernelGGL((k_deblock2<false, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
+			else if (planes == 2) hipLaunchKernelGGL((k_deblock2<false, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
+			else hipLaunchKernelGGL((k_deblock2<false, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
+		}
+		return (int)hipGetLastError();
+	}
 	if (p.is_idr) {
 		if (planes == 1) hipLaunchKernelGGL((k_deblock<true, 1>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
 		else if (planes == 2) hipLaunchKernelGGL((k_deblock<true, 2>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
