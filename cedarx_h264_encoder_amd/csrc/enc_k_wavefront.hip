@@ -1017,6 +1017,64 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
 //                workgroup, publishes progress
 // They meet only through two monotonic LDS counters (staged / filtered).
 // ------------------------------------------------------------------------
+// Edge codes: the mover turns every boundary strength into one byte, 0x80 | tc0 (0 = edge
+// not filtered), so the filter wave spends two bit-field extracts on it. |a-b|+c on byte
+// values is one v_sad_u8; thresholds go in negated so the sign bit is the comparison.
+DEVI int sadb(int a, int b, int c) { return (int)__builtin_amdgcn_sad_u8((uint32_t)a, (uint32_t)b, (uint32_t)c); }
+DEVI int med3i(int x, int lo, int hi) { return min(max(x, lo), hi); }
+DEVI int code_tc0(uint32_t w, int e) { return (int)((w >> (8 * e)) & 0x7fu); }
+DEVI int code_valid(uint32_t w, int e) { return (int)(w << (24 - 8 * e)) >> 31; }
+
+DEVI void filt_luma_n2(uint32_t w, int e, int nalpha, int nbeta,
+		       int &p2, int &p1, int &p0, int &q0, int &q1, int &q2)
+{
+	const int tc0 = code_tc0(w, e);
+	const int m = (max(max(sadb(p0, q0, nalpha), sadb(p1, p0, nbeta)), sadb(q1, q0, nbeta)) >> 31) & code_valid(w, e);
+	const int sp = sadb(p2, p0, nbeta) >> 31, sq = sadb(q2, q0, nbeta) >> 31; // -1 where the side is smooth
+	const int tc = (tc0 - sp - sq) & m;
+	const int tcp = tc0 & sp & m, tcq = tc0 & sq & m; // a masked-off update is a clip to [0, 0]
+	const int delta = med3i((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+	const int avg = (p0 + q0 + 1) >> 1;
+	p1 += med3i((p2 + avg - (p1 << 1)) >> 1, -tcp, tcp);
+	q1 += med3i((q2 + avg - (q1 << 1)) >> 1, -tcq, tcq);
+	p0 = med3i(p0 + delta, 0, 255);
+	q0 = med3i(q0 - delta, 0, 255);
+}
+
+DEVI void filt_luma_s2(uint32_t w, int e, int alpha, int beta, int p3, int &p2, int &p1, int &p0,
+		       int &q0, int &q1, int &q2, int q3)
+{
+	const int d = sadb(p0, q0, 0);
+	const int m = (max(max(d - alpha, sadb(p1, p0, -beta)), sadb(q1, q0, -beta)) >> 31) & code_valid(w, e);
+	const int small = (d - ((alpha >> 2) + 2)) >> 31;
+	const int sp = small & (sadb(p2, p0, -beta) >> 31), sq = small & (sadb(q2, q0, -beta) >> 31);
+	const int np0 = sel(sp, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, (2 * p1 + p0 + q1 + 2) >> 2);
+	const int np1 = sel(sp, (p2 + p1 + p0 + q0 + 2) >> 2, p1);
+	const int np2 = sel(sp, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2);
+	const int nq0 = sel(sq, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, (2 * q1 + q0 + p1 + 2) >> 2);
+	const int nq1 = sel(sq, (p0 + q0 + q1 + q2 + 2) >> 2, q1);
+	const int nq2 = sel(sq, (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3, q2);
+	p0 = sel(m, np0, p0); p1 = sel(m, np1, p1); p2 = sel(m, np2, p2);
+	q0 = sel(m, nq0, q0); q1 = sel(m, nq1, q1); q2 = sel(m, nq2, q2);
+}
+
+DEVI void filt_chroma_n2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &p0, int &q0, int q1)
+{
+	const int m = (max(max(sadb(p0, q0, nalpha), sadb(p1, p0, nbeta)), sadb(q1, q0, nbeta)) >> 31) & code_valid(w, e);
+	const int tc = (code_tc0(w, e) + 1) & m;
+	const int delta = med3i((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+	p0 = med3i(p0 + delta, 0, 255);
+	q0 = med3i(q0 - delta, 0, 255);
+}
+
+DEVI void filt_chroma_s2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &p0, int &q0, int q1)
+{
+	const int m = (max(max(sadb(p0, q0, nalpha), sadb(p1, p0, nbeta)), sadb(q1, q0, nbeta)) >> 31) & code_valid(w, e);
+	const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+	p0 = sel(m, np0, p0);
+	q0 = sel(m, nq0, q0);
+}
+
 constexpr int DB2_PAIRS = WF_WAVES / 2;
 
 struct Db2GroupLds {
@@ -1024,8 +1082,9 @@ struct Db2GroupLds {
 	uint8_t c[3][10 * DC_STRIDE];
 	uint8_t bot[4][4 * 16];
 	uint8_t botc[4][2 * 16];
-	uint32_t bsw[3][16];  // per lane: luma V bS (4 x 4 bit) | luma H bS << 16
-	uint32_t bsc[3][16];  // per lane: chroma V bS (2 x 4 bit)
+	uint32_t bsv[3][16];  // per lane (= sample row): edge codes of the 4 vertical luma edges, one byte each
+	uint32_t bsh[3][16];  // per lane (= sample column): the 4 horizontal luma edges
+	uint32_t bsc[3][16];  // chroma codes: bytes 0,1 vertical edges 0,2 (lane = plane, row); bytes 2,3 horizontal 0,2 (lane = column)
 };
 
 DEVI void lds_wait_ge(const int *word, int need, uint32_t *err)
@@ -1087,8 +1146,9 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 	const int nbands = (r1 - r0 + 3) >> 2;
 	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
 	const int nsteps = p.mb_w + 6;
-	const uint32_t tcw_y = ((uint32_t)p.tc0_y[0] << 8) | ((uint32_t)p.tc0_y[1] << 16) | ((uint32_t)p.tc0_y[2] << 24);
-	const uint32_t tcw_c = ((uint32_t)p.tc0_c[0] << 8) | ((uint32_t)p.tc0_c[1] << 16) | ((uint32_t)p.tc0_c[2] << 24);
+	// edge code by boundary strength 0..3, one byte each (bS 4 = 0x80: the strong filter has no tc0)
+	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
+	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
 	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2;
 	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
@@ -1139,8 +1199,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 					}
 				}
 				WAVE_SYNC();
-				const uint32_t bw = L.bsw[slot][l], bc = L.bsc[slot][l];
-				const bool any_work = __any(act && (bw | bc) != 0);
+				const uint32_t wv = DO_Y ? L.bsv[slot][l] : 0u, wh = DO_Y ? L.bsh[slot][l] : 0u, wc = DO_C ? L.bsc[slot][l] : 0u;
+				const bool any_work = __any((wv | wh | wc) != 0); // codes are 0 on idle lanes
 				if (act && any_work) {
 					// ---- vertical edges: lane = sample row l ----
 					if (DO_Y) {
@@ -1157,13 +1217,14 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 #pragma unroll
 						for (int e = 0; e < 4; e++) {
 							const int q = 4 + 4 * e;
-							const int bs = (int)((bw >> (4 * e)) & 15u);
+							if (!IDR && !__any((wv >> (8 * e)) & 0x80u))
+								continue;
 							if (IDR && e == 0)
-								filt_luma_s(bs, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
-									    px[q], px[q + 1], px[q + 2], px[q + 3]);
+								filt_luma_s2(wv, e, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+									     px[q], px[q + 1], px[q + 2], px[q + 3]);
 							else
-								filt_luma_n(bs, p.alpha_y, p.beta_y, tcw_y,
-									    px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
+								filt_luma_n2(wv, e, -p.alpha_y, -p.beta_y,
+									     px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
 						}
 						uint32_t *roww = (uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
 #pragma unroll
@@ -1172,15 +1233,14 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 					}
 					if (DO_C) { // lane = (plane c = l>>3, chroma row r = l&7); edges at chroma x = 0 and 4
 						const int c = l >> 3, r = l & 7;
-						const int bsc0 = (int)(bc & 15u), bsc2 = (int)((bc >> 4) & 15u);
 						uint8_t *cp = L.c[slot] + (2 + r) * DC_STRIDE + 16 + c;
 						int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
 						int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
 						if (IDR)
-							filt_chroma_s(bsc0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+							filt_chroma_s2(wc, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
 						else
-							filt_chroma_n(bsc0, p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
-						filt_chroma_n(bsc2, p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
+							filt_chroma_n2(wc, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+						filt_chroma_n2(wc, 1, -p.alpha_c, -p.beta_c, c1, c0, d0, d1);
 						cp[-2] = (uint8_t)a0;
 						cp[0] = (uint8_t)b0;
 						cp[6] = (uint8_t)c0;
@@ -1203,28 +1263,28 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 #pragma unroll
 						for (int e = 0; e < 4; e++) {
 							const int q = 4 + 4 * e;
-							const int bs = (int)((bw >> (16 + 4 * e)) & 15u);
+							if (!IDR && !__any((wh >> (8 * e)) & 0x80u))
+								continue;
 							if (IDR && e == 0)
-								filt_luma_s(bs, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
-									    py[q], py[q + 1], py[q + 2], py[q + 3]);
+								filt_luma_s2(wh, e, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+									     py[q], py[q + 1], py[q + 2], py[q + 3]);
 							else
-								filt_luma_n(bs, p.alpha_y, p.beta_y, tcw_y,
-									    py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
+								filt_luma_n2(wh, e, -p.alpha_y, -p.beta_y,
+									     py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
 						}
 #pragma unroll
 						for (int r = 1; r < 19; r++)
 							colp[r * DT_STRIDE] = (uint8_t)py[r];
 					}
 					if (DO_C) { // lane = byte column l of the nv12 row
-						const int bs0 = (int)((bw >> 16) & 15u), bs2 = (int)((bw >> 24) & 15u);
 						uint8_t *cp = L.c[slot] + 16 + l;
 						int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
 						int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
 						if (IDR)
-							filt_chroma_s(bs0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
+							filt_chroma_s2(wc, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
 						else
-							filt_chroma_n(bs0, p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
-						filt_chroma_n(bs2, p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
+							filt_chroma_n2(wc, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+						filt_chroma_n2(wc, 3, -p.alpha_c, -p.beta_c, c1, c0, d0, d1);
 						cp[DC_STRIDE] = (uint8_t)a0;
 						cp[2 * DC_STRIDE] = (uint8_t)b0;
 						cp[5 * DC_STRIDE] = (uint8_t)c0;
@@ -1249,8 +1309,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 #endif
 			}
 #ifdef DB2_TIMING
-			if (lane == 0 && s_ticket == 1 && pair == 1 && iter == 0 && !IDR)
-				printf("filter PL%d: total %lld wait %lld V %lld H %lld per step over %d steps\n", PL,
+			if (lane == 0 && s_ticket <= 1 && pair <= 2 && iter == 0 && !IDR && PL == 1)
+				printf("filter PL%d wg %d pair %d: total %lld wait %lld V %lld H %lld per step over %d steps\n", PL, s_ticket, pair,
 				       (__builtin_readcyclecounter() - tt0) / nsteps, tw / nsteps, tv / nsteps, th / nsteps, nsteps);
 #endif
 			continue;
@@ -1333,7 +1393,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 				mvc = (int)R.mv;
 				mvt = (int)R.mvt;
 			}
-			uint32_t bw = 0, bc = 0;
+			uint32_t wv = 0, wh = 0, wc = 0;
 			if (act) {
 				if (DO_Y)
 					*(u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16) = R.in;
@@ -1352,15 +1412,14 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = R.top;
 					}
 				}
-				const int k = l >> 2, ks = (l & 7) >> 1;
-				int bv[4], bh[4], bsc0, bsc2;
-				if (IDR) {
-					bv[0] = left_edge ? 4 : 0;
-					bh[0] = top_edge ? 4 : 0;
-					bv[1] = bv[2] = bv[3] = bh[1] = bh[2] = bh[3] = 3;
-					bsc0 = bv[0];
-					bsc2 = 3;
+				if (IDR) { // all intra: bS 4 (strong) on macroblock edges, 3 inside
+					const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
+					wv = in_y | (left_edge ? 0x80u : 0u);
+					wh = in_y | (top_edge ? 0x80u : 0u);
+					wc = (left_edge ? 0x80u : 0u) | in_c << 8 | (top_edge ? 0x80u : 0u) << 16 | in_c << 24;
 				} else {
+					const int k = l >> 2, ks = (l & 7) >> 1;
+					int bv[4], bh[4];
 					const int mvd_l = nz_mask(mvc ^ mvl) & 1, mvd_t = nz_mask(mvc ^ mvt) & 1;
 					const int nzv0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
 					bv[0] = (2 * nzv0 + ((1 - nzv0) & mvd_l)) & -(int)left_edge;
@@ -1372,18 +1431,26 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 						bh[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
 					}
 					const int nzc0 = (int)(((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1u);
-					bsc0 = (2 * nzc0 + ((1 - nzc0) & mvd_l)) & -(int)left_edge;
-					bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
-				}
+					const int bsc0 = (2 * nzc0 + ((1 - nzc0) & mvd_l)) & -(int)left_edge;
+					const int bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
+					// boundary strength -> edge code byte (0x80 | tc0, 0 = leave the edge alone)
 #pragma unroll
-				for (int e = 0; e < 4; e++)
-					bw |= (uint32_t)bv[e] << (4 * e) | (uint32_t)bh[e] << (16 + 4 * e);
-				bc = (uint32_t)bsc0 | (uint32_t)bsc2 << 4;
+					for (int e = 0; e < 4; e++) {
+						wv |= ((cod_y >> (8 * bv[e])) & 0xffu) << (8 * e);
+						wh |= ((cod_y >> (8 * bh[e])) & 0xffu) << (8 * e);
+					}
+					wc = ((cod_c >> (8 * bsc0)) & 0xffu) | ((cod_c >> (8 * bsc2)) & 0xffu) << 8 |
+					     ((cod_c >> (8 * bh[0])) & 0xffu) << 16 | ((cod_c >> (8 * bh[2])) & 0xffu) << 24;
+				}
 				nz_left = nz_cur;
 				mvl = mvc;
 			}
-			L.bsw[slot][l] = bw;
-			L.bsc[slot][l] = bc;
+			if (DO_Y) {
+				L.bsv[slot][l] = wv;
+				L.bsh[slot][l] = wh;
+			}
+			if (DO_C)
+				L.bsc[slot][l] = wc;
 		};
 
 		auto writeback_step = [&](int t) { // filtered tile of step t -> memory, next workgroup
@@ -1440,13 +1507,29 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 			}
 		};
 
+#ifdef DB2_TIMING
+		long long mw = 0, mb = 0;
+#endif
 		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
+#ifdef DB2_TIMING
+			long long c0 = __builtin_readcyclecounter();
+#endif
 			if (t >= 1)
 				lds_wait_ge(&s_filtered[pair], base + t, xerr); // step t-1 filtered
+#ifdef DB2_TIMING
+			long long c1 = __builtin_readcyclecounter();
+			mw += c1 - c0;
+#endif
 			publish();
 			if (t + 1 < nsteps) {
+#ifdef DB2_TIMING
+				long long c2 = __builtin_readcyclecounter();
+#endif
 				if (!R.top_ok)
 					load_step(t + 1, true, R);
+#ifdef DB2_TIMING
+				mb += __builtin_readcyclecounter() - c2;
+#endif
 				stage_step(t + 1, R);
 				load_step(t + 3, false, R);
 				lds_signal(&s_staged[pair], base + t + 2, lane);
@@ -1470,8 +1553,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 		}
 		publish();
 #ifdef DB2_TIMING
-		if (lane == 0 && s_ticket == 1 && pair == 1 && iter == 0 && !IDR)
-			printf("mover PL%d: total %lld\n", PL, (__builtin_readcyclecounter() - mt0) / nsteps);
+		if (lane == 0 && s_ticket <= 1 && pair <= 2 && iter == 0 && !IDR && PL == 1)
+			printf("mover PL%d wg %d pair %d: total %lld wait-filter %lld blocked-on-top %lld\n", PL, s_ticket, pair, (__builtin_readcyclecounter() - mt0) / nsteps, mw / nsteps, mb / nsteps);
 #endif
 	}
 }

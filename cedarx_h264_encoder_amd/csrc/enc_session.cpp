@@ -592,9 +592,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 			if ((b - a + 3) / 4 < nb_min) nb_min = (b - a + 3) / 4;
 		}
 		const char *env = getenv("CEDAR_WF_SPLIT");
-		// measured on MI355X (1080p): 1 unit: 4 parts = 1.26x on deblock, 1.36x on intra recon,
-		// 8 parts no better (each wave is then alone on its SIMD: issue-latency bound)
-		int split = env ? atoi(env) : (n_units <= 16 ? 4 : n_units <= 48 ? 2 : 1);
+		// measured on MI355X (1080p, 1 unit): deblock 0.58 ms with 4 parts, 0.51 ms with 8 (every
+		// filter wave alone on its SIMD, its mover on another); intra recon 1.36x from 4 parts
+		int split = env ? atoi(env) : (n_units <= 8 ? 8 : n_units <= 16 ? 4 : n_units <= 48 ? 2 : 1);
 		if (split > WF_MAX_SPLIT) split = WF_MAX_SPLIT;
 		if (split > nb_min / 2) split = nb_min / 2;
 		if (split < 1) split = 1;
