@@ -39,6 +39,7 @@ constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
 constexpr int WF_MAX_SPLIT = 8;   // workgroups sharing one unit's wavefront
 constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress
+constexpr int IN_K_STREAMS = 8;     // up to this many streams pass their frame pointers as kernel arguments
 constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
 // What one picture-slice header contributes in front of the macroblock data.
@@ -69,8 +70,9 @@ struct Params {
 	int32_t alpha_y, beta_y, tc0_y[3];
 	int32_t alpha_c, beta_c, tc0_c[3];
 	// device pointers
-	const uint8_t *const *in_luma;   // [n_streams] tightly packed width x height
+	const uint8_t *const *in_luma;   // [n_streams] tightly packed width x height; nullptr: use in_k
 	const uint8_t *const *in_chroma; // [n_streams]
+	const uint8_t *in_k[2 * IN_K_STREAMS]; // few streams: the frame pointers travel in the kernel arguments (luma, then chroma)
 	uint8_t *src_y, *src_uv;         // padded source planes
 	uint8_t *rec_y, *rec_uv;         // reconstruction being written
 	const uint8_t *ref_y, *ref_uv;   // previous reconstruction (deblocked)
@@ -101,6 +103,7 @@ struct Params {
 	uint32_t *wf_sync;               // [3][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock (luma), 2 deblock chroma
 	uint64_t *wf_hbuf;               // [n_units][wf_split-1][mb_w][WF_HBUF_GRANULES]
 	int32_t wf_split;
+	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
 	int32_t unit_mb_cap;             // max macroblocks of one unit

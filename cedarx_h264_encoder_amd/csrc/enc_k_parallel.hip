@@ -45,13 +45,29 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 	const int seg = blockIdx.x * blockDim.x + threadIdx.x;
 	const int row = blockIdx.y; // [0, ch) luma, [ch, ch + ch/2) chroma
 	const int st = blockIdx.z;
+	// first job of every frame on this stream: the ticket / abort / progress words of the
+	// three wavefront kernels start at zero (one memset launch less per frame)
+	if (row == 0 && st == 0 && p.wf_split > 1) {
+		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
+		for (int i = seg; i < 3 * used; i += gridDim.x * blockDim.x)
+			p.wf_sync[(i / used) * WF_SYNC_WORDS + i % used] = 0;
+	}
 	if (seg >= segs)
 		return;
 	const bool luma = row < p.ch;
 	const int prow = luma ? row : row - p.ch;
 	const int srows = luma ? p.height : p.height >> 1;
 	const int sy = prow < srows ? prow : srows - 1;
-	const uint8_t *src = (luma ? p.in_luma[st] : p.in_chroma[st]) + (size_t)sy * p.width;
+	const uint8_t *base;
+	if (p.in_luma) {
+		base = luma ? p.in_luma[st] : p.in_chroma[st];
+	} else { // wave-uniform pick from the kernel arguments without indexing them dynamically
+		base = nullptr;
+#pragma unroll
+		for (int k = 0; k < IN_K_STREAMS; k++)
+			base = st == k ? (luma ? p.in_k[k] : p.in_k[IN_K_STREAMS + k]) : base;
+	}
+	const uint8_t *src = base + (size_t)sy * p.width;
 	uint8_t *dst = luma ? p.src_y + (size_t)st * p.plane_y_stride + (size_t)prow * p.cw
 			    : p.src_uv + (size_t)st * p.plane_uv_stride + (size_t)prow * p.cw;
 	const int x0 = seg << 4;

@@ -69,7 +69,7 @@ DEVI uint32_t xwait(const uint32_t *word, uint32_t *abort_word, uint32_t *err_wo
 	while (v < need) {
 		if (++spins > (1u << 21) || xload32(abort_word)) {
 			xstore32(abort_word, 1u);
-			atomicOr(err_word, 4u);
+			__hip_atomic_store(err_word, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			return 0x7fffffffu;
 		}
 		__builtin_amdgcn_s_sleep(8);
@@ -115,6 +115,7 @@ struct IntraGroupLds {
 	int cdl[8];
 };
 
+// #define IR_TIMING 1
 template <int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
-	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2;
+	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
 	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
 	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
@@ -179,7 +180,13 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 		const bool xwg_band = band == b_lo && b_lo > 0;                    // row above lives in another workgroup
 		const bool xwg_top = g == 0 && xwg_band;
 		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands; // this row feeds the next workgroup
+#ifdef IR_TIMING
+		long long tl = 0, t4 = 0, t16 = 0, tc = 0, twb = 0, tt0 = __builtin_readcyclecounter();
+#endif
 		for (int step = 0; step < p.mb_w + 6; step++) {
+#ifdef IR_TIMING
+			long long c0 = __builtin_readcyclecounter();
+#endif
 			const int mx = step - 2 * g;
 			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 			const bool left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
@@ -257,6 +264,9 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 			int cbp = 0;
 			uint32_t nzmask16 = 0; // luma blocks with coefficients, bit = raster block
 
+#ifdef IR_TIMING
+			long long c1 = __builtin_readcyclecounter();
+#endif
 			// ---- Intra 4x4: serial over the 16 blocks, lane = sample ----
 			if (__any(is4)) {
 				if (is4)
@@ -314,6 +324,9 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 				}
 			}
 
+#ifdef IR_TIMING
+			long long c2 = __builtin_readcyclecounter();
+#endif
 			// ---- Intra 16x16: lane = 4x4 block (coding order) ----
 			if (__any(is16)) {
 				const int bx = blk_x(l), by = blk_y(l);
@@ -399,6 +412,9 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 					cbp = ((uint32_t)(bal >> (16 * g)) & 0xffffu) ? 15 : 0;
 			}
 
+#ifdef IR_TIMING
+			long long c3 = __builtin_readcyclecounter();
+#endif
 			// ---- chroma: lanes 0..7 of the group = (plane c, block blk) ----
 			int cnn = 0, cdcnz = 0;
 			{
@@ -488,6 +504,9 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 			}
 			WAVE_SYNC();
 
+#ifdef IR_TIMING
+			long long c4 = __builtin_readcyclecounter();
+#endif
 			// ---- write back reconstruction rows and the record ----
 			if (act) {
 				{
@@ -519,7 +538,17 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (act && l == 0)
 				__hip_atomic_store(&s_prog[my - r0], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef IR_TIMING
+			tl += c1 - c0; t4 += c2 - c1; t16 += c3 - c2; tc += c4 - c3; twb += __builtin_readcyclecounter() - c4;
+#endif
 		}
+#ifdef IR_TIMING
+		if (lane == 0 && s_ticket <= 1 && wave <= 1 && band < b_lo + NWAVES) {
+			const int n = p.mb_w + 6;
+			printf("intra wg %d wave %d: total %lld load %lld i4 %lld i16 %lld chroma %lld writeback %lld\n", s_ticket, wave,
+			       (__builtin_readcyclecounter() - tt0) / n, tl / n, t4 / n, t16 / n, tc / n, twb / n);
+		}
+#endif
 	}
 }
 
@@ -541,482 +570,33 @@ int Launch::intra_recon(const Params &p, void *stream)
 }
 
 // ------------------------------------------------------------------------
-// k_deblock: each wave sweeps a band of 4 macroblock rows; lane group
-// g = lane>>4 works on row band+g, two macroblocks behind group g-1, so all 64
-// lanes are busy. Within a group the 16 lanes are the 16 sample rows of the
-// macroblock for the vertical edges and its 16 sample columns for the
-// horizontal edges; each lane filters its line in registers (branch-free).
-//   * loads of step s+1 (samples, records) are issued at the start of step s and
-//     consumed at its end: no global latency on the dependency chain
-//   * the bottom rows a macroblock hands to the row below travel through LDS
-//     (`bot`) between groups of one wave; only band boundaries (another wave)
-//     go through memory, under the progress counters
-//   * template on the picture type: P pictures carry no strong-filter code
+// k_deblock2: in-loop deblocking as a macroblock wavefront. A band of 4 macroblock
+// rows is swept left to right; lane group g = lane>>4 works on row band+g, two
+// macroblocks behind group g-1, so all 64 lanes are busy. Within a group the 16
+// lanes are the 16 sample rows of the macroblock for the vertical edges and its 16
+// sample columns for the horizontal edges; each lane filters its line in registers
+// with pure integer mask arithmetic (hipcc turns `c ? a : b` chains into exec-mask
+// branches, which saturate the CU's one scalar pipe).
+//
+// SPECIALISED WAVES. A wave alone on its SIMD issues one instruction per ~4.5
+// cycles whatever their dependencies, so a step costs its instruction count. One
+// wave doing everything needed ~1400 instructions per step, of which ~550 filter
+// samples. Here every band is served by a PAIR:
+//   filter wave  per step: copy left columns / top rows inside LDS, 4 vertical +
+//                4 horizontal edges on the staged tile, save the bottom rows (`bot`)
+//   mover wave   ahead: loads of step t+3 in flight, stages step t+1 (samples +
+//                edge codes) into the next of 3 tile slots; behind: writes step t-1
+//                back to memory, feeds the next workgroup, publishes progress
+// They meet only through two monotonic LDS counters (staged / filtered). The bottom
+// rows a macroblock hands to the row below travel through LDS (`bot`) between the
+// groups of one filter wave; band boundaries (another pair) go through memory under
+// the progress counters, workgroup boundaries through the write-through hand-off
+// buffer. Templates: picture type (P pictures carry no strong-filter code) and planes
+// (luma and chroma are independent given the edge codes and run as two kernels).
 // ------------------------------------------------------------------------
 #define DT_STRIDE 32 // luma tile: (x,y) at [(4+y)*32 + 16 + x], x,y in [-4,15]
 #define DC_STRIDE 32 // chroma tile (nv12): (x,y,c) at [(2+y)*32 + 16 + 2x + c], x,y in [-2,7]
-
-struct DbGroupLds {
-	uint8_t y[20 * DT_STRIDE];
-	uint8_t c[10 * DC_STRIDE];
-	uint8_t bot[2][4 * 16];  // final bottom 4 luma rows of macroblock mx (slot mx&1)
-	uint8_t botc[2][2 * 16]; // final bottom 2 chroma rows
-};
-
-// All filters are pure integer mask arithmetic (a comparison becomes the sign bit
-// of a difference, a select becomes an AND with 0 / -1): hipcc turns `c ? a : b`
-// chains into exec-mask branches, ~80 regions per step, which saturate the CU's
-// one scalar pipe that all 16 waves of the workgroup share.
-
-// normal filter (bS 1..3). tcw = tc0 values for bS 0..3 packed one per byte (byte 0 = 0).
-DEVI void filt_luma_n(int bs, int alpha, int beta, uint32_t tcw,
-		      int &p2, int &p1, int &p0, int &q0, int &q1, int &q2)
-{
-	const int tc0 = (int)((tcw >> (8 * bs)) & 0xffu);
-	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
-	m = (m >> 31) & nz_mask(bs);
-	const int mp = lt_mask(iabs(p2 - p0), beta), mq = lt_mask(iabs(q2 - q0), beta);
-	const int tc = tc0 - mp - mq;
-	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3) & m;
-	const int avg = (p0 + q0 + 1) >> 1;
-	const int dp1 = clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) & m & mp;
-	const int dq1 = clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) & m & mq;
-	p0 = clip255(p0 + delta);
-	q0 = clip255(q0 - delta);
-	p1 += dp1;
-	q1 += dq1;
-}
-
-// strong filter (bS 4, macroblock edges of intra pictures); bs is 0 or 4
-DEVI void filt_luma_s(int bs, int alpha, int beta, int p3, int &p2, int &p1, int &p0,
-		      int &q0, int &q1, int &q2, int q3)
-{
-	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
-	m = (m >> 31) & nz_mask(bs);
-	const int small = lt_mask(iabs(p0 - q0), (alpha >> 2) + 2);
-	const int sp = small & lt_mask(iabs(p2 - p0), beta), sq = small & lt_mask(iabs(q2 - q0), beta);
-	const int np0 = sel(sp, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, (2 * p1 + p0 + q1 + 2) >> 2);
-	const int np1 = sel(sp, (p2 + p1 + p0 + q0 + 2) >> 2, p1);
-	const int np2 = sel(sp, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2);
-	const int nq0 = sel(sq, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, (2 * q1 + q0 + p1 + 2) >> 2);
-	const int nq1 = sel(sq, (p0 + q0 + q1 + q2 + 2) >> 2, q1);
-	const int nq2 = sel(sq, (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3, q2);
-	p0 = sel(m, np0, p0); p1 = sel(m, np1, p1); p2 = sel(m, np2, p2);
-	q0 = sel(m, nq0, q0); q1 = sel(m, nq1, q1); q2 = sel(m, nq2, q2);
-}
-
-DEVI void filt_chroma_n(int bs, int alpha, int beta, uint32_t tcw, int p1, int &p0, int &q0, int q1)
-{
-	const int tc = (int)((tcw >> (8 * bs)) & 0xffu) + 1;
-	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
-	m = (m >> 31) & nz_mask(bs);
-	const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3) & m;
-	p0 = clip255(p0 + delta);
-	q0 = clip255(q0 - delta);
-}
-
-DEVI void filt_chroma_s(int bs, int alpha, int beta, int p1, int &p0, int &q0, int q1)
-{
-	int m = (iabs(p0 - q0) - alpha) & (iabs(p1 - p0) - beta) & (iabs(q1 - q0) - beta);
-	m = (m >> 31) & nz_mask(bs);
-	const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-	p0 = sel(m, np0, p0);
-	q0 = sel(m, nq0, q0);
-}
-
-// PL: planes this launch filters (1 = luma, 2 = chroma, 3 = both). Luma and chroma
-// are independent given the boundary strengths, so they run as two concurrent
-// wavefronts on different CUs; the luma step (the critical path) gets shorter.
-template <bool IDR, int PL>
-__global__ __launch_bounds__(64 * WF_WAVES) void k_deblock(Params p)
-{
-	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
-	__shared__ __attribute__((aligned(16))) DbGroupLds s_g[WF_WAVES * 4];
-	__shared__ int s_prog[MAX_ROWS];
-
-	__shared__ int s_ticket;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int g = lane >> 4, l = lane & 15;
-	// several workgroups share one unit: tickets hand out (unit, part) in start order,
-	// so the workgroup a part waits for has always started before it
-	const int NWG = p.wf_split;
-	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1); // region 1 = deblock (luma), 2 = chroma
-	if (threadIdx.x == 0)
-		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
-	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
-		s_prog[i] = 0;
-	__syncthreads();
-	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
-	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
-	int r0, r1;
-	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
-
-	DbGroupLds &L = s_g[wave * 4 + g];
-	const DbGroupLds &LU = s_g[wave * 4 + (g > 0 ? g - 1 : 0)]; // the row above, same wave
-	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
-	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
-	const int nbands = (r1 - r0 + 3) >> 2;
-	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG; // this workgroup's bands
-	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;  // [part]: macroblocks handed to part+1
-	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2; // error word lives in region 0
-	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
-	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
-	uint32_t xseen = 0; // wave-uniform cache of the producer part's progress
-	const uint32_t tcw_y = ((uint32_t)p.tc0_y[0] << 8) | ((uint32_t)p.tc0_y[1] << 16) | ((uint32_t)p.tc0_y[2] << 24);
-	const uint32_t tcw_c = ((uint32_t)p.tc0_c[0] << 8) | ((uint32_t)p.tc0_c[1] << 16) | ((uint32_t)p.tc0_c[2] << 24);
-
-	for (int band = b_lo + wave; band < b_hi; band += WF_WAVES) {
-		const int my = r0 + 4 * band + g;
-		const bool row_ok = my < r1;
-		const bool top_edge = my > r0; // picture top, or slice top with idc 2: not filtered
-		const bool xwave_top = g == 0 && band > b_lo;            // rows above: another wave of this workgroup (memory + LDS counter)
-		const bool xwg_band = band == b_lo && b_lo > 0;          // rows above: another workgroup (hand-off buffer)
-		const bool xwg_top = g == 0 && xwg_band;
-		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands; // this row feeds the next workgroup
-		uint64_t r_topx = 0;
-		const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
-		uint32_t nz_left = 0;
-		int mvl = 0;
-
-		// prefetch registers: data of the NEXT step's macroblock
-		u32x4 r_in = u32x4{ 0, 0, 0, 0 }, r_c = r_in, r_top = r_in;
-		MbInfo r_mi{}, r_mt{};
-		uint8_t r_nz = 0, r_nzt = 0;
-		bool r_top_ok = false;
-
-		// group 0's column at a given step is `step`; prefetch is called with the
-		// column of THIS group, so the band-boundary test uses g == 0's view
-		auto prefetch_step = [&](int step, bool block) {
-			const int nmx = step - 2 * g;
-			// the readiness test must be wave-uniform: evaluate it for group 0's column
-			const int mx0 = step;
-			const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
-			const int cmx = nact ? nmx : 0;
-			const size_t a = row_mb + cmx;
-			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
-			if (DO_Y)
-				r_in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
-			if (DO_C)
-				r_c = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
-			if (!IDR) {
-				r_mi = p.mbi[a];
-				r_nz = p.nnz[a * NNZ_PER_MB + l];
-				const size_t at = (top_edge && row_ok) ? a - p.mb_w : a; // inactive row groups stay in bounds
-				r_mt = p.mbi[at];
-				r_nzt = p.nnz[at * NNZ_PER_MB + l];
-			}
-			r_top_ok = true;
-			if (band > b_lo && mx0 < p.mb_w) {
-				const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w;
-				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
-				if (!ready && block) {
-					wait_progress(s_prog, 4 * band - 1, need);
-					ready = true;
-				}
-				if (ready)
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				r_top_ok = ready;
-			} else if (xwg_band && mx0 < p.mb_w) {
-				// the producer part publishes the count of macroblocks whose bottom rows are final
-				const uint32_t need = (uint32_t)mx0 + 1u;
-				if (xseen < need)
-					xseen = xload32(&xprog[wj - 1]);
-				if (xseen < need && block)
-					xseen = xwait(&xprog[wj - 1], xabort, xerr, need);
-				r_top_ok = xseen >= need;
-			}
-			if (xwave_top && r_top_ok && nact) {
-				if (DO_Y && l < 4)
-					r_top = *(const u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0);
-				else if (DO_C && l >= 4 && l < 6)
-					r_top = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) - 2 + l - 4) * p.cw + x0);
-			}
-			if (xwg_top && r_top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
-				r_topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
-		};
-
-		// stage the data of a step (already in the r_* registers) into the LDS tiles
-		auto stage = [&](int step) {
-			const int mx = step - 2 * g;
-			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
-			if (!act)
-				return;
-			if (mx > 0) { // previous macroblock's last 4 columns become the left neighbours
-				if (DO_Y)
-					*(uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 28);
-				if (DO_C && l < 8)
-					*(uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 28);
-			}
-			if (DO_Y)
-				*(u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16) = r_in;
-			if (DO_C && l < 8)
-				*(u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16) = r_c;
-			if (top_edge) {
-				if (g > 0) { // from the group above, through LDS
-					if (DO_Y && l < 4)
-						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 1] + l * 16);
-					else if (DO_C && l >= 4 && l < 6)
-						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 1] + (l - 4) * 16);
-				} else if (xwg_top) { // from the workgroup above: 8 luma + 4 chroma granules
-					if (DO_Y && l < 8)
-						*(uint64_t *)(L.y + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = r_topx;
-					else if (DO_C && l >= 8 && l < 12)
-						*(uint64_t *)(L.c + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = r_topx;
-				} else {     // from the wave above, through memory
-					if (DO_Y && l < 4)
-						*(u32x4 *)(L.y + l * DT_STRIDE + 16) = r_top;
-					else if (DO_C && l >= 4 && l < 6)
-						*(u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16) = r_top;
-				}
-			}
-		};
-
-		// prologue: data of step 0
-		prefetch_step(0, true);
-		WAVE_SYNC();
-		int pending_pub = -1; // macroblock column whose stores are in flight, per group
-		int pending_x = -1;   // macroblocks handed to the next workgroup, not yet published
-
-		for (int step = 0; step < p.mb_w + 6; step++) {
-			const int mx = step - 2 * g;
-			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
-			const bool left_edge = mx > 0;
-			const int x0 = mx * 16, y0 = my * 16;
-			// this step's records (prefetched) before the registers are reused
-			const MbInfo mi = r_mi, mt = r_mt;
-			const uint8_t nzb = r_nz, nzt_b = r_nzt;
-			if (!r_top_ok) // band boundary not ready when prefetched: fetch now, blocking
-				prefetch_step(step, true);
-			stage(step);
-			// issue the loads of the next step; they complete while this step computes
-			prefetch_step(step + 1, false);
-
-			uint32_t nz_cur = 0, nz_top = 0;
-			int mvc = 0, mvt = 0;
-			if (!IDR) {
-				const uint64_t bal_c = __ballot(act && nzb != 0), bal_t = __ballot(act && top_edge && nzt_b != 0);
-				nz_cur = (uint32_t)(bal_c >> (16 * g)) & 0xffffu;
-				nz_top = (uint32_t)(bal_t >> (16 * g)) & 0xffffu;
-				mvc = ((int)mi.mvx << 16) ^ ((int)mi.mvy & 0xffff);
-				mvt = ((int)mt.mvx << 16) ^ ((int)mt.mvy & 0xffff);
-			}
-			WAVE_SYNC();
-
-			// content fast path: when no macroblock of the wave has any non-zero boundary
-			// strength (skipped / zero-residual regions with uniform motion), both filter
-			// phases are the identity; staging, hand-off and write-back still run
-			bool work = act;
-			if (!IDR)
-				work = act && (nz_cur != 0 || (left_edge && ((nz_left & 0x8888u) != 0 || mvc != mvl)) ||
-					       (top_edge && ((nz_top & 0xf000u) != 0 || mvc != mvt)));
-			const bool any_work = __any(work);
-
-			const int k = l >> 2; // 4-sample segment of this lane's line
-			if (act && any_work) {
-				// ---- vertical edges: lane = sample row l ----
-				int bs[4];
-				if (IDR) {
-					bs[0] = left_edge ? 4 : 0;
-					bs[1] = bs[2] = bs[3] = 3;
-				} else {
-					const int nzb0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
-					bs[0] = (2 * nzb0 + ((1 - nzb0) & (nz_mask(mvc ^ mvl) & 1))) & -(int)left_edge;
-#pragma unroll
-					for (int e = 1; e < 4; e++)
-						bs[e] = 2 * (int)(((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1u);
-				}
-				if (DO_Y) {
-				int px[20];
-				const uint32_t *rowp = (const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
-#pragma unroll
-				for (int w = 0; w < 5; w++) {
-					const uint32_t v = rowp[w];
-					px[4 * w] = v & 0xff;
-					px[4 * w + 1] = (v >> 8) & 0xff;
-					px[4 * w + 2] = (v >> 16) & 0xff;
-					px[4 * w + 3] = v >> 24;
-				}
-#pragma unroll
-				for (int e = 0; e < 4; e++) {
-					const int q = 4 + 4 * e;
-					if (IDR && e == 0)
-						filt_luma_s(bs[0], p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
-							    px[q], px[q + 1], px[q + 2], px[q + 3]);
-					else
-						filt_luma_n(bs[e], p.alpha_y, p.beta_y, tcw_y,
-							    px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
-				}
-				uint32_t *roww = (uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
-#pragma unroll
-				for (int w = 0; w < 5; w++)
-					roww[w] = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
-				}
-				// chroma: lane = (plane c = l>>3, chroma row r = l&7); edges at chroma x = 0 and 4
-				if (DO_C) {
-					const int c = l >> 3, r = l & 7, ks = r >> 1;
-					int bsc0, bsc2;
-					if (IDR) {
-						bsc0 = left_edge ? 4 : 0;
-						bsc2 = 3;
-					} else {
-						const int nzc0 = (int)(((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1u);
-						bsc0 = (2 * nzc0 + ((1 - nzc0) & (nz_mask(mvc ^ mvl) & 1))) & -(int)left_edge;
-						bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
-					}
-					uint8_t *cp = L.c + (2 + r) * DC_STRIDE + 16 + c;
-					int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
-					int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
-					if (IDR)
-						filt_chroma_s(bsc0, p.alpha_c, p.beta_c, a1, a0, b0, b1);
-					else
-						filt_chroma_n(bsc0, p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
-					filt_chroma_n(bsc2, p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
-					cp[-2] = (uint8_t)a0;
-					cp[0] = (uint8_t)b0;
-					cp[6] = (uint8_t)c0;
-					cp[8] = (uint8_t)d0;
-				}
-			}
-			WAVE_SYNC();
-			if (act && any_work) {
-				// ---- horizontal edges: lane = sample column l ----
-				int bs[4];
-				if (IDR) {
-					bs[0] = top_edge ? 4 : 0;
-					bs[1] = bs[2] = bs[3] = 3;
-				} else {
-					const int nzb0 = (int)(((nz_cur >> k) | (nz_top >> (12 + k))) & 1u);
-					bs[0] = (2 * nzb0 + ((1 - nzb0) & (nz_mask(mvc ^ mvt) & 1))) & -(int)top_edge;
-#pragma unroll
-					for (int e = 1; e < 4; e++)
-						bs[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
-				}
-				if (DO_Y) {
-				int py[20];
-				uint8_t *colp = L.y + 16 + l;
-#pragma unroll
-				for (int r = 0; r < 20; r++)
-					py[r] = colp[r * DT_STRIDE];
-#pragma unroll
-				for (int e = 0; e < 4; e++) {
-					const int q = 4 + 4 * e;
-					if (IDR && e == 0)
-						filt_luma_s(bs[0], p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
-							    py[q], py[q + 1], py[q + 2], py[q + 3]);
-					else
-						filt_luma_n(bs[e], p.alpha_y, p.beta_y, tcw_y,
-							    py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
-				}
-#pragma unroll
-				for (int r = 1; r < 19; r++)
-					colp[r * DT_STRIDE] = (uint8_t)py[r];
-				}
-				// chroma: lane = byte column l of the nv12 row (plane l&1, chroma x = l>>1)
-				if (DO_C) {
-					uint8_t *cp = L.c + 16 + l;
-					int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
-					int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
-					if (IDR)
-						filt_chroma_s(bs[0], p.alpha_c, p.beta_c, a1, a0, b0, b1);
-					else
-						filt_chroma_n(bs[0], p.alpha_c, p.beta_c, tcw_c, a1, a0, b0, b1);
-					filt_chroma_n(bs[2], p.alpha_c, p.beta_c, tcw_c, c1, c0, d0, d1);
-					cp[DC_STRIDE] = (uint8_t)a0;
-					cp[2 * DC_STRIDE] = (uint8_t)b0;
-					cp[5 * DC_STRIDE] = (uint8_t)c0;
-					cp[6 * DC_STRIDE] = (uint8_t)d0;
-				}
-			}
-			WAVE_SYNC();
-			// everything older (last step's stores, this step's prefetch) has long completed
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (pending_pub >= 0 && l == 0)
-				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			pending_pub = -1;
-			if (b_hi < nbands && band == b_hi - 1) { // wave-uniform: this band feeds the next workgroup
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through payload stores have landed
-				if (is_xprod && l == 0 && pending_x >= 0)
-					xstore32(&xprog[wj], (uint32_t)pending_x);
-				pending_x = -1;
-			}
-			if (act) {
-				// ---- hand the bottom rows to the row below (LDS), then write back ----
-				if (DO_Y && l >= 12) {
-					*(u32x4 *)(L.bot[mx & 1] + (l - 12) * 16) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
-					if (left_edge) // columns 12..15 of the previous macroblock are final only now
-						*(uint32_t *)(L.bot[(mx - 1) & 1] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
-				} else if (DO_C && l >= 6 && l < 8) {
-					*(u32x4 *)(L.botc[mx & 1] + (l - 6) * 16) = *(const u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16);
-					if (left_edge)
-						*(uint32_t *)(L.botc[(mx - 1) & 1] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
-				}
-				// a row that feeds another workgroup leaves its last 4 luma / 2 chroma rows to
-				// that workgroup (single writer: it stores them after filtering its top edge)
-				if (DO_Y && !(is_xprod && l >= 12)) {
-					*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y + (4 + l) * DT_STRIDE + 16);
-					if (left_edge)
-						*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y + (4 + l) * DT_STRIDE + 12);
-				}
-				if (DO_C && l < 8 && !(is_xprod && l >= 6)) {
-					*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c + (2 + l) * DC_STRIDE + 16);
-					if (left_edge)
-						*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c + (2 + l) * DC_STRIDE + 12);
-				}
-				if (top_edge) {
-					if (DO_Y && l < 4)
-						*(u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0) = *(const u32x4 *)(L.y + l * DT_STRIDE + 16);
-					else if (DO_C && l >= 4 && l < 6)
-						*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c + (l - 4) * DC_STRIDE + 16);
-				}
-				nz_left = nz_cur;
-				mvl = mvc;
-				pending_pub = mx;
-			}
-			WAVE_SYNC();
-			if (is_xprod && act) {
-				// bottom rows of macroblock mx-1 are final now (its columns 12..15 were just
-				// patched); the last macroblock of the row is final at once
-				const bool my_gran = (DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES);
-				if (left_edge && my_gran) {
-					const uint8_t *src = l < 8 ? L.bot[(mx - 1) & 1] + (l >> 1) * 16 + (l & 1) * 8
-								   : L.botc[(mx - 1) & 1] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
-					xstore64(hb_out + (size_t)(mx - 1) * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
-				}
-				if (mx == p.mb_w - 1 && my_gran) {
-					const uint8_t *src = l < 8 ? L.bot[mx & 1] + (l >> 1) * 16 + (l & 1) * 8
-								   : L.botc[mx & 1] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
-					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
-				}
-				pending_x = mx == p.mb_w - 1 ? p.mb_w : mx;
-			}
-		}
-		// drain: publish the last macroblock of every row of the band
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		if (pending_pub >= 0 && l == 0)
-			__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (b_hi < nbands && band == b_hi - 1) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (is_xprod && l == 0 && pending_x >= 0)
-				xstore32(&xprog[wj], (uint32_t)pending_x);
-		}
-	}
-}
-
-// ------------------------------------------------------------------------
 // #define DB2_TIMING 1
-// k_deblock2: the same wavefront with SPECIALISED WAVES. One wave's step used to be
-// ~1400 instructions of which ~550 filter samples; the rest stages tiles, derives
-// boundary strengths, writes results back and hands rows on. A wave alone on its
-// SIMD issues one instruction per ~4.5 cycles whatever their dependencies, so the
-// step time is the instruction count. Here every band is served by a PAIR:
-//   filter wave  per step: copy left columns / top rows inside LDS, 4 vertical +
-//                4 horizontal edges on the staged tile, save the bottom rows (`bot`)
-//   mover wave   one step ahead: loads of step t+2 in flight, stages step t+1
-//                (samples + packed boundary strengths) into the next of 3 tile
-//                slots, and behind: writes step t-1 back to memory, feeds the next
-//                workgroup, publishes progress
-// They meet only through two monotonic LDS counters (staged / filtered).
-// ------------------------------------------------------------------------
 // Edge codes: the mover turns every boundary strength into one byte, 0x80 | tc0 (0 = edge
 // not filtered), so the filter wave spends two bit-field extracts on it. |a-b|+c on byte
 // values is one v_sad_u8; thresholds go in negated so the sign bit is the comparison.
@@ -1092,7 +672,7 @@ DEVI void lds_wait_ge(const int *word, int need, uint32_t *err)
 	// bounded like every spin here: a lost partner ends in -EIO at collect, not in a hung grid
 	for (int spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spins++) {
 		if (spins > (1 << 22)) {
-			__hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			break;
 		}
 		__builtin_amdgcn_s_sleep(0);
@@ -1150,7 +730,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
 	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
-	uint32_t *xabort = sync + 1, *xerr = p.wf_sync + 2;
+	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
 	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
 	uint32_t xseen = 0;
@@ -1562,33 +1142,16 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 int Launch::deblock(const Params &p, void *stream, int planes)
 {
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
-	const unsigned pad_lds = 12 * 1024; // 74 KiB static + 12 KiB > 80 KiB: one workgroup per CU
 	hipStream_t s = (hipStream_t)stream;
-	static int version = 0;
-	if (!version) {
-		const char *e = getenv("CEDAR_DEBLOCK_V");
-		version = e ? atoi(e) : 2;
-	}
-	if (version == 2) { // specialised filter / mover waves (110 KiB LDS: one workgroup per CU by itself)
-		if (p.is_idr) {
-			if (planes == 1) hipLaunchKernelGGL((k_deblock2<true, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
-			else if (planes == 2) hipLaunchKernelGGL((k_deblock2<true, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
-			else hipLaunchKernelGGL((k_deblock2<true, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
-		} else {
-			if (planes == 1) hipLaunchKernelGGL((k_deblock2<false, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
-			else if (planes == 2) hipLaunchKernelGGL((k_deblock2<false, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
-			else hipLaunchKernelGGL((k_deblock2<false, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
-		}
-		return (int)hipGetLastError();
-	}
+	// 116 KiB of static LDS: one workgroup per CU by construction
 	if (p.is_idr) {
-		if (planes == 1) hipLaunchKernelGGL((k_deblock<true, 1>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
-		else if (planes == 2) hipLaunchKernelGGL((k_deblock<true, 2>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
-		else hipLaunchKernelGGL((k_deblock<true, 3>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+		if (planes == 1) hipLaunchKernelGGL((k_deblock2<true, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
+		else if (planes == 2) hipLaunchKernelGGL((k_deblock2<true, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
+		else hipLaunchKernelGGL((k_deblock2<true, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
 	} else {
-		if (planes == 1) hipLaunchKernelGGL((k_deblock<false, 1>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
-		else if (planes == 2) hipLaunchKernelGGL((k_deblock<false, 2>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
-		else hipLaunchKernelGGL((k_deblock<false, 3>), grid, dim3(64 * WF_WAVES), pad_lds, s, p);
+		if (planes == 1) hipLaunchKernelGGL((k_deblock2<false, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
+		else if (planes == 2) hipLaunchKernelGGL((k_deblock2<false, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
+		else hipLaunchKernelGGL((k_deblock2<false, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
 	}
 	return (int)hipGetLastError();
 }

@@ -131,7 +131,8 @@ struct InFlight {
 	hipEvent_t done_main = nullptr, done_ent = nullptr;
 	SliceHdr *h_hdr = nullptr;   // pinned staging for the per-frame slice headers
 	uint32_t *h_prefix = nullptr;
-	uint32_t *h_wf_err = nullptr; // pinned copy of the wavefront kernels' error word
+	uint32_t *h_wf_err = nullptr; // pinned word the wavefront kernels write an error code to
+	uint32_t *d_wf_err = nullptr; // the same word as the device sees it
 	Timing tm;
 };
 
@@ -538,8 +539,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * ext.slice_num, hipHostMallocDefault));
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocDefault));
-		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_wf_err, sizeof(uint32_t), hipHostMallocDefault));
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_wf_err, sizeof(uint32_t), hipHostMallocMapped));
 		*e->fl[i].h_wf_err = 0;
+		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].d_wf_err, e->fl[i].h_wf_err, 0));
 	}
 	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
 	P.plane_y_stride = (int64_t)plane_y;
@@ -754,15 +756,22 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, e->s_main));
 		}
 	}
-	if (e->in_ptrs_dirty) {
+	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
+		P.in_luma = P.in_chroma = nullptr;
+		for (int s = 0; s < S; s++) {
+			P.in_k[s] = e->h_in_ptrs[s];
+			P.in_k[IN_K_STREAMS + s] = e->h_in_ptrs[S + s];
+		}
+	} else if (e->in_ptrs_dirty) {
 		HIP_TRY(e, hipMemcpyAsync((void *)e->d_in_ptrs, e->h_in_ptrs.data(), sizeof(void *) * 2 * S,
 					  hipMemcpyHostToDevice, e->s_main));
 		e->in_ptrs_dirty = false;
 	}
 	if (any_host)
 		HIP_TRY(e, hipEventRecord(e->ev_input, e->s_main));
-	if (e->wf_split > 1) // ticket / abort / progress words of both wavefront kernels start at zero
-		HIP_TRY(e, hipMemsetAsync(e->d_wf_sync, 0, sizeof(uint32_t) * 3 * WF_SYNC_WORDS, e->s_main));
+	// (k_input also zeroes the ticket / abort / progress words of the wavefront kernels)
+	*f.h_wf_err = 0;
+	P.wf_err = f.d_wf_err;
 	if (Launch::input(P, e->s_main))
 		return fail(e, -EIO, "k_input launch failed");
 	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, e->s_main);
@@ -828,9 +837,6 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		return fail(e, -EIO, "k_deblock launch failed");
 	}
 	tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
-	*f.h_wf_err = 0;
-	if (e->wf_split > 1)
-		HIP_TRY(e, hipMemcpyAsync(f.h_wf_err, e->d_wf_sync + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->s_main));
 	// the frame is complete when both streams are (collect waits for both events)
 	HIP_TRY(e, hipEventRecord(f.done_main, e->s_main));
 

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 kernel trace CSV: per-frame busy/idle on the device (development tool)."""
+import csv, sys, collections
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
+rows.sort()
+# steady state: last 40% of the trace
+t0 = rows[int(len(rows) * 0.6)][0]
+rows = [r for r in rows if r[0] >= t0]
+span = rows[-1][1] - rows[0][0]
+# union of busy intervals
+busy = 0; cur_s, cur_e = rows[0][0], rows[0][1]
+for s, e, *_ in rows[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s; cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+print("span %.3f ms, device busy %.3f ms (%.1f%%), idle %.3f ms" % (span / 1e6, busy / 1e6, 100.0 * busy / span, (span - busy) / 1e6))
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n, q in rows:
+    k = n.split("(")[0][:60]
+    agg[k][0] += e - s; agg[k][1] += 1
+for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+    print("%-62s n=%5d total %.3f ms avg %.1f us" % (k, c, t / 1e6, t / c / 1e3))
+# print one P-frame worth of launches in order
+names = [r for r in rows if "k_input" in r[2]]
+if len(names) > 3:
+    a, b = names[2][0], names[3][0]
+    print("one frame (%.3f ms):" % ((b - a) / 1e6))
+    for s, e, n, q in rows:
+        if a <= s < b:
+            print("  +%8.1f us  %7.1f us  q=%s  %s" % ((s - a) / 1e3, (e - s) / 1e3, q, n.split("(")[0][:50]))
