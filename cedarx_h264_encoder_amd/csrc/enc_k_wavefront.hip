@@ -552,23 +552,6 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 	}
 }
 
-int Launch::intra_recon(const Params &p, void *stream)
-{
-	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
-	static int waves = 0;
-	if (!waves) {
-		const char *e = getenv("CEDAR_INTRA_WAVES");
-		waves = e ? atoi(e) : 8;
-	}
-	// wavefront workgroups are throughput-bound on their CU: ask for enough (unused)
-	// dynamic LDS that two of them can never share one CU (160 KiB per CU)
-	if (waves == 16)
-		hipLaunchKernelGGL(k_intra_recon<16>, grid, dim3(64 * 16), 0, (hipStream_t)stream, p);
-	else
-		hipLaunchKernelGGL(k_intra_recon<8>, grid, dim3(64 * 8), 40 * 1024, (hipStream_t)stream, p);
-	return (int)hipGetLastError();
-}
-
 // ------------------------------------------------------------------------
 // k_deblock2: in-loop deblocking as a macroblock wavefront. A band of 4 macroblock
 // rows is swept left to right; lane group g = lane>>4 works on row band+g, two
@@ -1139,6 +1122,616 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 	}
 }
 
+// ------------------------------------------------------------------------
+// k_intra_recon2: the intra wavefront with specialised waves, as k_deblock2. A step of
+// the single-wave kernel cost ~37000 cycles: ~3700 waiting for its own loads, 20500
+// Intra4x4 chain, 1700 Intra16x16, 10000 chroma, ~1000 write-back and fences. Chroma
+// prediction only needs chroma neighbours and the loads / stores need nobody, so a band
+// is served by a TRIPLE of waves:
+//   luma wave    Intra4x4 / Intra16x16 chain on its LDS tile, levels and nnz to memory
+//   chroma wave  the chroma blocks on its own tile (same step, other SIMD)
+//   mover wave   loads of step t+3 in flight, stages step t+1 (source samples, record,
+//                packed 4x4 modes, rows above for group 0); writes step t-1 back
+// The step is then the luma chain alone. Bottom rows travel between the groups of one
+// compute wave through LDS rings (boty / botc); band and workgroup boundaries as before.
+// ------------------------------------------------------------------------
+constexpr int IR_TRIPLES = 3;
+
+struct __attribute__((aligned(16))) Ir2GroupLds {
+	uint8_t t[17 * IT_STRIDE];  // luma wave's tile (persists: column 15 is the next left neighbour)
+	uint8_t c[9 * IC_STRIDE];   // chroma wave's tile
+	uint8_t srcy[3][256];       // staged source, ring by step
+	uint8_t srcc[3][128];
+	uint8_t outy[3][256];       // finished reconstruction for the mover
+	uint8_t outc[3][128];
+	uint8_t boty[4][16];        // last luma row of macroblock mx (slot mx&3) for the group below
+	uint8_t botc[4][16];        // last chroma row
+	uint8_t topy[3][32];        // group 0 only, laid out as tile row 0: [7] x=-1, [8..23], [24..27] x=16..19
+	uint8_t topc[3][32];        // [6..7] pair x=-1, [8..23]
+	uint32_t info[3][4];        // [0..1] MbInfo, [2..3] the 16 Intra4x4 modes, one nibble each
+	int cbp_y[3], cbp_c[3];
+	int dc[16], dcl[16], cdc[8], cdl[8];
+};
+
+__global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
+{
+	__shared__ Ir2GroupLds s_g[IR_TRIPLES * 4];
+	__shared__ int s_prog[MAX_ROWS];
+	__shared__ int s_staged[IR_TRIPLES], s_done_y[IR_TRIPLES], s_done_c[IR_TRIPLES];
+	__shared__ int s_ticket;
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// waves land on SIMD wave%4: the three waves of a triple sit on three different SIMDs
+	const int role = wave / IR_TRIPLES, trip = wave % IR_TRIPLES; // 0 luma, 1 chroma, 2 mover
+	const int g = lane >> 4, l = lane & 15;
+	const int NWG = p.wf_split;
+	uint32_t *sync = p.wf_sync; // region 0
+	if (threadIdx.x == 0)
+		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
+	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
+		s_prog[i] = 0;
+	if (threadIdx.x < IR_TRIPLES) {
+		s_staged[threadIdx.x] = 0;
+		s_done_y[threadIdx.x] = 0;
+		s_done_c[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
+	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
+	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
+	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
+	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint32_t xseen = 0;
+
+	Ir2GroupLds &L = s_g[trip * 4 + g];
+	const Ir2GroupLds &LU = s_g[trip * 4 + (g > 0 ? g - 1 : 0)];
+	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
+	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
+	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
+	const int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
+	const int nbands = (r1 - r0 + 3) >> 2;
+	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
+	const int nsteps = p.mb_w + 6;
+
+	// lane constants of the Intra4x4 path (lane = sample of a 4x4 block)
+	const int pi = l >> 2, pj = l & 3;
+	const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
+	const int rpos = 4 * kv + kh; // raster coefficient position held by this lane
+	const int pclass = kPosClass[rpos];
+	int zz = 0;
+#pragma unroll
+	for (int z = 0; z < 16; z++)
+		zz = kZigzag[z] == rpos ? z : zz;
+	uint32_t ptab0 = 0, ptab1 = 0, ptab2 = 0;
+	if (role == 0) {
+#pragma unroll
+		for (int m = 0; m < 4; m++) {
+			ptab0 |= (uint32_t)p.pred4_tab[m * 16 + l] << (8 * m);
+			ptab1 |= (uint32_t)p.pred4_tab[(4 + m) * 16 + l] << (8 * m);
+		}
+		ptab2 = p.pred4_tab[8 * 16 + l];
+	}
+	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
+	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
+	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
+
+	int iter = 0;
+	for (int band = b_lo + trip; band < b_hi; band += IR_TRIPLES, iter++) {
+		const int base = iter * (nsteps + 2);
+		const int my = r0 + 4 * band + g;
+		const bool row_ok = my < r1;
+		const bool top_mb = my > r0;
+		const bool xwg_band = band == b_lo && b_lo > 0;
+		const bool xwg_top = g == 0 && xwg_band;
+		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands;
+
+		if (role == 0) {
+			// ============================ luma wave ============================
+			for (int t = 0; t < nsteps; t++) {
+				const int mx = t - 2 * g;
+				const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+				const bool left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
+				const int slot = t % 3;
+				const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
+				lds_wait_ge(&s_staged[trip], base + t + 1, xerr);
+				const uint32_t miw = L.info[slot][0];
+				const uint64_t modes64 = (uint64_t)L.info[slot][2] | (uint64_t)L.info[slot][3] << 32;
+				const int mb_type = (int)(int8_t)(miw & 0xff), i16_mode = (int)((miw >> 8) & 0xff);
+				const uint8_t *SY = L.srcy[slot];
+				if (act) {
+					if (left_mb) // left neighbours = last column of the previous macroblock
+						L.t[(1 + l) * IT_STRIDE + 7] = L.t[(1 + l) * IT_STRIDE + 23];
+					if (top_mb) {
+						if (g == 0) { // staged by the mover
+							if (l == 0)
+								*(u32x4 *)(L.t + 8) = *(const u32x4 *)(L.topy[slot] + 8);
+							else if (l == 1 && tr_mb)
+								*(uint32_t *)(L.t + 24) = *(const uint32_t *)(L.topy[slot] + 24);
+							else if (l == 2 && left_mb)
+								L.t[7] = L.topy[slot][7];
+						} else { // the group above finished these two, one and three steps ago
+							if (l == 0)
+								*(u32x4 *)(L.t + 8) = *(const u32x4 *)LU.boty[mx & 3];
+							else if (l == 1 && tr_mb)
+								*(uint32_t *)(L.t + 24) = *(const uint32_t *)LU.boty[(mx + 1) & 3];
+							else if (l == 2 && left_mb)
+								L.t[7] = LU.boty[(mx - 1) & 3][15];
+						}
+					}
+				}
+				WAVE_SYNC();
+
+				int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
+				int16_t *cf_lane = cf + COEF_LUMA + zz;
+				uint8_t *nnz_mb = p.nnz + mbaddr * NNZ_PER_MB;
+				const bool is4 = act && mb_type == MB_I4x4, is16 = act && mb_type == MB_I16x16;
+				int cbp = 0;
+
+				// ---- Intra 4x4: serial over the 16 blocks, lane = sample ----
+				if (__any(is4)) {
+					if (is4)
+						cf[COEF_DC16 + l] = 0;
+					for (int idx = 0; idx < 16; idx++) {
+						const int bx = blk_x(idx), by = blk_y(idx);
+						int level = 0;
+						if (is4) {
+							const int tx = 8 + 4 * bx, ty = 1 + 4 * by;
+							bool ht, hl, htr;
+							blk4_avail(idx, top_mb, left_mb, tr_mb, ht, hl, htr);
+							const int mode = (int)((modes64 >> (4 * idx)) & 15u);
+							const uint8_t *T = L.t;
+							const int tkmax = htr ? 7 : 3;
+							auto eaddr = [&](int k) {
+								k = max(1, min(13, k));
+								const int row = ty - 1 + max(0, 5 - k);
+								const int col = tx - 1 + max(0, min(k - 6, tkmax) + 1);
+								return row * IT_STRIDE + col;
+							};
+							const uint32_t pw = mode < 4 ? ptab0 : mode < 8 ? ptab1 : ptab2;
+							const int ent = (int)((pw >> (8 * (mode & 3))) & 0xffu);
+							const int kind = ent >> 4, k = ent & 15;
+							const int ea = T[eaddr(k - 1)], eb = T[eaddr(k)], ec = T[eaddr(k + 1)];
+							int st_ = 0, sl_ = 0;
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								st_ += T[(ty - 1) * IT_STRIDE + tx + q];
+								sl_ += T[(ty + q) * IT_STRIDE + tx - 1];
+							}
+							const int dcv = (ht && hl) ? (st_ + sl_ + 4) >> 3 : hl ? (sl_ + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
+							const int pv = sel(nz_mask(kind ^ 3),
+									   sel(nz_mask(kind ^ 2), sel(nz_mask(kind ^ 1), eb, (eb + ec + 1) >> 1),
+									       (ea + 2 * eb + ec + 2) >> 2),
+									   dcv);
+							const int res = (int)SY[(4 * by + pi) * 16 + 4 * bx + pj] - pv;
+							const int w = fdct_lanes(res, ci, cj);
+							level = quant1(w, my_mf, f_intra, p.qbits);
+							cf_lane[idx * 16] = (int16_t)level;
+							const int d = (level * my_dv) << p.qshift;
+							const int r = idct_lanes(d, ci, cj);
+							L.t[(ty + pi) * IT_STRIDE + tx + pj] = (uint8_t)clip255(pv + r);
+						}
+						const uint64_t bal = __ballot(is4 && level != 0);
+						const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
+						if (is4) {
+							if (l == 0)
+								nnz_mb[bx + 4 * by] = (uint8_t)nn;
+							cbp |= nn ? (1 << (idx >> 2)) : 0;
+						}
+						WAVE_SYNC();
+					}
+				}
+
+				// ---- Intra 16x16: lane = 4x4 block (coding order) ----
+				if (__any(is16)) {
+					const int bx = blk_x(l), by = blk_y(l);
+					const uint8_t *T = L.t;
+					int d[16];
+					int nn = 0, dcv = 128, pa = 0, pb = 0, pc = 0;
+					auto pred16 = [&](int x, int y) {
+						return i16_mode == 0 ? (int)T[8 + x]
+						     : i16_mode == 1 ? (int)T[(1 + y) * IT_STRIDE + 7]
+						     : i16_mode == 2 ? dcv
+						     : clip255((pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5);
+					};
+					if (is16) {
+						int dcsum = 0, H = 0, V = 0;
+						for (int k = 0; k < 16; k++)
+							dcsum += (top_mb ? T[8 + k] : 0) + (left_mb ? T[(1 + k) * IT_STRIDE + 7] : 0);
+						dcv = (top_mb && left_mb) ? (dcsum + 16) >> 5 : (top_mb || left_mb) ? (dcsum + 8) >> 4 : 128;
+						for (int k = 0; k < 8; k++) {
+							H += (k + 1) * ((int)T[8 + 8 + k] - (int)T[8 + 6 - k]);
+							V += (k + 1) * ((int)T[(1 + 8 + k) * IT_STRIDE + 7] - (int)T[(1 + 6 - k) * IT_STRIDE + 7]);
+						}
+						pa = 16 * ((int)T[16 * IT_STRIDE + 7] + (int)T[8 + 15]);
+						pb = (5 * H + 32) >> 6;
+						pc = (5 * V + 32) >> 6;
+						int w[16];
+						{
+							int res[16];
+#pragma unroll
+							for (int i = 0; i < 16; i++) {
+								const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+								res[i] = (int)SY[y * 16 + x] - pred16(x, y);
+							}
+							fdct4x4(res, w);
+						}
+						L.dc[bx + 4 * by] = w[0];
+						cf[COEF_LUMA + l * 16] = 0;
+#pragma unroll
+						for (int i = 1; i < 16; i++) {
+							const int r = kZigzag[i], c = kPosClass[r];
+							const int lq = quant1(w[r], p.mf[c], f_intra, p.qbits);
+							cf[COEF_LUMA + l * 16 + i] = (int16_t)lq;
+							nn += lq != 0;
+							d[r] = (lq * p.dv[c]) << p.qshift;
+						}
+					}
+					WAVE_SYNC();
+					if (is16) { // forward Hadamard output (i,j) = raster lane
+						const int i = l >> 2, j = l & 3;
+						int s = 0;
+#pragma unroll
+						for (int a = 0; a < 4; a++)
+#pragma unroll
+							for (int b = 0; b < 4; b++)
+								s += hsign(i, a) * hsign(j, b) * L.dc[4 * a + b];
+						L.dcl[l] = quant1((s + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
+					}
+					WAVE_SYNC();
+					if (is16) {
+						cf[COEF_DC16 + l] = (int16_t)L.dcl[kZigzag[l]];
+						int s = 0;
+#pragma unroll
+						for (int a = 0; a < 4; a++)
+#pragma unroll
+							for (int b = 0; b < 4; b++)
+								s += hsign(by, a) * hsign(bx, b) * L.dcl[4 * a + b];
+						const int ls = 16 * p.dv[0];
+						d[0] = p.qp >= 36 ? (s * ls) << (p.qshift - 6) : (s * ls + (1 << (5 - p.qshift))) >> (6 - p.qshift);
+						int pred[16], out[16];
+#pragma unroll
+						for (int i = 0; i < 16; i++)
+							pred[i] = pred16(4 * bx + (i & 3), 4 * by + (i >> 2));
+						idct4x4_add(d, pred, out);
+						// all predictions of the group are read before any lane writes the tile
+						__builtin_amdgcn_wave_barrier();
+#pragma unroll
+						for (int k = 0; k < 16; k++)
+							L.t[(1 + 4 * by + (k >> 2)) * IT_STRIDE + 8 + 4 * bx + (k & 3)] = (uint8_t)out[k];
+						nnz_mb[bx + 4 * by] = (uint8_t)nn;
+					}
+					const uint64_t bal = __ballot(is16 && nn != 0);
+					if (is16)
+						cbp = ((uint32_t)(bal >> (16 * g)) & 0xffffu) ? 15 : 0;
+				}
+				WAVE_SYNC();
+				if (act) { // hand the macroblock to the mover and its last row to the group below
+					*(u32x4 *)(L.outy[slot] + l * 16) = *(const u32x4 *)(L.t + (1 + l) * IT_STRIDE + 8);
+					if (l == 15)
+						*(u32x4 *)L.boty[mx & 3] = *(const u32x4 *)(L.t + 16 * IT_STRIDE + 8);
+					if (l == 0)
+						L.cbp_y[slot] = cbp;
+				}
+				lds_signal(&s_done_y[trip], base + t + 1, lane);
+			}
+			continue;
+		}
+
+		if (role == 1) {
+			// =========================== chroma wave ===========================
+			for (int t = 0; t < nsteps; t++) {
+				const int mx = t - 2 * g;
+				const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+				const bool left_mb = mx > 0;
+				const int slot = t % 3;
+				const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
+				lds_wait_ge(&s_staged[trip], base + t + 1, xerr);
+				const int chroma_mode = (int)((L.info[slot][0] >> 16) & 0xff);
+				const uint8_t *SC = L.srcc[slot];
+				if (act) {
+					if (left_mb && l < 8)
+						*(uint16_t *)(L.c + (1 + l) * IC_STRIDE + 6) = *(const uint16_t *)(L.c + (1 + l) * IC_STRIDE + 22);
+					if (top_mb) {
+						const uint8_t *tp = g == 0 ? L.topc[slot] + 8 : LU.botc[mx & 3];
+						if (l == 8)
+							*(u32x4 *)(L.c + 8) = *(const u32x4 *)tp;
+						else if (l == 9 && left_mb)
+							*(uint16_t *)(L.c + 6) = g == 0 ? *(const uint16_t *)(L.topc[slot] + 6)
+											: *(const uint16_t *)(LU.botc[(mx - 1) & 3] + 14);
+					}
+				}
+				WAVE_SYNC();
+				int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
+				int cnn = 0, cdcnz = 0;
+				const bool is_c = act && l < 8;
+				const int c = l >> 2, blk = l & 3;
+				const int bx = blk & 1, by = blk >> 1;
+				const uint8_t *T = L.c;
+				int cd[16];
+				int dcv = 128, pa = 0, pb = 0, pc = 0;
+#define CT(xx, yy) T[(1 + (yy)) * IC_STRIDE + 8 + 2 * (xx) + c]
+				auto predc = [&](int x, int y) {
+					return chroma_mode == 0 ? dcv
+					     : chroma_mode == 1 ? (int)CT(-1, y)
+					     : chroma_mode == 2 ? (int)CT(x, -1)
+					     : clip255((pa + pb * (x - 3) + pc * (y - 3) + 16) >> 5);
+				};
+				if (is_c) {
+					int stp = 0, slf = 0, H = 0, V = 0;
+					for (int k = 0; k < 4; k++) {
+						stp += CT(4 * bx + k, -1);
+						slf += CT(-1, 4 * by + k);
+						H += (k + 1) * ((int)CT(4 + k, -1) - (int)CT(2 - k, -1));
+						V += (k + 1) * ((int)CT(-1, 4 + k) - (int)CT(-1, 2 - k));
+					}
+					bool use_t = top_mb, use_l = left_mb;
+					if (bx == 1 && by == 0 && top_mb)
+						use_l = false;
+					if (bx == 0 && by == 1 && left_mb)
+						use_t = false;
+					dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
+					pa = 16 * ((int)CT(-1, 7) + (int)CT(7, -1));
+					pb = (34 * H + 32) >> 6;
+					pc = (34 * V + 32) >> 6;
+					int w[16];
+					{
+						int res[16];
+#pragma unroll
+						for (int i = 0; i < 16; i++) {
+							const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
+							res[i] = (int)SC[y * 16 + 2 * x + c] - predc(x, y);
+						}
+						fdct4x4(res, w);
+					}
+					L.cdc[l] = w[0];
+					cf[COEF_CAC + (4 * c + blk) * 16] = 0;
+#pragma unroll
+					for (int i = 1; i < 16; i++) {
+						const int r = kZigzag[i], cl = kPosClass[r];
+						const int lq = quant1(w[r], p.mfc[cl], f_intra_c, p.qbits_c);
+						cf[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)lq;
+						cnn += lq != 0;
+						cd[r] = (lq * p.dvc[cl]) << p.qshift_c;
+					}
+				}
+				WAVE_SYNC();
+				if (is_c) {
+					const int *dcs = L.cdc + 4 * c;
+					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
+					const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
+					const int lq = quant1(hd, p.mfc[0], 2 * f_intra_c, p.qbits_c + 1);
+					L.cdl[l] = lq;
+					cf[COEF_CDC + 4 * c + blk] = (int16_t)lq;
+					cdcnz = lq != 0;
+				}
+				WAVE_SYNC();
+				if (is_c) {
+					const int *ls = L.cdl + 4 * c;
+					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
+					const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
+					cd[0] = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
+					int pred[16], out[16];
+#pragma unroll
+					for (int i = 0; i < 16; i++)
+						pred[i] = predc(4 * bx + (i & 3), 4 * by + (i >> 2));
+					idct4x4_add(cd, pred, out);
+					__builtin_amdgcn_wave_barrier();
+#pragma unroll
+					for (int i = 0; i < 16; i++)
+						L.c[(1 + 4 * by + (i >> 2)) * IC_STRIDE + 8 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
+					p.nnz[mbaddr * NNZ_PER_MB + 16 + l] = (uint8_t)cnn;
+				}
+#undef CT
+				const uint64_t acm = __ballot(cnn != 0), dcm = __ballot(cdcnz != 0);
+				const uint32_t ac = (uint32_t)(acm >> (16 * g)) & 0xffffu, dcb = (uint32_t)(dcm >> (16 * g)) & 0xffffu;
+				WAVE_SYNC();
+				if (act) {
+					if (l < 8)
+						*(u32x4 *)(L.outc[slot] + l * 16) = *(const u32x4 *)(L.c + (1 + l) * IC_STRIDE + 8);
+					else if (l == 8)
+						*(u32x4 *)L.botc[mx & 3] = *(const u32x4 *)(L.c + 8 * IC_STRIDE + 8);
+					else if (l == 9)
+						L.cbp_c[slot] = ac ? 0x20 : (dcb ? 0x10 : 0);
+				}
+				lds_signal(&s_done_c[trip], base + t + 1, lane);
+			}
+			continue;
+		}
+
+		// ============================== mover wave ==============================
+		struct MoverRegs {
+			u32x4 sy, sc, modes;
+			uint64_t mi, ta, tb;
+			bool top_ok;
+		};
+		MoverRegs RA{}, RB{};
+		int pending_pub = -1, pending_x = -1;
+
+		auto load_step = [&](int t, bool block, MoverRegs &R) {
+			const int nmx = t - 2 * g, mx0 = t;
+			const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
+			const int cmx = nact ? nmx : 0, cmy = row_ok ? my : r0;
+			const size_t a = (size_t)st * p.n_mb + (size_t)cmy * p.mb_w + cmx;
+			const int x0 = cmx * 16, y0 = cmy * 16;
+			const bool left_mb = nmx > 0, tr_mb = top_mb && nmx < p.mb_w - 1;
+			R.top_ok = true;
+			const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w; // the macroblock above-right must be done
+			if (band > b_lo && mx0 < p.mb_w) {
+				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
+				if (!ready && block) {
+					wait_progress(s_prog, 4 * band - 1, need);
+					ready = true;
+				}
+				if (ready)
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				R.top_ok = ready;
+			} else if (xwg_band && mx0 < p.mb_w) {
+				if (xseen < (uint32_t)need)
+					xseen = xload32(&xprog[wj - 1]);
+				if (xseen < (uint32_t)need && block)
+					xseen = xwait(&xprog[wj - 1], xabort, xerr, (uint32_t)need);
+				R.top_ok = xseen >= (uint32_t)need;
+			}
+			R.sy = *(const u32x4 *)(src_y + (size_t)(y0 + l) * p.cw + x0);
+			R.sc = *(const u32x4 *)(src_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
+			R.mi = *(const uint64_t *)&p.mbi[a];
+			R.modes = *(const u32x4 *)(p.i4modes + a * 16);
+			R.ta = R.tb = 0;
+			if (g == 0 && top_mb && nact && R.top_ok) {
+				if (xwg_top) { // the other workgroup's write-through buffer
+					const uint64_t *hb = hb_in + (size_t)cmx * WF_HBUF_GRANULES;
+					if (l == 8 || l == 9)
+						R.ta = xload64(hb + (l - 8));
+					else if (l == 10 && tr_mb)
+						R.ta = xload64(hb + WF_HBUF_GRANULES);         // next MB, first 4 samples
+					else if (l == 11 && left_mb)
+						R.ta = xload64(hb - WF_HBUF_GRANULES + 1) >> 56; // previous MB, last sample
+					else if (l == 12 || l == 13)
+						R.ta = xload64(hb + 2 + (l - 12));
+					else if (l == 14 && left_mb)
+						R.ta = xload64(hb - WF_HBUF_GRANULES + 3) >> 48; // previous MB, last CbCr pair
+				} else {
+					if (l == 8) {
+						const uint64_t *tp = (const uint64_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0);
+						R.ta = tp[0];
+						R.tb = tp[1];
+					} else if (l == 10 && tr_mb) {
+						R.ta = *(const uint32_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0 + 16);
+					} else if (l == 11 && left_mb) {
+						R.ta = rec_y[(size_t)(y0 - 1) * p.cw + x0 - 1];
+					} else if (l == 12) {
+						const uint64_t *tp = (const uint64_t *)(rec_uv + (size_t)((y0 >> 1) - 1) * p.cw + x0);
+						R.ta = tp[0];
+						R.tb = tp[1];
+					} else if (l == 14 && left_mb) {
+						R.ta = *(const uint16_t *)(rec_uv + (size_t)((y0 >> 1) - 1) * p.cw + x0 - 2);
+					}
+				}
+			}
+		};
+
+		auto stage_step = [&](int t, const MoverRegs &R) {
+			const int mx = t - 2 * g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+			const int slot = t % 3;
+			if (!act)
+				return;
+			*(u32x4 *)(L.srcy[slot] + l * 16) = R.sy;
+			if (l < 8)
+				*(u32x4 *)(L.srcc[slot] + l * 16) = R.sc;
+			if (l == 15) {
+				const uint32_t mw[4] = { R.modes.x, R.modes.y, R.modes.z, R.modes.w };
+				uint64_t modes64 = 0;
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+					modes64 |= (uint64_t)((mw[k >> 2] >> (8 * (k & 3))) & 15u) << (4 * k);
+				*(u32x4 *)L.info[slot] = u32x4{ (uint32_t)R.mi, (uint32_t)(R.mi >> 32), (uint32_t)modes64, (uint32_t)(modes64 >> 32) };
+			}
+			if (g == 0 && top_mb) {
+				if (xwg_top) {
+					if (l == 8 || l == 9)
+						*(uint64_t *)(L.topy[slot] + 8 + (l - 8) * 8) = R.ta;
+					else if (l == 10)
+						*(uint32_t *)(L.topy[slot] + 24) = (uint32_t)R.ta;
+					else if (l == 11)
+						L.topy[slot][7] = (uint8_t)R.ta;
+					else if (l == 12 || l == 13)
+						*(uint64_t *)(L.topc[slot] + 8 + (l - 12) * 8) = R.ta;
+					else if (l == 14)
+						*(uint16_t *)(L.topc[slot] + 6) = (uint16_t)R.ta;
+				} else {
+					if (l == 8) {
+						*(uint64_t *)(L.topy[slot] + 8) = R.ta;
+						*(uint64_t *)(L.topy[slot] + 16) = R.tb;
+					} else if (l == 10) {
+						*(uint32_t *)(L.topy[slot] + 24) = (uint32_t)R.ta;
+					} else if (l == 11) {
+						L.topy[slot][7] = (uint8_t)R.ta;
+					} else if (l == 12) {
+						*(uint64_t *)(L.topc[slot] + 8) = R.ta;
+						*(uint64_t *)(L.topc[slot] + 16) = R.tb;
+					} else if (l == 14) {
+						*(uint16_t *)(L.topc[slot] + 6) = (uint16_t)R.ta;
+					}
+				}
+			}
+		};
+
+		auto writeback_step = [&](int t) {
+			const int mx = t - 2 * g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+			const int slot = t % 3;
+			if (!act)
+				return;
+			const int x0 = mx * 16, y0 = my * 16;
+			const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+			*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.outy[slot] + l * 16);
+			if (l < 8)
+				*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.outc[slot] + l * 16);
+			if (l == 15) { // the record, with the coded block pattern of both compute waves
+				const uint32_t cbp = (uint32_t)(L.cbp_y[slot] | L.cbp_c[slot]) & 0xffu;
+				const uint32_t w0 = (L.info[slot][0] & 0x00ffffffu) | cbp << 24;
+				*(uint64_t *)&p.mbi[mbaddr] = (uint64_t)w0 | (uint64_t)L.info[slot][1] << 32;
+			}
+			pending_pub = mx;
+			if (is_xprod) {
+				if (l < 4) {
+					const uint8_t *srcp = l < 2 ? L.outy[slot] + 15 * 16 + l * 8 : L.outc[slot] + 7 * 16 + (l - 2) * 8;
+					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)srcp);
+				}
+				pending_x = mx + 1;
+			}
+		};
+
+		auto publish = [&]() { // everything issued an iteration ago has completed by now
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (pending_pub >= 0 && l == 0)
+				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			pending_pub = -1;
+			if (b_hi < nbands && band == b_hi - 1) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (is_xprod && l == 0 && pending_x >= 0)
+					xstore32(&xprog[wj], (uint32_t)pending_x);
+				pending_x = -1;
+			}
+		};
+
+		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
+			if (t >= 1) {
+				lds_wait_ge(&s_done_y[trip], base + t, xerr);
+				lds_wait_ge(&s_done_c[trip], base + t, xerr);
+			}
+			publish();
+			if (t + 1 < nsteps) {
+				if (!R.top_ok)
+					load_step(t + 1, true, R);
+				stage_step(t + 1, R);
+				load_step(t + 3, false, R);
+				lds_signal(&s_staged[trip], base + t + 2, lane);
+			}
+			if (t >= 1)
+				writeback_step(t - 1);
+		};
+		load_step(0, true, RA);
+		load_step(1, false, RB);
+		stage_step(0, RA);
+		load_step(2, false, RA);
+		lds_signal(&s_staged[trip], base + 1, lane);
+		for (int t = 0; t <= nsteps; t += 2) {
+			mover_iter(t, RB);
+			if (t + 1 <= nsteps)
+				mover_iter(t + 1, RA);
+		}
+		publish();
+	}
+}
+
+
 int Launch::deblock(const Params &p, void *stream, int planes)
 {
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
@@ -1153,6 +1746,23 @@ int Launch::deblock(const Params &p, void *stream, int planes)
 		else if (planes == 2) hipLaunchKernelGGL((k_deblock2<false, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
 		else hipLaunchKernelGGL((k_deblock2<false, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
 	}
+	return (int)hipGetLastError();
+}
+
+int Launch::intra_recon(const Params &p, void *stream)
+{
+	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
+	static int version = 0;
+	if (!version) {
+		const char *e = getenv("CEDAR_INTRA_V");
+		version = e ? atoi(e) : 2;
+	}
+	// wavefront workgroups are throughput-bound on their CU: enough LDS (static, or unused
+	// dynamic) that two of them can never share one CU (160 KiB per CU)
+	if (version == 2)
+		hipLaunchKernelGGL(k_intra_recon2, grid, dim3(64 * 3 * IR_TRIPLES), 64 * 1024, (hipStream_t)stream, p);
+	else
+		hipLaunchKernelGGL(k_intra_recon<8>, grid, dim3(64 * 8), 40 * 1024, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 
