@@ -102,7 +102,8 @@ struct Params {
 	// and the write-through hand-off buffer for the rows crossing a workgroup boundary
 	uint32_t *wf_sync;               // [3][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock (luma), 2 deblock chroma
 	uint64_t *wf_hbuf;               // [n_units][wf_split-1][mb_w][WF_HBUF_GRANULES]
-	int32_t wf_split;
+	int32_t wf_split;                // workgroups per unit: deblock
+	int32_t wf_split_intra;          // workgroups per unit: intra recon
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream

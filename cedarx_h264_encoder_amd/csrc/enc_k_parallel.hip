@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 	const int st = blockIdx.z;
 	// first job of every frame on this stream: the ticket / abort / progress words of the
 	// three wavefront kernels start at zero (one memset launch less per frame)
-	if (row == 0 && st == 0 && p.wf_split > 1) {
+	if (row == 0 && st == 0 && (p.wf_split > 1 || p.wf_split_intra > 1)) {
 		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
 		for (int i = seg; i < 3 * used; i += gridDim.x * blockDim.x)
 			p.wf_sync[(i / used) * WF_SYNC_WORDS + i % used] = 0;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int g = lane >> 4, l = lane & 15;
-	const int NWG = p.wf_split; // workgroups sharing this unit's wavefront (see k_deblock)
+	const int NWG = p.wf_split_intra; // workgroups sharing this unit's wavefront (see k_deblock)
 	uint32_t *sync = p.wf_sync; // region 0 = intra_recon
 	if (threadIdx.x == 0)
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
@@ -639,6 +639,7 @@ DEVI void filt_chroma_s2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &
 }
 
 constexpr int DB2_PAIRS = WF_WAVES / 2;
+constexpr int DB2_XRING = 16; // macroblocks of bottom rows a band keeps for the band below (power of two)
 
 struct Db2GroupLds {
 	uint8_t y[3][20 * DT_STRIDE];
@@ -676,7 +677,9 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 {
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
 	__shared__ __attribute__((aligned(16))) Db2GroupLds s_g[DB2_PAIRS * 4];
-	__shared__ int s_prog[MAX_ROWS];
+	// bottom rows of a band's last macroblock row, for the pair that filters the band below
+	__shared__ __attribute__((aligned(16))) uint8_t s_xbot[DB2_PAIRS][DB2_XRING][DO_Y ? 64 : 16];
+	__shared__ __attribute__((aligned(16))) uint8_t s_xbotc[DB2_PAIRS][DB2_XRING][DO_C ? 32 : 16];
 	__shared__ int s_staged[DB2_PAIRS], s_filtered[DB2_PAIRS];
 	__shared__ int s_ticket;
 
@@ -690,8 +693,6 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
 	if (threadIdx.x == 0)
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
-	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
-		s_prog[i] = 0;
 	if (threadIdx.x < DB2_PAIRS) {
 		s_staged[threadIdx.x] = 0;
 		s_filtered[threadIdx.x] = 0;
@@ -724,7 +725,14 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 		const int my = r0 + 4 * band + g;
 		const bool row_ok = my < r1;
 		const bool top_edge = my > r0;
-		const bool xwave_top = g == 0 && band > b_lo;
+		// bands of one workgroup hand their bottom rows on through LDS (s_xbot), filter wave to
+		// filter wave: the pair below follows two macroblocks behind like a group of the same
+		// wave would; its movers stay out of that dependency chain
+		const int rel = band - b_lo;
+		const bool in_top = rel > 0, in_bot = band + 1 < b_hi;
+		const int pair_up = (rel - 1) & (DB2_PAIRS - 1), base_up = ((rel - 1) / DB2_PAIRS) * (nsteps + 2);
+		const int pair_dn = (rel + 1) & (DB2_PAIRS - 1), base_dn = ((rel + 1) / DB2_PAIRS) * (nsteps + 2);
+		const bool feeds_next = g == 3 && band + 1 < nbands; // its last 4 rows are stored by whoever filters below
 		const bool xwg_band = band == b_lo && b_lo > 0;
 		const bool xwg_top = g == 0 && xwg_band;
 		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands;
@@ -747,6 +755,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 				long long c1 = __builtin_readcyclecounter();
 				tw += c1 - c0;
 #endif
+				if (in_top && t < p.mb_w) // the macroblock above-right of group 0's has been filtered
+					lds_wait_ge(&s_filtered[pair_up], base_up + (t + 8 < nsteps ? t + 8 : nsteps), xerr);
 				if (act) {
 					if (left_edge) { // previous tile's last 4 columns (final) become the left neighbours
 						if (DO_Y)
@@ -759,6 +769,11 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 3] + l * 16);
 						else if (DO_C && l >= 4 && l < 6)
 							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 3] + (l - 4) * 16);
+					} else if (in_top && g == 0) { // ... or the pair above did
+						if (DO_Y && l < 4)
+							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(s_xbot[pair_up][mx & (DB2_XRING - 1)] + l * 16);
+						else if (DO_C && l >= 4 && l < 6)
+							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(s_xbotc[pair_up][mx & (DB2_XRING - 1)] + (l - 4) * 16);
 					}
 				}
 				WAVE_SYNC();
@@ -855,15 +870,31 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 					}
 				}
 				WAVE_SYNC();
+				if (in_bot && t - 6 >= DB2_XRING && t - 6 < p.mb_w) // ring slot of group 3: consumed by the pair below?
+					lds_wait_ge(&s_filtered[pair_dn], base_dn + (t - 6 - DB2_XRING) + 1, xerr);
 				if (act) { // bottom rows for the row below; columns 12..15 of the previous MB are final now
 					if (DO_Y && l >= 12) {
-						*(u32x4 *)(L.bot[mx & 3] + (l - 12) * 16) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
+						const u32x4 rowv = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
+						const uint32_t patch = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+						*(u32x4 *)(L.bot[mx & 3] + (l - 12) * 16) = rowv;
 						if (left_edge)
-							*(uint32_t *)(L.bot[(mx - 1) & 3] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+							*(uint32_t *)(L.bot[(mx - 1) & 3] + (l - 12) * 16 + 12) = patch;
+						if (g == 3 && in_bot) {
+							*(u32x4 *)(s_xbot[pair][mx & (DB2_XRING - 1)] + (l - 12) * 16) = rowv;
+							if (left_edge)
+								*(uint32_t *)(s_xbot[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 12) * 16 + 12) = patch;
+						}
 					} else if (DO_C && l >= 6 && l < 8) {
-						*(u32x4 *)(L.botc[mx & 3] + (l - 6) * 16) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
+						const u32x4 rowv = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
+						const uint32_t patch = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+						*(u32x4 *)(L.botc[mx & 3] + (l - 6) * 16) = rowv;
 						if (left_edge)
-							*(uint32_t *)(L.botc[(mx - 1) & 3] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+							*(uint32_t *)(L.botc[(mx - 1) & 3] + (l - 6) * 16 + 12) = patch;
+						if (g == 3 && in_bot) {
+							*(u32x4 *)(s_xbotc[pair][mx & (DB2_XRING - 1)] + (l - 6) * 16) = rowv;
+							if (left_edge)
+								*(uint32_t *)(s_xbotc[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 6) * 16 + 12) = patch;
+						}
 					}
 				}
 				lds_signal(&s_filtered[pair], base + t + 1, lane);
@@ -884,7 +915,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 		// two register sets: the loads of step t+3 are issued while step t+1 is staged (memory
 		// latency here is about one whole step)
 		struct MoverRegs {
-			u32x4 in, c, top;
+			u32x4 in, c;
 			uint64_t topx;
 			uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
 			uint8_t nz, nzt;
@@ -893,7 +924,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 		MoverRegs RA{}, RB{};
 		uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
 		int mvl = 0;
-		int pending_pub = -1, pending_x = -1;
+		int pending_x = -1;
 
 		auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t into the r_* registers
 			const int nmx = t - 2 * g, mx0 = t;
@@ -903,17 +934,8 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
 			// readiness of the rows above first: its acquire must not sit behind this step's own loads
 			R.top_ok = true;
-			if (band > b_lo && mx0 < p.mb_w) {
-				const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w;
-				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
-				if (!ready && block) {
-					wait_progress(s_prog, 4 * band - 1, need);
-					ready = true;
-				}
-				if (ready)
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				R.top_ok = ready;
-			} else if (xwg_band && mx0 < p.mb_w) {
+			if (xwg_band && mx0 < p.mb_w) { // rows above live in another workgroup
+
 				const uint32_t need = (uint32_t)mx0 + 1u;
 				if (xseen < need)
 					xseen = xload32(&xprog[wj - 1]);
@@ -931,12 +953,6 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 				const size_t at = (top_edge && row_ok) ? a - p.mb_w : a;
 				R.mvt = ((const uint32_t *)&p.mbi[at])[1];
 				R.nzt = p.nnz[at * NNZ_PER_MB + l];
-			}
-			if (xwave_top && R.top_ok && nact) {
-				if (DO_Y && l < 4)
-					R.top = *(const u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0);
-				else if (DO_C && l >= 4 && l < 6)
-					R.top = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) - 2 + l - 4) * p.cw + x0);
 			}
 			if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
 				R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
@@ -962,18 +978,11 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 					*(u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16) = R.in;
 				if (DO_C && l < 8)
 					*(u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16) = R.c;
-				if (top_edge && g == 0) {
-					if (xwg_top) {
-						if (DO_Y && l < 8)
-							*(uint64_t *)(L.y[slot] + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = R.topx;
-						else if (DO_C && l >= 8 && l < 12)
-							*(uint64_t *)(L.c[slot] + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = R.topx;
-					} else {
-						if (DO_Y && l < 4)
-							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = R.top;
-						else if (DO_C && l >= 4 && l < 6)
-							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = R.top;
-					}
+				if (xwg_top) { // rows above from the other workgroup (inside a workgroup the filter wave fetches them)
+					if (DO_Y && l < 8)
+						*(uint64_t *)(L.y[slot] + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = R.topx;
+					else if (DO_C && l >= 8 && l < 12)
+						*(uint64_t *)(L.c[slot] + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = R.topx;
 				}
 				if (IDR) { // all intra: bS 4 (strong) on macroblock edges, 3 inside
 					const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
@@ -1024,12 +1033,12 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 			const int x0 = mx * 16, y0 = my * 16;
 			if (!act)
 				return;
-			if (DO_Y && !(is_xprod && l >= 12)) {
+			if (DO_Y && !(feeds_next && l >= 12)) {
 				*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
 				if (left_edge)
 					*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
 			}
-			if (DO_C && l < 8 && !(is_xprod && l >= 6)) {
+			if (DO_C && l < 8 && !(feeds_next && l >= 6)) {
 				*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
 				if (left_edge)
 					*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
@@ -1040,7 +1049,6 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 				else if (DO_C && l >= 4 && l < 6)
 					*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16);
 			}
-			pending_pub = mx;
 			if (is_xprod) {
 				const bool my_gran = (DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES);
 				if (left_edge && my_gran) {
@@ -1058,10 +1066,6 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 		};
 
 		auto publish = [&]() { // everything issued an iteration ago has completed by now
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (pending_pub >= 0 && l == 0)
-				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			pending_pub = -1;
 			if (b_hi < nbands && band == b_hi - 1) {
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				if (is_xprod && l == 0 && pending_x >= 0)
@@ -1164,7 +1168,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	// waves land on SIMD wave%4: the three waves of a triple sit on three different SIMDs
 	const int role = wave / IR_TRIPLES, trip = wave % IR_TRIPLES; // 0 luma, 1 chroma, 2 mover
 	const int g = lane >> 4, l = lane & 15;
-	const int NWG = p.wf_split;
+	const int NWG = p.wf_split_intra;
 	uint32_t *sync = p.wf_sync; // region 0
 	if (threadIdx.x == 0)
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
@@ -1751,7 +1755,7 @@ int Launch::deblock(const Params &p, void *stream, int planes)
 
 int Launch::intra_recon(const Params &p, void *stream)
 {
-	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
+	dim3 grid(p.n_streams * p.slice_num * p.wf_split_intra);
 	static int version = 0;
 	if (!version) {
 		const char *e = getenv("CEDAR_INTRA_V");

@@ -171,7 +171,7 @@ struct cedar_enc {
 	uint8_t *d_pred4 = nullptr;
 	uint32_t *d_wf_sync = nullptr;
 	uint64_t *d_wf_hbuf = nullptr;
-	int wf_split = 1;
+	int wf_split = 1, wf_split_intra = 1;
 	// pinned host memory
 	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
 	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = { nullptr, nullptr };
@@ -593,14 +593,25 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 			slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
 			if ((b - a + 3) / 4 < nb_min) nb_min = (b - a + 3) / 4;
 		}
-		const char *env = getenv("CEDAR_WF_SPLIT");
-		// measured on MI355X (1080p, 1 unit): deblock 0.58 ms with 4 parts, 0.51 ms with 8 (every
-		// filter wave alone on its SIMD, its mover on another); intra recon 1.36x from 4 parts
-		int split = env ? atoi(env) : (n_units <= 8 ? 8 : n_units <= 16 ? 4 : n_units <= 48 ? 2 : 1);
-		if (split > WF_MAX_SPLIT) split = WF_MAX_SPLIT;
-		if (split > nb_min / 2) split = nb_min / 2;
-		if (split < 1) split = 1;
-		e->wf_split = split;
+		auto clamp_split = [&](int split) {
+			if (split > WF_MAX_SPLIT) split = WF_MAX_SPLIT;
+			if (split > nb_min / 2) split = nb_min / 2;
+			return split < 1 ? 1 : split;
+		};
+		const char *env = getenv("CEDAR_WF_SPLIT"), *env_i = getenv("CEDAR_WF_SPLIT_INTRA");
+		// Measured on MI355X, 1080p (17 bands of 4 macroblock rows per unit), see DESIGN.md:
+		//   deblock (8 filter/mover pairs per workgroup): 1 unit 0.64 / 0.51 / 0.47 ms at 2 / 4 / 8
+		//   parts; 32 units 1.06 / 0.89 / 0.82 ms at 1 / 2 / 4 parts
+		//   intra recon (3 luma/chroma/mover triples per workgroup): a workgroup with more than 3
+		//   bands serialises them, 7.1 ms at 4 parts against 3.3 ms at 6 (1 unit)
+		int nb_max = 0;
+		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
+			int a, b;
+			slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
+			if ((b - a + 3) / 4 > nb_max) nb_max = (b - a + 3) / 4;
+		}
+		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 8 ? 8 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
+		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 2) / 3);
 	}
 	if ((rc = dalloc(e, &e->d_wf_sync, (size_t)3 * WF_SYNC_WORDS))) return rc;
 	if ((rc = dalloc(e, &e->d_wf_hbuf, (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc;
@@ -657,6 +668,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.wf_sync = e->d_wf_sync;
 	P.wf_hbuf = e->d_wf_hbuf;
 	P.wf_split = e->wf_split;
+	P.wf_split_intra = e->wf_split_intra;
 
 	build_sps_pps(e);
 	e->frame_count = 0; // cedar.c:815-816
