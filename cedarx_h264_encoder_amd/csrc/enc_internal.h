@@ -34,7 +34,7 @@ constexpr int COEF_PER_MB = 408;  // 816 bytes = 51 x 16 B
 constexpr int NNZ_PER_MB = 24;    // 16 luma (raster bx+4*by), 4 Cb, 4 Cr
 constexpr int SLOT_BYTES = 2048;  // private CAVLC bit buffer of one macroblock
 constexpr int SLOT_WORDS = SLOT_BYTES / 4;
-constexpr int ESC_CHUNK = 256;    // bytes of RBSP per emulation-prevention thread
+constexpr int ESC_CHUNK = 32;     // bytes of RBSP per emulation-prevention thread
 constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
 constexpr int WF_MAX_SPLIT = 8;   // workgroups sharing one unit's wavefront
@@ -92,7 +92,7 @@ struct Params {
 	uint32_t *esc_cnt;               // [n_units][esc_chunks_cap]
 	uint32_t *nal_off;               // [n_units] byte offset of the NAL in out
 	uint32_t *nal_size;              // [n_units]
-	uint32_t *stream_size;           // [n_streams + 2] bytes per stream; [n] total; [n+1] error flags
+	uint32_t *stream_size;           // [n_streams + 3] bytes per stream; [n] total; [n+1] error flags; [n+2] units scanned (k_esc_scan)
 	uint8_t *out;                    // compact output: all streams back to back
 	const SliceHdr *hdr;             // [n_units] (identical across streams per slice)
 	const uint32_t *prefix_len;      // [n_streams] bytes reserved in front (SPS+PPS)

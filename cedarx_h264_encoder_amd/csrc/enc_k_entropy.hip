@@ -11,6 +11,8 @@
 //                write over fixed chunks, NAL start code + header, compact output
 // In the reference all of this is silicon behind PUTBITS/STM registers
 // (kernel/cedar_regs.h:59-63; emulation prevention toggled at cedar.c:872-880).
+#include <stdlib.h>
+
 #include <hip/hip_runtime.h>
 
 #include "enc_device.h"
@@ -367,6 +369,343 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 		atomicOr(&p.stream_size[p.n_streams + 1], 1u);
 }
 
+// ------------------------------------------------------------------------
+// k_cavlc2: one wave codes TWO macroblocks, one lane per syntax part:
+//   lane 0 of a half   macroblock header (type, prediction modes / mvd, cbp, qp delta;
+//                      P_Skip inference)
+//   lane 1             Intra16x16 DC block
+//   lanes 2..17        the 16 luma 4x4 blocks (coding order)
+//   lanes 18, 19       chroma DC Cb, Cr
+//   lanes 20..27       chroma AC Cb 0..3, Cr 0..3
+// Every lane runs residual_block_cavlc on its block into a private LDS bit buffer;
+// a prefix sum of the lengths gives each part its bit position, the parts are ORed
+// into the macroblock's slot image in LDS and stored with coalesced writes.
+// Thread-per-macroblock (the previous form) left a 1080p picture with 128 waves of
+// serial work, 0.25 ms; this form has 4080 waves of 1/28 the chain.
+// ------------------------------------------------------------------------
+constexpr int CV_LANE_WORDS = 24; // 768 bits >= the longest coded 4x4 block (16 escapes + token + zeros + runs < 640)
+
+struct LdsBitW {
+	uint32_t *buf;
+	uint64_t acc;
+	int nacc, words, overflow;
+};
+
+DEVI void lw_put(LdsBitW &b, uint32_t v, int n)
+{
+	if (n == 0)
+		return;
+	b.acc = (b.acc << n) | (uint64_t)(v & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u)));
+	b.nacc += n;
+	if (b.nacc >= 32) {
+		if (b.words < CV_LANE_WORDS)
+			b.buf[b.words] = (uint32_t)(b.acc >> (b.nacc - 32));
+		else
+			b.overflow = 1;
+		b.words++;
+		b.nacc -= 32;
+	}
+}
+DEVI void lw_ue(LdsBitW &b, uint32_t v)
+{
+	v++;
+	lw_put(b, v, 2 * (32 - __clz(v)) - 1);
+}
+DEVI void lw_se(LdsBitW &b, int v) { lw_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+DEVI void lw_code(LdsBitW &b, uint16_t packed) { lw_put(b, packed & 0xff, packed >> 8); }
+
+// residual_block_cavlc (7.3.5.3.2 / 9.2) of lv[first .. first+maxc), levels read from LDS
+DEVI void cavlc_block_lds(LdsBitW &b, const int16_t *lv, int first, int maxc, int nC)
+{
+	uint32_t mask = 0;
+	for (int i = 0; i < maxc; i++)
+		mask |= lv[first + i] != 0 ? 1u << i : 0u;
+	const int n = __popc(mask);
+	int t1 = 0;
+	for (uint32_t m = mask; m && t1 < 3; t1++) {
+		const int hi = 31 - __clz(m);
+		const int v = lv[first + hi];
+		if (v != 1 && v != -1)
+			break;
+		m &= ~(1u << hi);
+	}
+	if (nC < 0)
+		lw_code(b, kCoeffTokenChromaDC[4 * n + t1]);
+	else
+		lw_code(b, kCoeffToken[(nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3) * 68 + 4 * n + t1]);
+	if (n == 0)
+		return;
+	int suffix_len = (n > 10 && t1 < 3) ? 1 : 0;
+	uint32_t m = mask;
+	for (int k = 0; k < n; k++) {
+		const int hi = 31 - __clz(m);
+		m &= ~(1u << hi);
+		const int level = lv[first + hi];
+		if (k < t1) {
+			lw_put(b, level < 0, 1);
+			continue;
+		}
+		const int a = level < 0 ? -level : level;
+		int code = 2 * a - 2 + (level < 0);
+		if (k == t1 && t1 < 3)
+			code -= 2;
+		if (suffix_len == 0) {
+			if (code < 14) {
+				lw_put(b, 1, code + 1);
+			} else if (code < 30) {
+				lw_put(b, 1, 15);
+				lw_put(b, (uint32_t)(code - 14), 4);
+			} else {
+				lw_put(b, 1, 16);
+				lw_put(b, (uint32_t)(code - 30), 12);
+			}
+		} else if (code < (15 << suffix_len)) {
+			lw_put(b, 1, (code >> suffix_len) + 1);
+			lw_put(b, (uint32_t)(code & ((1 << suffix_len) - 1)), suffix_len);
+		} else {
+			lw_put(b, 1, 16);
+			lw_put(b, (uint32_t)(code - (15 << suffix_len)), 12);
+		}
+		if (suffix_len == 0)
+			suffix_len = 1;
+		if (a > (3 << (suffix_len - 1)) && suffix_len < 6)
+			suffix_len++;
+	}
+	const int last = 31 - __clz(mask);
+	const int total_zeros = last + 1 - n;
+	if (n < maxc) {
+		if (maxc == 4)
+			lw_code(b, kTotalZerosChromaDC[(n - 1) * 4 + total_zeros]);
+		else
+			lw_code(b, kTotalZeros[(n - 1) * 16 + total_zeros]);
+	}
+	int zeros_left = total_zeros;
+	m = mask;
+	for (int k = 0; k < n - 1 && zeros_left > 0; k++) {
+		const int hi = 31 - __clz(m);
+		m &= ~(1u << hi);
+		const int next = 31 - __clz(m);
+		const int run = hi - next - 1;
+		lw_code(b, kRunBefore[((zeros_left > 7 ? 7 : zeros_left) - 1) * 16 + run]);
+		zeros_left -= run;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_cavlc2(Params p)
+{
+	__shared__ __attribute__((aligned(16))) int16_t s_cf[2][COEF_PER_MB];
+	__shared__ __attribute__((aligned(16))) uint8_t s_nnz[2][3][32]; // cur, left, top
+	__shared__ __attribute__((aligned(16))) int8_t s_modes[2][3][16];
+	__shared__ MbInfo s_mi[2][4];                                      // cur, left, top, top-right / top-left
+	__shared__ uint32_t s_lane[64][CV_LANE_WORDS];
+	__shared__ uint32_t s_out[2][SLOT_WORDS];
+
+	const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+	const int i = blockIdx.x * 2 + half; // macroblock index within the encoded rows
+	const int st = blockIdx.y;
+	const int nmb = p.row_num * p.mb_w;
+	const bool valid = i < nmb;
+	const int ci = valid ? i : nmb - 1;
+	const int my = p.row_first + ci / p.mb_w, mx = ci % p.mb_w;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
+	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+	const bool has_left = mx > 0, has_top = my > r0;
+	const bool has_c = has_top && (mx < p.mb_w - 1 || mx > 0);
+	const size_t addr_c = has_top ? (mx < p.mb_w - 1 ? mbaddr - p.mb_w + 1 : mbaddr - p.mb_w - 1) : mbaddr;
+
+	// ---- stage everything the half needs (coalesced) ----
+	{
+		const u32x4 *src = (const u32x4 *)(p.coef + mbaddr * COEF_PER_MB);
+		u32x4 *dst = (u32x4 *)s_cf[half];
+		dst[hl] = src[hl];
+		if (hl + 32 < COEF_PER_MB / 8)
+			dst[hl + 32] = src[hl + 32];
+		if (hl < 24) {
+			s_nnz[half][0][hl] = p.nnz[mbaddr * NNZ_PER_MB + hl];
+			s_nnz[half][1][hl] = has_left ? p.nnz[(mbaddr - 1) * NNZ_PER_MB + hl] : 0;
+			s_nnz[half][2][hl] = has_top ? p.nnz[(mbaddr - p.mb_w) * NNZ_PER_MB + hl] : 0;
+		}
+		if (hl < 16 && p.is_idr) {
+			s_modes[half][0][hl] = p.i4modes[mbaddr * 16 + hl];
+			s_modes[half][1][hl] = has_left ? p.i4modes[(mbaddr - 1) * 16 + hl] : 2;
+			s_modes[half][2][hl] = has_top ? p.i4modes[(mbaddr - p.mb_w) * 16 + hl] : 2;
+		}
+		if (hl < 4) {
+			const size_t a = hl == 0 ? mbaddr : hl == 1 ? (has_left ? mbaddr - 1 : mbaddr)
+					 : hl == 2 ? (has_top ? mbaddr - p.mb_w : mbaddr) : addr_c;
+			s_mi[half][hl] = p.mbi[a];
+		}
+	}
+	__syncthreads();
+
+	const MbInfo mi = s_mi[half][0];
+	const int16_t *cf = s_cf[half];
+	Nb nb;
+	nb.cur = s_nnz[half][0];
+	nb.left = has_left ? s_nnz[half][1] : nullptr;
+	nb.top = has_top ? s_nnz[half][2] : nullptr;
+	LdsBitW b;
+	b.buf = s_lane[lane];
+	b.acc = 0;
+	b.nacc = b.words = b.overflow = 0;
+	int skip = 0;
+	const int cbp = mi.cbp & 0x3f;
+
+	if (valid && hl == 0) {
+		// ---- macroblock header ----
+		if (p.is_idr) {
+			if (mi.type == MB_I4x4) {
+				lw_ue(b, 0);
+				const int8_t *mo = s_modes[half][0];
+				const bool left_i4 = has_left && s_mi[half][1].type == MB_I4x4;
+				const bool top_i4 = has_top && s_mi[half][2].type == MB_I4x4;
+				for (int idx = 0; idx < 16; idx++) {
+					const int bx = blk_x(idx), by = blk_y(idx);
+					// predicted mode (8.3.1.1): DC when either neighbour MB is unavailable
+					int ma = 2, mb_ = 2;
+					bool dcflag = false;
+					if (bx > 0)
+						ma = mo[idx - (bx & 1 ? 1 : 3)];
+					else if (has_left)
+						ma = left_i4 ? s_modes[half][1][idx + 5] : 2;
+					else
+						dcflag = true;
+					if (by > 0)
+						mb_ = mo[idx - (by & 1 ? 2 : 6)];
+					else if (has_top)
+						mb_ = top_i4 ? s_modes[half][2][idx + 10] : 2;
+					else
+						dcflag = true;
+					const int pm = dcflag ? 2 : (ma < mb_ ? ma : mb_);
+					const int m = mo[idx];
+					if (m == pm) {
+						lw_put(b, 1, 1);
+					} else {
+						lw_put(b, 0, 1);
+						lw_put(b, (uint32_t)(m < pm ? m : m - 1), 3);
+					}
+				}
+				lw_ue(b, (uint32_t)mi.chroma_mode);
+				lw_ue(b, kCbpCodeIntra[cbp]);
+				if (cbp)
+					lw_se(b, 0);
+			} else {
+				const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
+				lw_ue(b, (uint32_t)t);
+				lw_ue(b, (uint32_t)mi.chroma_mode);
+				lw_se(b, 0);
+			}
+		} else {
+			// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1)
+			const bool hasA = has_left, hasB = has_top, hasC = has_c;
+			const MbInfo mA = s_mi[half][1], mB = s_mi[half][2], mC = s_mi[half][3];
+			const int ax = hasA ? mA.mvx : 0, ay = hasA ? mA.mvy : 0;
+			const int bx_ = hasB ? mB.mvx : 0, by_ = hasB ? mB.mvy : 0;
+			const int cx = hasC ? mC.mvx : 0, cy = hasC ? mC.mvy : 0;
+			int px, py;
+			const int n = (int)hasA + (int)hasB + (int)hasC;
+			if (!hasB && !hasC && hasA) {
+				px = ax; py = ay;
+			} else if (n == 1) {
+				px = hasA ? ax : hasB ? bx_ : cx;
+				py = hasA ? ay : hasB ? by_ : cy;
+			} else {
+				px = median3(ax, bx_, cx);
+				py = median3(ay, by_, cy);
+			}
+			int skx = px, sky = py;
+			if (!hasA || !hasB || (ax == 0 && ay == 0) || (bx_ == 0 && by_ == 0)) {
+				skx = 0; sky = 0;
+			}
+			if (mi.cbp == 0 && mi.mvx == skx && mi.mvy == sky) {
+				skip = 1;
+				p.mbi[mbaddr].type = MB_PSKIP; // nobody else reads .type of a P macroblock concurrently
+			} else {
+				lw_ue(b, 0); // P_L0_16x16
+				lw_se(b, 4 * (mi.mvx - px));
+				lw_se(b, 4 * (mi.mvy - py));
+				lw_ue(b, kCbpCodeInter[cbp]);
+				if (cbp)
+					lw_se(b, 0);
+			}
+		}
+	} else if (valid && hl == 1) {
+		if (mi.type == MB_I16x16)
+			cavlc_block_lds(b, cf + COEF_DC16, 0, 16, calc_nc(nb, 0, 0, 0));
+	} else if (valid && hl < 18) {
+		const int idx = hl - 2;
+		if (cbp & (1 << (idx >> 2))) {
+			const int nC = calc_nc(nb, 0, blk_x(idx), blk_y(idx));
+			if (mi.type == MB_I16x16)
+				cavlc_block_lds(b, cf + COEF_LUMA + idx * 16, 1, 15, nC);
+			else
+				cavlc_block_lds(b, cf + COEF_LUMA + idx * 16, 0, 16, nC);
+		}
+	} else if (valid && hl < 20) {
+		if (cbp & 0x30)
+			cavlc_block_lds(b, cf + COEF_CDC + 4 * (hl - 18), 0, 4, -1);
+	} else if (valid && hl < 28) {
+		if (cbp & 0x20) {
+			const int c = (hl - 20) >> 2, blk = (hl - 20) & 3;
+			cavlc_block_lds(b, cf + COEF_CAC + (4 * c + blk) * 16, 1, 15, calc_nc(nb, 1 + c, blk & 1, blk >> 1));
+		}
+	}
+	// flush the partial word, left-aligned
+	if (b.nacc > 0) {
+		if (b.words < CV_LANE_WORDS)
+			b.buf[b.words] = (uint32_t)(b.acc << (32 - b.nacc));
+		else
+			b.overflow = 1;
+	}
+	const int my_bits = b.words * 32 + b.nacc;
+
+	// ---- bit position of every part: exclusive prefix over the 32 lanes of the half ----
+	int incl = my_bits;
+#pragma unroll
+	for (int off = 1; off < 32; off <<= 1) {
+		const int o = __shfl_up(incl, off, 32);
+		if (hl >= off)
+			incl += o;
+	}
+	const int total = __shfl(incl, 31, 32);
+	const int nwords = (total + 31) >> 5;
+	for (int w = hl; w < nwords && w < SLOT_WORDS; w += 32)
+		s_out[half][w] = 0;
+	__syncthreads();
+	{
+		uint32_t pos = (uint32_t)(incl - my_bits);
+		const int nw = b.words + (b.nacc > 0 ? 1 : 0);
+		for (int w = 0; w < nw && w < CV_LANE_WORDS; w++) {
+			const int nbt = w < b.words ? 32 : b.nacc;
+			const uint32_t v = b.buf[w] >> (32 - nbt); // right-aligned
+			const uint32_t wi = pos >> 5, sft = pos & 31;
+			if (wi + 1 < (uint32_t)SLOT_WORDS) {
+				if (sft + nbt <= 32) {
+					atomicOr(&s_out[half][wi], v << (32 - sft - nbt));
+				} else {
+					const int lo = (int)sft + nbt - 32;
+					atomicOr(&s_out[half][wi], v >> lo);
+					atomicOr(&s_out[half][wi + 1], v << (32 - lo));
+				}
+			}
+			pos += nbt;
+		}
+	}
+	__syncthreads();
+	if (valid) {
+		uint32_t *slot = p.slot + mbaddr * SLOT_WORDS;
+		for (int w = hl; w < nwords && w < SLOT_WORDS; w += 32)
+			slot[w] = s_out[half][w];
+		if (hl == 0) {
+			p.mb_bits[mbaddr] = (uint32_t)total;
+			p.skip[mbaddr] = (uint8_t)skip;
+		}
+		if (b.overflow || (hl == 0 && nwords + 1 >= SLOT_WORDS))
+			atomicOr(&p.stream_size[p.n_streams + 1], 1u);
+	}
+}
+
 // ---------------- block-wide inclusive scans (1024 threads) ----------------
 template <bool IS_MAX>
 DEVI int block_scan_incl(int v, int *s_tmp)
@@ -562,44 +901,61 @@ DEVI int zero_state_before(const uint8_t *rb, int pos)
 	return run == 0 ? 0 : ((run & 1) ? 1 : 2);
 }
 
+// The escaping automaton over one ESC_CHUNK of RBSP held in registers. EMIT = write the
+// escaped bytes to o (byte stores: the output is shifted by a running, unaligned amount).
+template <bool EMIT>
+DEVI uint32_t esc_chunk(const uint8_t *rb, int start, int end, uint8_t *o)
+{
+	static_assert(ESC_CHUNK == 32, "two 16-byte loads per chunk");
+	const u32x4 a = *(const u32x4 *)(rb + start), c = *(const u32x4 *)(rb + start + 16);
+	const uint32_t w[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+	int z = zero_state_before(rb, start);
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int i = 0; i < ESC_CHUNK; i++) {
+		if (start + i < end) {
+			const uint32_t v = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+			if (z == 2 && v <= 3) {
+				cnt++;
+				z = 0;
+				if (EMIT)
+					*o++ = 3;
+			}
+			if (EMIT)
+				*o++ = (uint8_t)v;
+			z = v == 0 ? z + 1 : 0;
+		}
+	}
+	return cnt;
+}
+
 __global__ __launch_bounds__(256) void k_esc_count(Params p)
 {
 	const int unit = blockIdx.y;
 	const int nbytes = (int)((p.unit_bits[unit] + 7) >> 3);
 	const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
 	const int start = chunk * ESC_CHUNK;
-	if (chunk >= p.esc_chunks_cap)
+	if (chunk >= p.esc_chunks_cap || start >= nbytes + ESC_CHUNK) // one zero entry past the end is all the scan reads
 		return;
 	uint32_t cnt = 0;
 	if (start < nbytes) {
 		const uint8_t *rb = p.rbsp + (size_t)unit * p.rbsp_cap;
-		const int end = start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes;
-		int z = zero_state_before(rb, start);
-		for (int i = start; i < end; i++) {
-			const uint8_t v = rb[i];
-			if (z == 2 && v <= 3) {
-				cnt++;
-				z = 0;
-			}
-			z = v == 0 ? z + 1 : 0;
-		}
+		cnt = esc_chunk<false>(rb, start, start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes, nullptr);
 	}
 	p.esc_cnt[(size_t)unit * p.esc_chunks_cap + chunk] = cnt;
 }
 
-// one block: per unit exclusive prefix of the escape counts, NAL sizes, compact
-// output offsets (stream-major, each stream preceded by its SPS/PPS prefix)
+// One block per unit: exclusive prefix of its escape counts. The block that finishes last
+// lays the NAL units out: sizes, compact output offsets (stream-major, each stream preceded
+// by its SPS/PPS prefix), total and overflow flag.
 __global__ __launch_bounds__(1024) void k_esc_scan(Params p)
 {
 	__shared__ int s_tmp[32];
 	__shared__ int s_carry;
-	__shared__ uint32_t s_pos;
+	__shared__ int s_last;
 	const int n_units = p.n_streams * p.slice_num;
-	if (threadIdx.x == 0)
-		s_pos = 0;
-	__syncthreads();
-	for (int unit = 0; unit < n_units; unit++) {
-		const int st = unit / p.slice_num, ls = unit % p.slice_num;
+	const int unit = blockIdx.x;
+	{
 		const int nbytes = (int)((p.unit_bits[unit] + 7) >> 3);
 		const int chunks = (nbytes + ESC_CHUNK - 1) / ESC_CHUNK;
 		uint32_t *cnt = p.esc_cnt + (size_t)unit * p.esc_chunks_cap;
@@ -619,25 +975,37 @@ __global__ __launch_bounds__(1024) void k_esc_scan(Params p)
 			__syncthreads();
 		}
 		if (threadIdx.x == 0) {
-			uint32_t pos = s_pos;
-			if (ls == 0) {
-				p.stream_size[st] = pos; // start of the stream, fixed up below
-				pos += p.prefix_len[st];
-			}
-			const uint32_t size = 5u + (uint32_t)nbytes + (uint32_t)s_carry;
-			p.nal_off[unit] = pos;
-			p.nal_size[unit] = size;
-			pos += size;
-			s_pos = pos;
-			if (ls == p.slice_num - 1)
-				p.stream_size[st] = pos - p.stream_size[st];
-			if (pos > (uint32_t)p.out_cap || (uint32_t)nbytes + 8u > (uint32_t)p.rbsp_cap)
-				atomicOr(&p.stream_size[p.n_streams + 1], 2u);
+			p.nal_size[unit] = 5u + (uint32_t)nbytes + (uint32_t)s_carry;
+			__threadfence();
+			s_last = atomicAdd(&p.stream_size[p.n_streams + 2], 1u) == (uint32_t)n_units - 1;
 		}
 		__syncthreads();
 	}
-	if (threadIdx.x == 0)
-		p.stream_size[p.n_streams] = s_pos;
+	if (!s_last || threadIdx.x != 0)
+		return;
+	__threadfence();
+	uint32_t pos = 0, flags = 0;
+	for (int u = 0; u < n_units; u++) {
+		const int st = u / p.slice_num, ls = u % p.slice_num;
+		const uint32_t size = __hip_atomic_load(&p.nal_size[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t nbytes = (__hip_atomic_load(&p.unit_bits[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 7) >> 3;
+		uint32_t start_of_stream = 0;
+		if (ls == 0) {
+			start_of_stream = pos;
+			p.stream_size[st] = pos; // start of the stream, fixed up below
+			pos += p.prefix_len[st];
+		}
+		(void)start_of_stream;
+		p.nal_off[u] = pos;
+		pos += size;
+		if (ls == p.slice_num - 1)
+			p.stream_size[st] = pos - p.stream_size[st];
+		if (pos > (uint32_t)p.out_cap || nbytes + 8u > (uint32_t)p.rbsp_cap)
+			flags |= 2u;
+	}
+	p.stream_size[p.n_streams] = pos;
+	if (flags)
+		atomicOr(&p.stream_size[p.n_streams + 1], flags);
 }
 
 __global__ __launch_bounds__(256) void k_esc_write(Params p)
@@ -658,17 +1026,7 @@ __global__ __launch_bounds__(256) void k_esc_write(Params p)
 		o[4] = (uint8_t)((p.nal_ref_idc << 5) | p.nal_type);
 	}
 	o += 5 + start + p.esc_cnt[(size_t)unit * p.esc_chunks_cap + chunk];
-	const int end = start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes;
-	int z = zero_state_before(rb, start);
-	for (int i = start; i < end; i++) {
-		const uint8_t v = rb[i];
-		if (z == 2 && v <= 3) {
-			*o++ = 3;
-			z = 0;
-		}
-		*o++ = v;
-		z = v == 0 ? z + 1 : 0;
-	}
+	esc_chunk<true>(rb, start, start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes, o);
 }
 
 int Launch::entropy(const Params &p, void *stream)
@@ -676,12 +1034,23 @@ int Launch::entropy(const Params &p, void *stream)
 	hipStream_t s = (hipStream_t)stream;
 	const int n_units = p.n_streams * p.slice_num;
 	const int mbs = p.row_num * p.mb_w;
-	hipLaunchKernelGGL(k_cavlc, dim3((mbs + 63) / 64, p.n_streams), dim3(64), 0, s, p);
+	// Few macroblocks: k_cavlc2 (a lane per block, short chains; 1080p x 1: 0.04 ms against
+	// 0.25 ms). Many: k_cavlc (a thread per macroblock does ~1/3 of the instructions per
+	// macroblock; 1080p x 32: 0.40 ms against 1.38 ms).
+	static int version = -1;
+	if (version < 0) {
+		const char *e = getenv("CEDAR_CAVLC_V");
+		version = e ? atoi(e) : 0;
+	}
+	if (version == 2 || (version == 0 && (long)mbs * p.n_streams <= 40000))
+		hipLaunchKernelGGL(k_cavlc2, dim3((mbs + 1) / 2, p.n_streams), dim3(64), 0, s, p);
+	else
+		hipLaunchKernelGGL(k_cavlc, dim3((mbs + 63) / 64, p.n_streams), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k_scan, dim3(n_units), dim3(1024), 0, s, p);
 	hipLaunchKernelGGL(k_zero, dim3((p.rbsp_cap / 16 + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_pack, dim3((p.unit_mb_cap + 2 + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_esc_count, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
-	hipLaunchKernelGGL(k_esc_scan, dim3(1), dim3(1024), 0, s, p);
+	hipLaunchKernelGGL(k_esc_scan, dim3(n_units), dim3(1024), 0, s, p);
 	hipLaunchKernelGGL(k_esc_write, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
 	return (int)hipGetLastError();
 }

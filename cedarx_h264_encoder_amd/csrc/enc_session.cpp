@@ -575,11 +575,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	if ((rc = dalloc(e, &e->d_bit_off, (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
 	if ((rc = dalloc(e, &e->d_run, (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
 	if ((rc = dalloc(e, &e->d_unit_bits, (size_t)n_units))) return rc;
-	if ((rc = dalloc(e, &e->d_rbsp, (size_t)n_units * P.rbsp_cap))) return rc;
+	if ((rc = dalloc(e, &e->d_rbsp, (size_t)n_units * P.rbsp_cap + 64))) return rc; // + one escape chunk of read slack
 	if ((rc = dalloc(e, &e->d_esc, (size_t)n_units * P.esc_chunks_cap))) return rc;
 	if ((rc = dalloc(e, &e->d_nal_off, (size_t)n_units))) return rc;
 	if ((rc = dalloc(e, &e->d_nal_size, (size_t)n_units))) return rc;
-	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 2))) return rc;
+	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 3))) return rc;
 	if ((rc = dalloc(e, &e->d_out, e->out_cap))) return rc;
 	if ((rc = dalloc(e, &e->d_hdr, (size_t)ext.slice_num))) return rc;
 	if ((rc = dalloc(e, &e->d_prefix, (size_t)S))) return rc;
@@ -821,7 +821,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
 	HIP_TRY(e, hipMemcpyAsync(e->d_hdr, f.h_hdr, sizeof(SliceHdr) * e->ext.slice_num, hipMemcpyHostToDevice, e->s_ent));
 	HIP_TRY(e, hipMemcpyAsync(e->d_prefix, f.h_prefix, sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->s_ent));
-	HIP_TRY(e, hipMemsetAsync(e->d_stream_size, 0, sizeof(uint32_t) * (S + 2), e->s_ent));
+	HIP_TRY(e, hipMemsetAsync(e->d_stream_size, 0, sizeof(uint32_t) * (S + 3), e->s_ent));
 	if (Launch::entropy(P, e->s_ent))
 		return fail(e, -EIO, "entropy launch failed");
 	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
