@@ -171,7 +171,7 @@ def run_rank(args, rank, world, local_rank):
     if stage == "deblock" and st.get("deblock_planes_split"):
         # luma and chroma run as two concurrent kernels; the timed one (critical path) is luma:
         # 256 B read + 256 B written per macroblock
-        kname, tkey, per_mb = "k_deblock<planes=luma>", "deblock_luma", 512
+        kname, tkey, per_mb = "k_deblock2<planes=luma>", "deblock_luma", 512
     alg_bytes = per_mb * mb_per_launch
     if stage == "entropy":
         alg_bytes += nbytes / max(1, args.steps)
