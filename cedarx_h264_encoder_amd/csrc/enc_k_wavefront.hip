@@ -672,16 +672,31 @@ DEVI void lds_signal(int *word, int value, int lane)
 		__hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Everything a deblock workgroup keeps in LDS. It lives in DYNAMIC shared memory so that the
+// luma and the chroma instantiation can sit in one kernel (k_deblock2_planes: one launch, the
+// plane picked per workgroup) without their footprints adding up.
+template <int PL>
+struct Db2Shared {
+	Db2GroupLds g[DB2_PAIRS * 4];
+	// bottom rows of a band's last macroblock row, for the pair that filters the band below
+	uint8_t xbot[DB2_PAIRS][DB2_XRING][(PL & 1) ? 64 : 16];
+	uint8_t xbotc[DB2_PAIRS][DB2_XRING][(PL & 2) ? 32 : 16];
+	int staged[DB2_PAIRS], filtered[DB2_PAIRS];
+	int ticket;
+};
+
+extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+
 template <bool IDR, int PL>
-__global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
+DEVI void deblock2_body(const Params &p, const int wg)
 {
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
-	__shared__ __attribute__((aligned(16))) Db2GroupLds s_g[DB2_PAIRS * 4];
-	// bottom rows of a band's last macroblock row, for the pair that filters the band below
-	__shared__ __attribute__((aligned(16))) uint8_t s_xbot[DB2_PAIRS][DB2_XRING][DO_Y ? 64 : 16];
-	__shared__ __attribute__((aligned(16))) uint8_t s_xbotc[DB2_PAIRS][DB2_XRING][DO_C ? 32 : 16];
-	__shared__ int s_staged[DB2_PAIRS], s_filtered[DB2_PAIRS];
-	__shared__ int s_ticket;
+	Db2Shared<PL> &S = *reinterpret_cast<Db2Shared<PL> *>(dyn_lds);
+	Db2GroupLds *s_g = S.g;
+	auto &s_xbot = S.xbot;
+	auto &s_xbotc = S.xbotc;
+	int *s_staged = S.staged, *s_filtered = S.filtered;
+	int &s_ticket = S.ticket;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	// waves land on SIMD wave%4: filter k on SIMD k%4, its mover on SIMD (k+2)%4, so the
@@ -692,7 +707,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 	const int NWG = p.wf_split;
 	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
 	if (threadIdx.x == 0)
-		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
+		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : wg;
 	if (threadIdx.x < DB2_PAIRS) {
 		s_staged[threadIdx.x] = 0;
 		s_filtered[threadIdx.x] = 0;
@@ -1123,6 +1138,26 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2(Params p)
 		if (lane == 0 && s_ticket <= 1 && pair <= 2 && iter == 0 && !IDR && PL == 1)
 			printf("mover PL%d wg %d pair %d: total %lld wait-filter %lld blocked-on-top %lld\n", PL, s_ticket, pair, (__builtin_readcyclecounter() - mt0) / nsteps, mw / nsteps, mb / nsteps);
 #endif
+	}
+}
+
+// planes: 1 luma, 2 chroma, 3 both planes in every wave pair (many units), 4 both planes in
+// one launch as separate workgroups (first half of the grid luma, second half chroma)
+template <bool IDR>
+__global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2_planes(Params p, int planes)
+{
+	const int nwg = p.n_streams * p.slice_num * p.wf_split;
+	if (planes == 4) {
+		if ((int)blockIdx.x < nwg)
+			deblock2_body<IDR, 1>(p, (int)blockIdx.x);
+		else
+			deblock2_body<IDR, 2>(p, (int)blockIdx.x - nwg);
+	} else if (planes == 1) {
+		deblock2_body<IDR, 1>(p, (int)blockIdx.x);
+	} else if (planes == 2) {
+		deblock2_body<IDR, 2>(p, (int)blockIdx.x);
+	} else {
+		deblock2_body<IDR, 3>(p, (int)blockIdx.x);
 	}
 }
 
@@ -1738,18 +1773,22 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 
 int Launch::deblock(const Params &p, void *stream, int planes)
 {
-	dim3 grid(p.n_streams * p.slice_num * p.wf_split);
+	const int nwg = p.n_streams * p.slice_num * p.wf_split;
 	hipStream_t s = (hipStream_t)stream;
-	// 116 KiB of static LDS: one workgroup per CU by construction
-	if (p.is_idr) {
-		if (planes == 1) hipLaunchKernelGGL((k_deblock2<true, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
-		else if (planes == 2) hipLaunchKernelGGL((k_deblock2<true, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
-		else hipLaunchKernelGGL((k_deblock2<true, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
-	} else {
-		if (planes == 1) hipLaunchKernelGGL((k_deblock2<false, 1>), grid, dim3(64 * WF_WAVES), 0, s, p);
-		else if (planes == 2) hipLaunchKernelGGL((k_deblock2<false, 2>), grid, dim3(64 * WF_WAVES), 0, s, p);
-		else hipLaunchKernelGGL((k_deblock2<false, 3>), grid, dim3(64 * WF_WAVES), 0, s, p);
+	// ~130 KiB of dynamic LDS: one workgroup per CU by construction
+	const size_t lds = sizeof(Db2Shared<1>) > sizeof(Db2Shared<3>) ? sizeof(Db2Shared<1>) : sizeof(Db2Shared<3>);
+	static bool attr_set = false;
+	if (!attr_set) {
+		if (hipFuncSetAttribute((const void *)k_deblock2_planes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+			return -1;
+		attr_set = true;
 	}
+	dim3 grid(planes == 4 ? 2 * nwg : nwg);
+	if (p.is_idr)
+		hipLaunchKernelGGL(k_deblock2_planes<true>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+	else
+		hipLaunchKernelGGL(k_deblock2_planes<false>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
 	return (int)hipGetLastError();
 }
 

@@ -838,16 +838,10 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 
 	// ---- in-loop deblocking: produces the next frame's reference ----
 	tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
-	if (e->split_planes) {
-		// luma and chroma are independent wavefronts: chroma on its own stream / CUs
-		HIP_TRY(e, hipStreamWaitEvent(e->s_aux, e->ev_analysis, 0));
-		if (Launch::deblock(P, e->s_aux, 2) || Launch::deblock(P, e->s_main, 1))
-			return fail(e, -EIO, "k_deblock launch failed");
-		HIP_TRY(e, hipEventRecord(e->ev_chroma, e->s_aux));
-		HIP_TRY(e, hipStreamWaitEvent(e->s_main, e->ev_chroma, 0));
-	} else if (Launch::deblock(P, e->s_main, 3)) {
+	// luma and chroma are independent wavefronts: one launch, the plane picked per workgroup
+	// (few units), or both planes in every wave pair (many units: CUs are the scarce thing)
+	if (Launch::deblock(P, e->s_main, e->split_planes ? 4 : 3))
 		return fail(e, -EIO, "k_deblock launch failed");
-	}
 	tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
 	// the frame is complete when both streams are (collect waits for both events)
 	HIP_TRY(e, hipEventRecord(f.done_main, e->s_main));
