@@ -25,6 +25,11 @@ import ctypes
 import hashlib
 import json
 import os
+
+# the encoder's frame pipelining wants more hardware queues than the HIP runtime's default 4;
+# read when the runtime starts, so it has to be in the environment before the first HIP call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import sys
 import time
 
@@ -117,12 +122,18 @@ def run_rank(args, rank, world, local_rank):
         enc.reset_stats()
         barrier()
         t0 = time.perf_counter()
-        # pipelined: one frame in flight behind the one being submitted
-        feed(warmup)
-        for i in range(warmup + 1, warmup + steps):
+        # pipelined: as many frames in flight as the session allows (cedar_enc_submit / collect)
+        depth = enc.pipeline_depth
+        in_flight = 0
+        for i in range(warmup, warmup + steps):
+            if in_flight == depth:
+                nbytes += enc.collect()
+                in_flight -= 1
             feed(i)
+            in_flight += 1
+        while in_flight:
             nbytes += enc.collect()
-        nbytes += enc.collect()
+            in_flight -= 1
         barrier()
         dt = time.perf_counter() - t0
         st = enc.stats()
@@ -133,7 +144,7 @@ def run_rank(args, rank, world, local_rank):
     sweep = [int(x) for x in str(args.batched_streams).split(",") if x.strip() and int(x) > 0 and int(x) != S]
     # at most 8 distinct synthetic streams are generated; larger batches reuse them cyclically
     inputs = make_inputs(max(S, min(8, max(sweep + [1]))))
-    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, True)
+    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, os.environ.get("BENCH_NO_PROFILE") is None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -39,6 +39,8 @@ constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
 constexpr int WF_MAX_SPLIT = 8;   // workgroups sharing one unit's wavefront
 constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress
+constexpr int PROG_BANDS = 128;     // deblock bands (4 macroblock rows) per unit with a progress word
+constexpr int PROG_ALL = 0xffff;     // progress value: everything through
 constexpr int IN_K_STREAMS = 8;     // up to this many streams pass their frame pointers as kernel arguments
 constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
@@ -104,6 +106,17 @@ struct Params {
 	uint64_t *wf_hbuf;               // [n_units][wf_split-1][mb_w][WF_HBUF_GRANULES]
 	int32_t wf_split;                // workgroups per unit: deblock
 	int32_t wf_split_intra;          // workgroups per unit: intra recon
+	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
+	// picture along diagonals s = x + 2*y (absolute macroblock coordinates), so progress is
+	// counted in diagonals: "every macroblock with x + 2*y < D is through". Words live in device
+	// memory, are written with agent-scope release and polled by kernels of other streams.
+	// A value is (frame tag << 16 | D), compared modulo 2^32: a slot's words never need zeroing
+	// and the stale value of the frame that used the slot before reads as "nothing yet".
+	uint32_t *prog_inter;            // [1] D of this frame's analysis + reconstruction (all streams)
+	uint32_t *prog_db;               // [2][n_units][PROG_BANDS] D of every deblock band written back: luma, then chroma
+	const uint32_t *prev_db;         // the previous frame's prog_db (what k_gate waits for)
+	uint32_t prog_tag, prev_tag;
+	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + 2*y < s1 (stripe_s1 <= 0: the whole picture)
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
@@ -144,7 +157,15 @@ struct Launch {
 	static int input(const Params &p, void *stream);
 	static int intra_decide(const Params &p, void *stream);
 	static int intra_recon(const Params &p, void *stream);
-	static int inter(const Params &p, void *stream);
+	static int inter(const Params &p, void *stream);   // diagonals [stripe_s0, stripe_s1)
+	// 1 wave: publish prog_inter = publish_d (if >= 0), then wait until every deblock band of the
+	// previous frame has written back all macroblocks with x + 2*y < need_d (if > 0)
+	static int gate(const Params &p, void *stream, int publish_d, int need_d);
+	// 1 thread: *word = value with system scope (completion flags in pinned host memory)
+	static int flag(void *stream, uint32_t *word, uint32_t value);
+	// concurrency probe: does a kernel on `waiter` see a flag set by a later launch on `setter`?
+	// (HIP maps streams onto few hardware queues; two streams on one queue run back to back)
+	static int probe_overlap(void *waiter, void *setter, uint32_t *d_words, bool *overlaps);
 	static int deblock(const Params &p, void *stream, int planes); // 1 luma, 2 chroma, 3 both
 	static int entropy(const Params &p, void *stream); // cavlc, scan, pack, escape
 };

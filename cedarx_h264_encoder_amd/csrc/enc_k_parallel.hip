@@ -45,12 +45,13 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 	const int seg = blockIdx.x * blockDim.x + threadIdx.x;
 	const int row = blockIdx.y; // [0, ch) luma, [ch, ch + ch/2) chroma
 	const int st = blockIdx.z;
-	// first job of every frame on this stream: the ticket / abort / progress words of the
-	// three wavefront kernels start at zero (one memset launch less per frame)
-	if (row == 0 && st == 0 && (p.wf_split > 1 || p.wf_split_intra > 1)) {
+	// first job of every frame on this stream: the ticket / abort / progress words of the intra
+	// wavefront kernel (region 0) start at zero; the deblock regions are cleared on the deblock
+	// kernel's own stream
+	if (row == 0 && st == 0 && p.wf_split_intra > 1) {
 		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
-		for (int i = seg; i < 3 * used; i += gridDim.x * blockDim.x)
-			p.wf_sync[(i / used) * WF_SYNC_WORDS + i % used] = 0;
+		for (int i = seg; i < used; i += gridDim.x * blockDim.x)
+			p.wf_sync[i] = 0;
 	}
 	if (seg >= segs)
 		return;
@@ -106,6 +107,25 @@ int Launch::input(const Params &p, void *stream)
 #define REF_STRIDE 48
 #define REFC_STRIDE 64
 
+// k_inter covers the diagonals stripe_s0 <= x + 2*y < stripe_s1 of every stream (the whole
+// picture when stripe_s1 <= 0). Returns false for the blocks of a stripe that fall outside.
+DEVI bool stripe_mb(const Params &p, int &mx, int &my, int &st)
+{
+	if (p.stripe_s1 <= 0) {
+		xcd_mb(p, mx, my, st);
+		return true;
+	}
+	const uint32_t nb = gridDim.x, hb = blockIdx.x;
+	const uint32_t xcd = hb & 7u, i = hb >> 3, q = nb >> 3, r = nb & 7u;
+	const uint32_t lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+	const uint32_t w = (uint32_t)(p.stripe_s1 - p.stripe_s0), per_stream = w * (uint32_t)p.row_num;
+	st = (int)(lb / per_stream);
+	const uint32_t m = lb - (uint32_t)st * per_stream;
+	my = p.row_first + (int)(m / w);
+	mx = p.stripe_s0 - 2 * my + (int)(m % w);
+	return mx >= 0 && mx < p.mb_w;
+}
+
 __global__ __launch_bounds__(64) void k_inter(Params p)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_ref[48 * REF_STRIDE + 64];
@@ -120,7 +140,8 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 
 	const int lane = threadIdx.x;
 	int mx, my, st;
-	xcd_mb(p, mx, my, st);
+	if (!stripe_mb(p, mx, my, st))
+		return;
 	const int x0 = mx * 16, y0 = my * 16;
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
@@ -340,8 +361,106 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 
 int Launch::inter(const Params &p, void *stream)
 {
-	dim3 grid(p.mb_w * p.row_num * p.n_streams);
+	dim3 grid((p.stripe_s1 > 0 ? p.stripe_s1 - p.stripe_s0 : p.mb_w) * p.row_num * p.n_streams);
 	hipLaunchKernelGGL(k_inter, grid, dim3(64), 0, (hipStream_t)stream, p);
+	return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// k_gate: the only place a frame WAITS for the frame before it. One wave. A P picture is
+// analysed in a few diagonal stripes; in front of stripe [s0, s1) this kernel (1) publishes
+// how far this frame's analysis has come (the deblock kernel of this frame, already running
+// on another stream, polls that word) and (2) spins until every deblock band of the previous
+// frame has written back the macroblocks with x + 2*y < need_d: the motion search of (x, y)
+// reads the final samples of (x-1..x+1, y-1..y+1), final once their right and lower
+// neighbours are filtered, i.e. need_d = s1 + 5.
+// Spins are bounded: a time-out leaves an error code and lets the stream drain.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d)
+{
+	const int lane = threadIdx.x;
+	if (lane == 0 && publish_d >= 0 && p.prog_inter) // the launches before this one have completed (stream order)
+		__hip_atomic_store(p.prog_inter, p.prog_tag | (uint32_t)publish_d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	if (need_d <= 0 || !p.prev_db)
+		return;
+	const int n_units = p.n_streams * p.slice_num;
+	const int n = 2 * n_units * PROG_BANDS;
+	for (int e0 = 0; e0 < n; e0 += 64) {
+		const int e = e0 + lane;
+		bool pending = false;
+		if (e < n) {
+			const int band = e % PROG_BANDS, unit = (e / PROG_BANDS) % n_units;
+			int r0, r1;
+			slice_rows(p.mb_h, p.slice_count, p.slice_first + unit % p.slice_num, &r0, &r1);
+			// a band owns the diagonals from 2*(r0 + 4*band) on: nothing of it is below that
+			pending = band < ((r1 - r0 + 3) >> 2) && 2 * (r0 + 4 * band) < need_d;
+		}
+		uint32_t spins = 0;
+		while (true) {
+			if (pending) {
+				const uint32_t v = __hip_atomic_load(&p.prev_db[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				pending = (int32_t)(v - (p.prev_tag | (uint32_t)need_d)) < 0;
+			}
+			if (!__any(pending))
+				break;
+			if (++spins > (1u << 20)) {
+				if (lane == 0)
+					__hip_atomic_store(p.wf_err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				return;
+			}
+			__builtin_amdgcn_s_sleep(32);
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ void k_flag(uint32_t *word, uint32_t value)
+{
+	__hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int Launch::flag(void *stream, uint32_t *word, uint32_t value)
+{
+	hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, (hipStream_t)stream, word, value);
+	return (int)hipGetLastError();
+}
+
+__global__ void k_probe_wait(uint32_t *w)
+{
+	// bounded: ~20 ms at most if the setter never runs beside us
+	for (int i = 0; i < (1 << 15); i++) {
+		if (__hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+			w[1] = 1;
+			return;
+		}
+		__builtin_amdgcn_s_sleep(64);
+	}
+	w[1] = 0;
+}
+
+__global__ void k_probe_set(uint32_t *w)
+{
+	__hip_atomic_store(&w[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int Launch::probe_overlap(void *waiter, void *setter, uint32_t *d_words, bool *overlaps)
+{
+	uint32_t h[2] = { 0, 0 };
+	if (hipMemcpy(d_words, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess)
+		return -1;
+	hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, (hipStream_t)waiter, d_words);
+	hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, (hipStream_t)setter, d_words);
+	if (hipStreamSynchronize((hipStream_t)waiter) != hipSuccess || hipStreamSynchronize((hipStream_t)setter) != hipSuccess)
+		return -1;
+	if (hipMemcpy(h, d_words, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+		return -1;
+	*overlaps = h[1] != 0;
+	return 0;
+}
+
+int Launch::gate(const Params &p, void *stream, int publish_d, int need_d)
+{
+	hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, p, publish_d, need_d);
 	return (int)hipGetLastError();
 }
 

@@ -712,6 +712,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		s_staged[threadIdx.x] = 0;
 		s_filtered[threadIdx.x] = 0;
 	}
+
 	__syncthreads();
 	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
 	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
@@ -926,6 +927,43 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		}
 
 		// ============================== mover wave ==============================
+		// Frame pipelining: this frame's analysis runs ahead of us on another stream in diagonal
+		// stripes (prog_inter), and the next frame's analysis follows OUR write-back (prog_db).
+		// All four rows of the band are on the same diagonal at every step: x + 2*y = t + diag0.
+		const int diag0 = 2 * (r0 + 4 * band);
+		uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
+		uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
+		auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
+			const uint32_t need = (uint32_t)(t + diag0 + 1);
+			if (inter_seen >= need)
+				return;
+			uint32_t spins = 0;
+			while (true) {
+				const uint32_t v = __hip_atomic_load(p.prog_inter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((int32_t)(v - (p.prog_tag | need)) >= 0) {
+					inter_seen = v & 0xffffu;
+					break;
+				}
+				if (++spins > (1u << 22)) {
+					__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					inter_seen = 0x7fffffffu;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(16);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		};
+		auto publish_diag = [&](uint32_t d) { // every macroblock of this band with x + 2*y < d is written back
+			if (!my_prog)
+				return;
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			if (lane == 0) {
+				__hip_atomic_store(my_prog, p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (PL == 3)
+					__hip_atomic_store(my_prog + p.n_streams * p.slice_num * PROG_BANDS, p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		};
 		const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
 		// two register sets: the loads of step t+3 are issued while step t+1 is staged (memory
 		// latency here is about one whole step)
@@ -947,6 +985,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			const int cmx = nact ? nmx : 0;
 			const size_t a = row_mb + cmx;
 			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
+			if (t < nsteps)
+				wait_analysis(t < p.mb_w + 6 ? t : p.mb_w + 5);
 			// readiness of the rows above first: its acquire must not sit behind this step's own loads
 			R.top_ok = true;
 			if (xwg_band && mx0 < p.mb_w) { // rows above live in another workgroup
@@ -1103,6 +1143,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			mw += c1 - c0;
 #endif
 			publish();
+			if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
+				publish_diag((uint32_t)(t - 1 + diag0));
 			if (t + 1 < nsteps) {
 #ifdef DB2_TIMING
 				long long c2 = __builtin_readcyclecounter();
@@ -1113,8 +1155,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				mb += __builtin_readcyclecounter() - c2;
 #endif
 				stage_step(t + 1, R);
-				load_step(t + 3, false, R);
 				lds_signal(&s_staged[pair], base + t + 2, lane);
+				load_step(t + 3, false, R); // may wait for this frame's analysis: after the filter wave has its tile
 			}
 			if (t >= 1)
 				writeback_step(t - 1);
@@ -1134,6 +1176,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				mover_iter(t + 1, RA);
 		}
 		publish();
+		publish_diag((uint32_t)PROG_ALL);
 #ifdef DB2_TIMING
 		if (lane == 0 && s_ticket <= 1 && pair <= 2 && iter == 0 && !IDR && PL == 1)
 			printf("mover PL%d wg %d pair %d: total %lld wait-filter %lld blocked-on-top %lld\n", PL, s_ticket, pair, (__builtin_readcyclecounter() - mt0) / nsteps, mw / nsteps, mb / nsteps);

@@ -16,6 +16,10 @@
 
 #include <vector>
 
+#include <sched.h>
+
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include "../../include/cedar_h264enc.h"
@@ -24,6 +28,9 @@
 using namespace cedar;
 
 namespace {
+
+constexpr int DB_STREAMS = 3;
+constexpr int AN_STREAMS = 3;
 
 // ---- ITU-T H.264 constants needed on the host (clauses 8.5.9, 8.7.2) ----
 const uint16_t kQuantMF[6][3] = { // class 0 even/even, 1 odd/odd, 2 mixed
@@ -128,11 +135,18 @@ struct InFlight {
 	int host_out = 0;      // which host output buffer receives this frame
 	uint32_t spec_bytes = 0; // bytes copied speculatively with the frame
 	bool with_ps = false;  // SPS+PPS precede this frame's slices
-	hipEvent_t done_main = nullptr, done_ent = nullptr;
+	hipEvent_t done_main = nullptr, done_ent = nullptr; // done_main: reconstruction deblocked (stream s_db)
+	int ds = 0; // device slot (frame number % depth) holding this frame's device-side state
 	SliceHdr *h_hdr = nullptr;   // pinned staging for the per-frame slice headers
 	uint32_t *h_prefix = nullptr;
 	uint32_t *h_wf_err = nullptr; // pinned word the wavefront kernels write an error code to
 	uint32_t *d_wf_err = nullptr; // the same word as the device sees it
+	// completion flags in pinned host memory, written by 1-thread kernels at the end of the
+	// frame's entropy ([0]) and deblock ([1]) work. collect polls them: hipEventSynchronize on a
+	// stream that already holds later frames waits for those too.
+	volatile uint32_t *h_done = nullptr;
+	uint32_t *d_done = nullptr;
+	uint32_t done_tag = 0;
 	Timing tm;
 };
 
@@ -154,40 +168,55 @@ struct cedar_enc {
 	uint8_t **d_in_ptrs = nullptr; // [2*n_streams]
 	std::vector<const uint8_t *> h_in_ptrs;
 	bool in_ptrs_dirty = true;
-	uint8_t *d_src_y = nullptr, *d_src_uv = nullptr;
+	// per frame in flight (slot): source planes, records, levels, wavefront sync + progress words
+	uint8_t *d_src_y[CEDAR_ENC_PIPELINE_DEPTH] = {}, *d_src_uv[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint8_t *d_rec_y[2] = { nullptr, nullptr }, *d_rec_uv[2] = { nullptr, nullptr };
-	MbInfo *d_mbi[2] = { nullptr, nullptr };
-	int8_t *d_i4[2] = { nullptr, nullptr };
-	uint8_t *d_nnz[2] = { nullptr, nullptr };
-	int16_t *d_coef[2] = { nullptr, nullptr };
+	MbInfo *d_mbi[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	int8_t *d_i4[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint8_t *d_nnz[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	int16_t *d_coef[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint32_t *d_slot = nullptr, *d_mb_bits = nullptr;
 	uint8_t *d_skip = nullptr;
 	uint32_t *d_bit_off = nullptr, *d_run = nullptr, *d_unit_bits = nullptr;
 	uint8_t *d_rbsp = nullptr;
 	uint32_t *d_esc = nullptr, *d_nal_off = nullptr, *d_nal_size = nullptr, *d_stream_size = nullptr;
-	uint8_t *d_out = nullptr;
+	uint8_t *d_out[CEDAR_ENC_PIPELINE_DEPTH] = {}; // compact bytestreams, one per frame in flight
 	SliceHdr *d_hdr = nullptr;
 	uint32_t *d_prefix = nullptr;
 	uint8_t *d_pred4 = nullptr;
-	uint32_t *d_wf_sync = nullptr;
-	uint64_t *d_wf_hbuf = nullptr;
+	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint64_t *d_wf_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint32_t *d_prog[CEDAR_ENC_PIPELINE_DEPTH] = {}; // [0] prog_inter, [16..) prog_db[2][n_units]
+	bool row_pipe = false;      // consecutive frames overlap along the wavefront diagonals (few units)
+	int db_streams = 1;         // deblock streams that really run beside s_main and each other
+	int inter_bands = 1;
+	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
 	int wf_split = 1, wf_split_intra = 1;
 	// pinned host memory
 	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
-	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = { nullptr, nullptr };
-	uint32_t *h_sizes[CEDAR_ENC_PIPELINE_DEPTH] = { nullptr, nullptr };
+	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint32_t *h_sizes[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	size_t out_cap = 0;
 	// streams / events
-	hipStream_t s_main = nullptr, s_ent = nullptr, s_aux = nullptr;
-	hipEvent_t ev_chroma = nullptr;
+	// s_main: input + analysis of all frames in order; s_db[frame % DB_STREAMS]: deblocking (the
+	// deblock kernels of consecutive frames overlap); s_ent: entropy coding + read-back. The HIP
+	// runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them
+	// the null stream's); streams sharing a queue run back to back, so the session asks for 8
+	// before the runtime starts and probes what it got (see config).
+	hipStream_t s_main = nullptr, s_ent = nullptr, s_db[DB_STREAMS] = {};
+	hipStream_t s_ana[AN_STREAMS] = {}; // analysis streams; s_ana[0] == s_main
+	int an_streams = 1;
 	bool split_planes = true;
-	hipEvent_t ev_input = nullptr, ev_analysis = nullptr;
+	hipEvent_t ev_host_in = nullptr; // pinned input buffers consumed
+	// per device slot: source planes + sync words ready (s_main), records complete (s_main),
+	// reconstruction deblocked (s_db)
+	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH] = {}, ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	InFlight fl[CEDAR_ENC_PIPELINE_DEPTH];
 	int fl_head = 0, fl_count = 0; // ring of frames in flight
 	// results of the last collected frame
 	std::vector<uint32_t> res_off, res_size;
 	int res_host = 0;
-	int last_parity = 0, last_rec = 0;
+	int last_slot = 0, last_rec = 0;
 	std::vector<uint8_t> sps_pps;
 	// stats
 	bool profiling = false;
@@ -228,31 +257,39 @@ void free_all(cedar_enc *e)
 {
 	auto F = [](void *p) { if (p) hipFree(p); };
 	auto H = [](void *p) { if (p) hipHostFree(p); };
-	F(e->d_in_y); F(e->d_in_uv); F((void *)e->d_in_ptrs); F(e->d_src_y); F(e->d_src_uv);
+	F(e->d_in_y); F(e->d_in_uv); F((void *)e->d_in_ptrs);
 	for (int i = 0; i < 2; i++) {
-		F(e->d_rec_y[i]); F(e->d_rec_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
+		F(e->d_rec_y[i]); F(e->d_rec_uv[i]);
+	}
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
+		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
 	F(e->d_slot); F(e->d_mb_bits); F(e->d_skip); F(e->d_bit_off); F(e->d_run); F(e->d_unit_bits);
-	F(e->d_rbsp); F(e->d_esc); F(e->d_nal_off); F(e->d_nal_size); F(e->d_stream_size); F(e->d_out);
-	F(e->d_hdr); F(e->d_prefix); F(e->d_pred4); F(e->d_wf_sync); F(e->d_wf_hbuf);
+	F(e->d_rbsp); F(e->d_esc); F(e->d_nal_off); F(e->d_nal_size); F(e->d_stream_size);
+	F(e->d_hdr); F(e->d_prefix); F(e->d_pred4);
 	H(e->h_luma); H(e->h_chroma);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
-		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_wf_err);
+		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_wf_err); H((void *)e->fl[i].h_done);
 		if (e->fl[i].done_main)
 			hipEventDestroy(e->fl[i].done_main);
 		if (e->fl[i].done_ent)
 			hipEventDestroy(e->fl[i].done_ent);
+		if (e->ev_input[i]) hipEventDestroy(e->ev_input[i]);
+		if (e->ev_analysis[i]) hipEventDestroy(e->ev_analysis[i]);
+		if (e->ev_deblocked[i]) hipEventDestroy(e->ev_deblocked[i]);
 		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
 			for (int k = 0; k < 2; k++)
 				if (e->fl[i].tm.ev[s][k])
 					hipEventDestroy(e->fl[i].tm.ev[s][k]);
 	}
-	if (e->ev_input) hipEventDestroy(e->ev_input);
-	if (e->ev_analysis) hipEventDestroy(e->ev_analysis);
+	if (e->ev_host_in) hipEventDestroy(e->ev_host_in);
 	if (e->s_main) hipStreamDestroy(e->s_main);
+	for (int i = 1; i < AN_STREAMS; i++)
+		if (e->s_ana[i]) hipStreamDestroy(e->s_ana[i]);
 	if (e->s_ent) hipStreamDestroy(e->s_ent);
-	if (e->s_aux) hipStreamDestroy(e->s_aux);
-	if (e->ev_chroma) hipEventDestroy(e->ev_chroma);
+	for (int i = 0; i < DB_STREAMS; i++)
+		if (e->s_db[i]) hipStreamDestroy(e->s_db[i]);
 }
 
 // SPS (cedar.c:892-937) + PPS (cedar.c:939-982)
@@ -442,6 +479,9 @@ extern "C" const char *cedar_enc_version(void)
 
 extern "C" cedar_enc *cedar_enc_open(void)
 {
+	// More hardware queues than the runtime's default 4 (takes effect if HIP has not started yet
+	// in this process; the session probes what it really got and adapts)
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
 		errno = ENODEV; // no CPU fallback: the encode path exists only as HIP kernels
@@ -542,6 +582,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_wf_err, sizeof(uint32_t), hipHostMallocMapped));
 		*e->fl[i].h_wf_err = 0;
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].d_wf_err, e->fl[i].h_wf_err, 0));
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_done, 2 * sizeof(uint32_t), hipHostMallocMapped));
+		e->fl[i].h_done[0] = e->fl[i].h_done[1] = 0;
+		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].d_done, (void *)e->fl[i].h_done, 0));
 	}
 	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
 	P.plane_y_stride = (int64_t)plane_y;
@@ -549,11 +592,13 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S))) return rc;
 	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S))) return rc;
 	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S))) return rc;
-	if ((rc = dalloc(e, &e->d_src_y, plane_y * S))) return rc;
-	if ((rc = dalloc(e, &e->d_src_uv, plane_uv * S))) return rc;
 	for (int i = 0; i < 2; i++) {
 		if ((rc = dalloc(e, &e->d_rec_y[i], plane_y * S))) return rc;
 		if ((rc = dalloc(e, &e->d_rec_uv[i], plane_uv * S))) return rc;
+	}
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		if ((rc = dalloc(e, &e->d_src_y[i], plane_y * S))) return rc;
+		if ((rc = dalloc(e, &e->d_src_uv[i], plane_uv * S))) return rc;
 		if ((rc = dalloc(e, &e->d_mbi[i], (size_t)P.n_mb * S))) return rc;
 		if ((rc = dalloc(e, &e->d_i4[i], (size_t)P.n_mb * S * 16))) return rc;
 		if ((rc = dalloc(e, &e->d_nnz[i], (size_t)P.n_mb * S * NNZ_PER_MB))) return rc;
@@ -580,7 +625,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	if ((rc = dalloc(e, &e->d_nal_off, (size_t)n_units))) return rc;
 	if ((rc = dalloc(e, &e->d_nal_size, (size_t)n_units))) return rc;
 	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 3))) return rc;
-	if ((rc = dalloc(e, &e->d_out, e->out_cap))) return rc;
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++)
+		if ((rc = dalloc(e, &e->d_out[i], e->out_cap))) return rc;
 	if ((rc = dalloc(e, &e->d_hdr, (size_t)ext.slice_num))) return rc;
 	if ((rc = dalloc(e, &e->d_prefix, (size_t)S))) return rc;
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
@@ -613,8 +659,15 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 8 ? 8 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
 		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 2) / 3);
 	}
-	if ((rc = dalloc(e, &e->d_wf_sync, (size_t)3 * WF_SYNC_WORDS))) return rc;
-	if ((rc = dalloc(e, &e->d_wf_hbuf, (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc;
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)3 * WF_SYNC_WORDS))) return rc;
+		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc;
+		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 2 * n_units * PROG_BANDS))) return rc;
+		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 2 * (size_t)n_units * PROG_BANDS)));
+	}
+	{
+		e->prev_slot = e->prev2_slot = -1;
+	}
 	uint8_t tab[9 * 16];
 	build_pred4_table(tab);
 	HIP_TRY(e, hipMemcpy(e->d_pred4, tab, sizeof(tab), hipMemcpyHostToDevice));
@@ -626,17 +679,78 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	e->in_ptrs_dirty = true;
 
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+	e->s_ana[0] = e->s_main;
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
-	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_aux, hipStreamNonBlocking));
-	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_chroma, hipEventDisableTiming));
+	for (int i = 0; i < DB_STREAMS; i++)
+		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_db[i], hipStreamNonBlocking));
+	for (int i = 1; i < AN_STREAMS; i++)
+		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ana[i], hipStreamNonBlocking));
 	{
 		const char *env = getenv("CEDAR_DEBLOCK_PLANES");
 		e->split_planes = env ? atoi(env) != 0 : n_units <= 32; // two concurrent wavefronts while CUs are spare
 	}
-	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming));
-	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis, hipEventDisableTiming));
+	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_host_in, hipEventDisableTiming));
+	{
+		// Frame pipelining needs kernels of s_main and of the deblock streams to be on the GPU at
+		// the same time (they poll each other's progress words). Probe it: a stream that shares
+		// its hardware queue with s_main would wait forever (until the spin bound) otherwise.
+		// And it must leave the GPU mostly free: a pipelined deblock kernel is resident (one CU per
+		// workgroup, nothing else fits beside it) while it waits for its frame's analysis, so the
+		// deblock workgroups of all frames in flight may only take a fraction of the CUs, or the
+		// analysis they wait for finds no CU to run on.
+		int cus = 0;
+		HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+		const char *env = getenv("CEDAR_ROW_PIPE");
+		bool want = env ? atoi(env) != 0 : 2 * n_units * e->wf_split * DB_STREAMS <= cus / 2;
+		int usable = 0;
+		for (int i = 0; want && i < DB_STREAMS; i++) {
+			bool ok = false, ok2 = true;
+			if (Launch::probe_overlap(e->s_db[i], e->s_main, e->d_prog[0], &ok))
+				return fail(e, -EIO, "stream probe failed");
+			for (int j = 0; ok && j < usable; j++) // and beside the deblock streams already accepted
+				if (Launch::probe_overlap(e->s_db[i], e->s_db[j], e->d_prog[0], &ok2) || !ok2)
+					ok = false;
+			if (ok) {
+				hipStream_t t = e->s_db[usable];
+				e->s_db[usable] = e->s_db[i];
+				e->s_db[i] = t;
+				usable++;
+			}
+		}
+		HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+		e->row_pipe = want && usable >= 1;
+		e->db_streams = usable >= 1 ? usable : 1;
+		// further analysis streams: each must run beside every deblock stream and every analysis
+		// stream already accepted (a frame's gate kernels spin while the next frame's run)
+		int an = 1;
+		const char *enva = getenv("CEDAR_ANALYSIS_STREAMS");
+		const int an_max = enva ? atoi(enva) : AN_STREAMS;
+		for (int i = 1; e->row_pipe && i < AN_STREAMS && an < an_max; i++) {
+			bool ok = true, o = false;
+			for (int j = 0; ok && j < e->db_streams; j++)
+				if (Launch::probe_overlap(e->s_ana[i], e->s_db[j], e->d_prog[0], &o) || !o)
+					ok = false;
+			for (int j = 0; ok && j < an; j++)
+				if (Launch::probe_overlap(e->s_ana[i], e->s_ana[j], e->d_prog[0], &o) || !o)
+					ok = false;
+			if (ok) {
+				hipStream_t t = e->s_ana[an];
+				e->s_ana[an] = e->s_ana[i];
+				e->s_ana[i] = t;
+				an++;
+			}
+		}
+		e->an_streams = an;
+		const char *envb = getenv("CEDAR_INTER_BANDS");
+		int nb = envb ? atoi(envb) : 5;
+		if (nb > 64) nb = 64;
+		e->inter_bands = e->row_pipe ? (nb < 1 ? 1 : nb) : 1;
+	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
+		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input[i], hipEventDisableTiming));
+		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis[i], hipEventDisableTiming));
+		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_deblocked[i], hipEventDisableTiming));
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_ent, hipEventDisableTiming));
 		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
 			for (int k = 0; k < 2; k++)
@@ -647,8 +761,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	// static device pointers
 	P.in_luma = (const uint8_t *const *)e->d_in_ptrs;
 	P.in_chroma = (const uint8_t *const *)(e->d_in_ptrs + S);
-	P.src_y = e->d_src_y;
-	P.src_uv = e->d_src_uv;
+	P.src_y = e->d_src_y[0];
+	P.src_uv = e->d_src_uv[0];
 	P.slot = e->d_slot;
 	P.mb_bits = e->d_mb_bits;
 	P.skip = e->d_skip;
@@ -661,12 +775,18 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.nal_off = e->d_nal_off;
 	P.nal_size = e->d_nal_size;
 	P.stream_size = e->d_stream_size;
-	P.out = e->d_out;
+	P.out = e->d_out[0];
 	P.hdr = e->d_hdr;
 	P.prefix_len = e->d_prefix;
 	P.pred4_tab = e->d_pred4;
-	P.wf_sync = e->d_wf_sync;
-	P.wf_hbuf = e->d_wf_hbuf;
+	P.wf_sync = e->d_wf_sync[0];
+	P.wf_hbuf = e->d_wf_hbuf[0];
+	P.prog_inter = nullptr;
+	P.prog_db = nullptr;
+	P.prev_db = nullptr;
+	P.stripe_s0 = 0;
+	P.stripe_s1 = 0;
+	P.prog_tag = P.prev_tag = 0;
 	P.wf_split = e->wf_split;
 	P.wf_split_intra = e->wf_split_intra;
 
@@ -722,6 +842,11 @@ static void tm_end(cedar_enc *e, InFlight &f, int stage, hipStream_t s)
 		hipEventRecord(f.tm.ev[stage][1], s);
 }
 
+extern "C" int cedar_enc_pipeline_depth(void)
+{
+	return CEDAR_ENC_PIPELINE_DEPTH;
+}
+
 extern "C" int cedar_enc_submit(cedar_enc *e)
 {
 	if (!e)
@@ -740,32 +865,56 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	memset(f.tm.used, 0, sizeof(f.tm.used));
 	// frames in flight were submitted in order, so counters advance at submit
 	const bool idr = e->frame_p_count == 0; // cedar.c:1047-1050
-	const int par = e->parity;
+	// Device-side per-frame state rotates with the frame number (never the slot of the frame
+	// before, even when the ring of frames in flight restarts at 0)
+	const int ds = e->frame_count % CEDAR_ENC_PIPELINE_DEPTH;
+	f.ds = ds;
+	f.done_tag = (uint32_t)e->frame_count + 1u;
 	Params P = e->P;
 	P.is_idr = idr;
 	P.rec_y = e->d_rec_y[e->cur];
 	P.rec_uv = e->d_rec_uv[e->cur];
 	P.ref_y = e->d_rec_y[e->cur ^ 1];
 	P.ref_uv = e->d_rec_uv[e->cur ^ 1];
-	P.mbi = e->d_mbi[par];
-	P.i4modes = e->d_i4[par];
-	P.nnz = e->d_nnz[par];
-	P.coef = e->d_coef[par];
+	P.src_y = e->d_src_y[ds];
+	P.src_uv = e->d_src_uv[ds];
+	P.mbi = e->d_mbi[ds];
+	P.i4modes = e->d_i4[ds];
+	P.nnz = e->d_nnz[ds];
+	P.coef = e->d_coef[ds];
+	P.wf_sync = e->d_wf_sync[ds];
+	P.wf_hbuf = e->d_wf_hbuf[ds];
+	P.out = e->d_out[ds];
+	const int prev = e->prev_slot, prev2 = e->prev2_slot;
+	const bool pipe = e->row_pipe;
+	if (pipe) {
+		P.prog_inter = e->d_prog[ds];
+		P.prog_db = e->d_prog[ds] + 16;
+		P.prev_db = prev >= 0 ? e->d_prog[prev] + 16 : nullptr;
+		P.prog_tag = (uint32_t)(e->frame_count + 1) << 16;
+		P.prev_tag = (uint32_t)e->frame_count << 16;
+	}
+	hipStream_t s_db = e->s_db[e->frame_count % e->db_streams];
+	hipStream_t s_ana = e->s_ana[e->frame_count % e->an_streams]; // frames take turns: each stream's gates wait for one frame only
 	P.nal_ref_idc = idr ? 3 : 2; // cedar.c:987-990
 	P.nal_type = idr ? 5 : 1;
 
 	// ---- input: H2D of the pinned buffers unless the caller supplied device frames ----
-	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, e->s_main);
+	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, s_ana);
 	bool any_host = false;
+	for (int s = 0; s < S; s++)
+		any_host = any_host || e->h_in_ptrs[s] == e->d_in_y + (size_t)s * e->cfg.input_luma_size;
+	if (any_host && prev >= 0 && e->an_streams > 1) // the device staging copy of the host input is shared by all frames
+		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[prev], 0));
 	for (int s = 0; s < S; s++) {
 		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
 		if (e->h_in_ptrs[s] == own) {
 			any_host = true;
 			HIP_TRY(e, hipMemcpyAsync((void *)own, e->h_luma + (size_t)s * e->cfg.input_luma_size,
-						  (size_t)P.width * P.height, hipMemcpyHostToDevice, e->s_main));
+						  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_ana));
 			HIP_TRY(e, hipMemcpyAsync(e->d_in_uv + (size_t)s * e->cfg.input_chroma_size,
 						  e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
-						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, e->s_main));
+						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_ana));
 		}
 	}
 	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
@@ -776,35 +925,100 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		}
 	} else if (e->in_ptrs_dirty) {
 		HIP_TRY(e, hipMemcpyAsync((void *)e->d_in_ptrs, e->h_in_ptrs.data(), sizeof(void *) * 2 * S,
-					  hipMemcpyHostToDevice, e->s_main));
+					  hipMemcpyHostToDevice, s_ana));
 		e->in_ptrs_dirty = false;
 	}
 	if (any_host)
-		HIP_TRY(e, hipEventRecord(e->ev_input, e->s_main));
+		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_ana));
 	// (k_input also zeroes the ticket / abort / progress words of the wavefront kernels)
 	*f.h_wf_err = 0;
 	P.wf_err = f.d_wf_err;
-	if (Launch::input(P, e->s_main))
+	if (Launch::input(P, s_ana))
 		return fail(e, -EIO, "k_input launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, e->s_main);
+	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, s_ana);
+	HIP_TRY(e, hipEventRecord(e->ev_input[ds], s_ana));
+
+	auto launch_deblock = [&]() -> int {
+	// ---- in-loop deblocking: produces the next frame's reference ----
+		// Row-pipelined it starts at once and polls the analysis progress itself; otherwise it
+		// waits for the whole analysis.
+		// No event here: a cross-stream wait resolves to a later point of s_main than the record.
+		// The kernel needs nothing of this frame's s_main work up front: its sync words are zeroed
+		// on its own stream, the progress words need no zeroing (frame tags).
+		if (!pipe)
+			HIP_TRY(e, hipStreamWaitEvent(s_db, e->ev_analysis[ds], 0));
+		if (e->wf_split > 1)
+			HIP_TRY(e, hipMemsetAsync(e->d_wf_sync[ds] + WF_SYNC_WORDS, 0,
+						  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)S * e->ext.slice_num * WF_MAX_SPLIT), s_db));
+		tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
+		// luma and chroma are independent wavefronts: one launch, the plane picked per workgroup
+		// (few units), or both planes in every wave pair (many units: CUs are the scarce thing)
+		if (Launch::deblock(P, s_db, e->split_planes ? 4 : 3))
+			return fail(e, -EIO, "k_deblock launch failed");
+		tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
+		// the frame is complete when deblocking and entropy coding are (collect waits for both events)
+		HIP_TRY(e, hipEventRecord(f.done_main, s_db));
+		HIP_TRY(e, hipEventRecord(e->ev_deblocked[ds], s_db));
+		if (Launch::flag(s_db, f.d_done + 1, f.done_tag))
+			return fail(e, -EIO, "k_flag launch failed");
+		return 0;
+	};
+	// Row-pipelined, the deblock kernel only polls progress words: it is queued BEFORE this
+	// frame's analysis so that it is resident and waiting when the first stripe arrives.
+	if (pipe) {
+		const int rc_db = launch_deblock();
+		if (rc_db)
+			return rc_db;
+	}
 
 	// ---- analysis + reconstruction ----
+	// What this frame overwrites or reads of its predecessors:
+	//   rec[cur] was deblocked in place by frame n-2 (same s_db stream as this frame's deblock);
+	//   a P picture reads rec[cur^1], which frame n-1 is deblocking.
+	// Row-pipelined, a P picture follows frame n-1's deblocking band by band (k_gate), which
+	// also implies frame n-2 is through; everything else waits for whole frames.
+	if (prev2 >= 0 && (idr || !pipe))
+		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_deblocked[prev2], 0));
+	if (prev >= 0 && idr && e->an_streams > 1) // an IDR overwrites the picture the frame before is still searching
+		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_analysis[prev], 0));
+	if (prev >= 0 && !idr && !pipe)
+		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_deblocked[prev], 0));
 	if (idr) {
-		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, e->s_main);
-		if (Launch::intra_decide(P, e->s_main))
+		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
+		if (Launch::intra_decide(P, s_ana))
 			return fail(e, -EIO, "k_intra_decide launch failed");
-		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, e->s_main);
-		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_RECON, e->s_main);
-		if (Launch::intra_recon(P, e->s_main))
+		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
+		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_RECON, s_ana);
+		if (Launch::intra_recon(P, s_ana))
 			return fail(e, -EIO, "k_intra_recon launch failed");
-		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_RECON, e->s_main);
+		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_RECON, s_ana);
+		if (pipe && Launch::gate(P, s_ana, PROG_ALL, 0))
+			return fail(e, -EIO, "k_gate launch failed");
 	} else {
-		tm_begin(e, f, CEDAR_ENC_STAGE_INTER, e->s_main);
-		if (Launch::inter(P, e->s_main))
+		tm_begin(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
+		if (pipe) {
+			// diagonal stripes s = x + 2*y: the order in which the deblock wavefront of the
+			// previous frame releases the reference and in which this frame's own can follow
+			const int nb = e->inter_bands;
+			const int d_lo = 2 * P.row_first, d_hi = P.mb_w - 1 + 2 * (P.row_first + P.row_num - 1) + 1;
+			for (int k = 0; k < nb; k++) {
+				P.stripe_s0 = d_lo + (int)((long)(d_hi - d_lo) * k / nb);
+				P.stripe_s1 = d_lo + (int)((long)(d_hi - d_lo) * (k + 1) / nb);
+				if (Launch::gate(P, s_ana, k > 0 ? P.stripe_s0 : -1, P.stripe_s1 + 5))
+					return fail(e, -EIO, "k_gate launch failed");
+				if (Launch::inter(P, s_ana))
+					return fail(e, -EIO, "k_inter launch failed");
+			}
+			if (Launch::gate(P, s_ana, PROG_ALL, 0))
+				return fail(e, -EIO, "k_gate launch failed");
+			P.stripe_s0 = P.stripe_s1 = 0;
+		} else if (Launch::inter(P, s_ana)) {
 			return fail(e, -EIO, "k_inter launch failed");
-		tm_end(e, f, CEDAR_ENC_STAGE_INTER, e->s_main);
+		}
+		tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
 	}
-	HIP_TRY(e, hipEventRecord(e->ev_analysis, e->s_main));
+	HIP_TRY(e, hipEventRecord(e->ev_analysis[ds], s_ana));
+	const double t_main = now_ms();
 
 	// ---- entropy coding on its own stream, concurrent with deblocking ----
 	const int idr_pic_id = (e->frame_count / e->cfg.keyframe_interval) & 1;
@@ -817,7 +1031,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	f.with_ps = with_ps;
 	for (int s = 0; s < S; s++)
 		f.h_prefix[s] = with_ps ? (uint32_t)e->sps_pps.size() : 0;
-	HIP_TRY(e, hipStreamWaitEvent(e->s_ent, e->ev_analysis, 0));
+	HIP_TRY(e, hipStreamWaitEvent(e->s_ent, e->ev_analysis[ds], 0));
 	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
 	HIP_TRY(e, hipMemcpyAsync(e->d_hdr, f.h_hdr, sizeof(SliceHdr) * e->ext.slice_num, hipMemcpyHostToDevice, e->s_ent));
 	HIP_TRY(e, hipMemcpyAsync(e->d_prefix, f.h_prefix, sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->s_ent));
@@ -833,24 +1047,25 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		spec = (uint32_t)e->out_cap;
 	f.spec_bytes = spec;
 	HIP_TRY(e, hipMemcpyAsync(e->h_sizes[slot], e->d_stream_size, sizeof(uint32_t) * (S + 2), hipMemcpyDeviceToHost, e->s_ent));
-	HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out], e->d_out, spec, hipMemcpyDeviceToHost, e->s_ent));
+	HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out], e->d_out[ds], spec, hipMemcpyDeviceToHost, e->s_ent));
 	HIP_TRY(e, hipEventRecord(f.done_ent, e->s_ent));
+	if (Launch::flag(e->s_ent, f.d_done, f.done_tag))
+		return fail(e, -EIO, "k_flag launch failed");
+	const double t_ent = now_ms();
 
-	// ---- in-loop deblocking: produces the next frame's reference ----
-	tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
-	// luma and chroma are independent wavefronts: one launch, the plane picked per workgroup
-	// (few units), or both planes in every wave pair (many units: CUs are the scarce thing)
-	if (Launch::deblock(P, e->s_main, e->split_planes ? 4 : 3))
-		return fail(e, -EIO, "k_deblock launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, e->s_main);
-	// the frame is complete when both streams are (collect waits for both events)
-	HIP_TRY(e, hipEventRecord(f.done_main, e->s_main));
+	if (!pipe) {
+		const int rc_db = launch_deblock();
+		if (rc_db)
+			return rc_db;
+	}
 
 	f.active = true;
 	f.idr = idr;
 	e->fl_count++;
-	e->last_parity = par;
+	e->last_slot = ds;
 	e->last_rec = e->cur;
+	e->prev2_slot = e->prev_slot;
+	e->prev_slot = ds;
 	// cedar.c:1193-1201: advance the GOP counter, swap reference frames
 	e->frame_p_count++;
 	if (e->frame_p_count == e->cfg.keyframe_interval)
@@ -859,7 +1074,9 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	e->cur ^= 1;
 	e->parity ^= 1;
 	if (any_host) // the caller may refill the pinned input buffers once they are on the device
-		HIP_TRY(e, hipEventSynchronize(e->ev_input));
+		HIP_TRY(e, hipEventSynchronize(e->ev_host_in));
+	if (getenv("CEDAR_TRACE_SUBMIT"))
+		fprintf(stderr, "submit frame %d: main %.3f ms, entropy %.3f ms, deblock %.3f ms\n", e->frame_count - 1, t_main - t0, t_ent - t_main, now_ms() - t_ent);
 	e->stats.encode_wall_ms += now_ms() - t0;
 	return 0;
 }
@@ -875,8 +1092,24 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	const int slot = e->fl_head;
 	InFlight &f = e->fl[slot];
 	HIP_TRY(e, hipSetDevice(e->device));
-	HIP_TRY(e, hipEventSynchronize(f.done_ent));
-	HIP_TRY(e, hipEventSynchronize(f.done_main));
+	{
+		// poll the frame's own completion flags (see InFlight::h_done); fall back to the events
+		// if they do not show up (they are written after everything the events cover)
+		const double t_poll = now_ms();
+		unsigned spins = 0;
+		while (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
+			if ((++spins & 63) == 0) {
+				if (now_ms() - t_poll > 2000.0)
+					break;
+				sched_yield();
+			}
+		}
+		if (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
+			HIP_TRY(e, hipEventSynchronize(f.done_ent));
+			HIP_TRY(e, hipEventSynchronize(f.done_main));
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+	}
 	e->fl_head = (e->fl_head + 1) % CEDAR_ENC_PIPELINE_DEPTH;
 	e->fl_count--;
 	f.active = false;
@@ -887,7 +1120,7 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	if (flags || total > e->out_cap)
 		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
 	if (total > f.spec_bytes) {
-		HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out] + f.spec_bytes, e->d_out + f.spec_bytes,
+		HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out] + f.spec_bytes, e->d_out[f.ds] + f.spec_bytes,
 					  total - f.spec_bytes, hipMemcpyDeviceToHost, e->s_ent));
 		HIP_TRY(e, hipStreamSynchronize(e->s_ent));
 	}
@@ -1000,7 +1233,7 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 	const Params &P = e->P;
 	const void *src = nullptr;
 	size_t n = 0;
-	const int par = e->last_parity, rec = e->last_rec;
+	const int par = e->last_slot, rec = e->last_rec;
 	switch (what) {
 	case CEDAR_ENC_DBG_MBINFO: src = e->d_mbi[par] + (size_t)stream * P.n_mb; n = sizeof(MbInfo) * P.n_mb; break;
 	case CEDAR_ENC_DBG_I4MODES: src = e->d_i4[par] + (size_t)stream * P.n_mb * 16; n = (size_t)16 * P.n_mb; break;
@@ -1008,8 +1241,8 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 	case CEDAR_ENC_DBG_COEF: src = e->d_coef[par] + (size_t)stream * P.n_mb * COEF_PER_MB; n = (size_t)2 * COEF_PER_MB * P.n_mb; break;
 	case CEDAR_ENC_DBG_RECON_Y: src = e->d_rec_y[rec] + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
 	case CEDAR_ENC_DBG_RECON_UV: src = e->d_rec_uv[rec] + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
-	case CEDAR_ENC_DBG_SRC_Y: src = e->d_src_y + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
-	case CEDAR_ENC_DBG_SRC_UV: src = e->d_src_uv + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
+	case CEDAR_ENC_DBG_SRC_Y: src = e->d_src_y[par] + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
+	case CEDAR_ENC_DBG_SRC_UV: src = e->d_src_uv[par] + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
 	case CEDAR_ENC_DBG_MB_BITS: src = e->d_mb_bits + (size_t)stream * P.n_mb; n = sizeof(uint32_t) * P.n_mb; break;
 	default: return -EINVAL;
 	}

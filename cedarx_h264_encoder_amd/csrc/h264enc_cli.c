@@ -137,7 +137,7 @@ int main(int argc, char **argv)
 				else
 					in_flight++;
 			}
-			while (in_flight > (got ? 1 : 0)) {
+			while (in_flight > (got ? CEDAR_ENC_PIPELINE_DEPTH - 1 : 0)) {
 				const uint8_t *data;
 				int size;
 

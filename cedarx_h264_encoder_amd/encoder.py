@@ -79,6 +79,11 @@ def _share_hip_runtime_with_torch():
         pass
 
 
+# Frame pipelining wants the deblock streams on hardware queues of their own; the HIP runtime
+# reads this when it starts (first HIP call of the process), the session probes the result.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def load_library():
     """Load the native library; build it first if it is missing (hipcc is
     present on the GPU boxes). Fails loudly: there is no other implementation."""
@@ -95,6 +100,8 @@ def load_library():
     L.cedar_enc_config.argtypes = [vp, ctypes.POINTER(_Config)]
     L.cedar_enc_config_ext.argtypes = [vp, ctypes.POINTER(_Config), ctypes.POINTER(_ConfigExt)]
     L.cedar_enc_encode.argtypes = [vp]
+    L.cedar_enc_pipeline_depth.argtypes = []
+    L.cedar_enc_pipeline_depth.restype = ctypes.c_int
     L.cedar_enc_submit.argtypes = [vp]
     L.cedar_enc_collect.argtypes = [vp]
     L.cedar_enc_close.argtypes = [vp]
@@ -211,6 +218,11 @@ class CedarEncoder:
     # -- CEDAR_IOCTL_ENCODE --
     def encode(self):
         return self._check(self._L.cedar_enc_encode(self._h), "CEDAR_IOCTL_ENCODE")
+
+    @property
+    def pipeline_depth(self):
+        """Frames that may be in flight between submit() and collect()."""
+        return int(self._L.cedar_enc_pipeline_depth())
 
     def submit(self):
         return self._check(self._L.cedar_enc_submit(self._h), "submit")

@@ -129,8 +129,13 @@ int cedar_enc_set_device_input(cedar_enc *enc, int stream, const void *d_luma, c
  * stream without waiting; collect waits for the oldest submitted frame and
  * returns its byte count (same meaning as cedar_enc_encode). At most
  * CEDAR_ENC_PIPELINE_DEPTH frames may be in flight. cedar_enc_encode ==
- * submit + collect. */
-#define CEDAR_ENC_PIPELINE_DEPTH 2
+ * submit + collect. With few streams, frames in flight overlap on the device
+ * along macroblock rows (frame n+1 is analysed behind frame n's deblocking
+ * wavefront); the bytes are the same at any depth. Device input frames
+ * (cedar_enc_set_device_input) must stay untouched until their frame is
+ * collected. */
+#define CEDAR_ENC_PIPELINE_DEPTH 4
+int cedar_enc_pipeline_depth(void);
 int cedar_enc_submit(cedar_enc *enc);
 int cedar_enc_collect(cedar_enc *enc);
 

@@ -5,6 +5,11 @@ host logic, C-ABI symbol checks); `-m gpu` runs the parity tests proper on
 an MI355X through the C-ABI library.
 """
 import os
+
+# the encoder's frame pipelining wants more hardware queues than the HIP runtime's default 4;
+# read when the runtime starts, so it has to be in the environment before the first HIP call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import subprocess
 import sys
 

@@ -4,7 +4,7 @@ import csv, sys, collections
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], "s%s/q%s" % (r.get("Stream_Id", "?"), r.get("Queue_Id", "?"))))
 rows.sort()
 # steady state: last 40% of the trace
 t0 = rows[int(len(rows) * 0.6)][0]
@@ -25,11 +25,19 @@ for s, e, n, q in rows:
     agg[k][0] += e - s; agg[k][1] += 1
 for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
     print("%-62s n=%5d total %.3f ms avg %.1f us" % (k, c, t / 1e6, t / c / 1e3))
-# print one P-frame worth of launches in order
+# print a few frames' worth of launches in order
 names = [r for r in rows if "k_input" in r[2]]
-if len(names) > 3:
-    a, b = names[2][0], names[3][0]
-    print("one frame (%.3f ms):" % ((b - a) / 1e6))
+if len(names) > 6:
+    a, b = names[2][0], names[5][0]
+    print("three frames (%.3f ms):" % ((b - a) / 1e6))
     for s, e, n, q in rows:
-        if a <= s < b:
+        if a <= s < b and ((e - s) > 8000 or "k_input" in n or "fill" in n):
             print("  +%8.1f us  %7.1f us  q=%s  %s" % ((s - a) / 1e3, (e - s) / 1e3, q, n.split("(")[0][:50]))
+# compact view: k_input / deblock / first and last k_inter per frame, for 8 frames
+ins = [r for r in rows if "k_input" in r[2]]
+if len(ins) > 12:
+    a, b = ins[2][0], ins[11][0]
+    print("nine frames (%.3f ms):" % ((b - a) / 1e6))
+    for s_, e_, n_, q_ in rows:
+        if a <= s_ < b and ("k_input" in n_ or "deblock" in n_ or "intra" in n_ or ("k_gate" in n_ and e_ - s_ > 30000)):
+            print("  +%8.1f .. %8.1f us  %-12s %s" % ((s_ - a) / 1e3, (e_ - a) / 1e3, q_, n_.split("(")[0][:40]))

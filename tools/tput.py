@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Throughput of S lock-step 1080p streams with the full submit/collect pipeline, no profiling events (development tool)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cedarx_h264_encoder_amd as ce
+W, H = 1920, 1080
+dev = torch.device("cuda", 0)
+frames = []
+for s in range(8):
+    fr = []
+    for f in range(26):
+        y, uv = ce.gen_pattern("B", W, H, f, s << 8)
+        fr.append((torch.from_numpy(y).to(dev), torch.from_numpy(uv).to(dev)))
+    frames.append(fr)
+torch.cuda.synchronize()
+for S in [int(x) for x in sys.argv[1:]] or [1]:
+    enc = ce.CedarEncoder(width=W, height=H, qp=24, keyframe_interval=int(os.environ.get("KEYINT", "25")), n_streams=S)
+    depth = enc.pipeline_depth
+    def feed(i):
+        for s in range(S):
+            y, uv = frames[s % 8][i % 26 if i % 25 else 0]
+            enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
+        enc.submit()
+    for i in range(25):
+        feed(i); enc.collect()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n, q = 200, 0
+    for i in range(25, 25 + n):
+        if q == depth:
+            enc.collect(); q -= 1
+        feed(i); q += 1
+    while q:
+        enc.collect(); q -= 1
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("S=%d depth %d: %.3f ms/step, %.2f M MB/s" % (S, depth, dt / n * 1e3, S * 8160 * n / dt / 1e6), flush=True)
+    enc.close()
