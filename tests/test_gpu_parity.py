@@ -225,6 +225,81 @@ def test_pipelined_submit_collect_equals_synchronous(ce):
     assert out == sync
 
 
+def _encode_pipelined(enc, frames, streams=1):
+    """Keep as many frames in flight as the session allows; returns the access units in order
+    (a list per frame when streams > 1)."""
+    depth, out, q = enc.pipeline_depth, [], 0
+    for fr in frames:
+        if q == depth:
+            enc.collect()
+            out.append(enc.output() if streams == 1 else [enc.output(s) for s in range(streams)])
+            q -= 1
+        if streams == 1:
+            enc.set_input(*fr)
+        else:
+            for s in range(streams):
+                enc.set_input(fr[s][0], fr[s][1], stream=s)
+        enc.submit()
+        q += 1
+    while q:
+        enc.collect()
+        out.append(enc.output() if streams == 1 else [enc.output(s) for s in range(streams)])
+        q -= 1
+    return out
+
+
+@pytest.mark.parametrize("w,h,qp,keyint,n", [(320, 240, 28, 4, 14), (854, 480, 24, 25, 8), (1920, 1080, 24, 3, 7)])
+def test_full_depth_pipeline_matches_oracle(ce, w, h, qp, keyint, n):
+    """Frames in flight overlap on the device (frame n+1 is analysed in diagonal stripes behind
+    frame n's deblocking wavefront, several deblock kernels run at once): same bytes as the
+    scalar oracle, IDR pictures included."""
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint) as enc:
+        assert enc.pipeline_depth >= 2
+        got = _encode_pipelined(enc, frames)
+    assert [len(g) for g in got] == [len(x) for x in want]
+    assert got == want
+
+
+def test_frame_pipelining_on_off_and_stripe_counts_agree(ce, monkeypatch):
+    w, h = 640, 368
+    frames = [ol.gen_frame("C", w, h, f) for f in range(9)]
+    outs = {}
+    for key, env in (("off", {"CEDAR_ROW_PIPE": "0"}), ("on", {"CEDAR_ROW_PIPE": "1"}),
+                     ("2 stripes", {"CEDAR_ROW_PIPE": "1", "CEDAR_INTER_BANDS": "2"}),
+                     ("11 stripes, 1 analysis stream", {"CEDAR_ROW_PIPE": "1", "CEDAR_INTER_BANDS": "11",
+                                                        "CEDAR_ANALYSIS_STREAMS": "1"})):
+        for k in ("CEDAR_ROW_PIPE", "CEDAR_INTER_BANDS", "CEDAR_ANALYSIS_STREAMS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)   # read by cedar_enc_config
+        with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4) as enc:
+            outs[key] = _encode_pipelined(enc, frames)
+    assert outs["on"] == outs["off"]
+    assert outs["2 stripes"] == outs["off"]
+    assert outs["11 stripes, 1 analysis stream"] == outs["off"]
+
+
+def test_pipelined_multi_slice_and_multi_stream_sessions(ce):
+    """Progress words are per unit (stream x slice): a 3-slice picture and a 2-stream session,
+    both pipelined, against the oracle."""
+    w, h = 640, 480
+    frames = [ol.gen_frame("B", w, h, f) for f in range(7)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=5, slice_count=3))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=5, slice_count=3) as enc:
+        assert _encode_pipelined(enc, frames) == want
+    two = [[ol.gen_frame("B", w, h, f, seed_offset=s << 8) for s in range(2)] for f in range(6)]
+    want2 = []
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=5)) for _ in range(2)]
+    for fr in two:
+        want2.append([oes[s].encode(fr[s][0], fr[s][1]) for s in range(2)])
+    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=5, n_streams=2) as enc:
+        assert _encode_pipelined(enc, two, streams=2) == want2
+
+
 def test_device_resident_input_equals_host_input(ce):
     torch = pytest.importorskip("torch")
     w, h = 320, 240
