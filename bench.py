@@ -179,10 +179,9 @@ def run_rank(args, rank, world, local_rank):
     avg_ms = st["ms"][stage] / launches
     mb_per_launch = S * mbs_per_frame
     kname, tkey, per_mb = "k_" + stage, stage, KERNEL_BYTES_PER_MB[stage]
-    if stage == "deblock" and st.get("deblock_planes_split"):
-        # luma and chroma run as two concurrent kernels; the timed one (critical path) is luma:
-        # 256 B read + 256 B written per macroblock
-        kname, tkey, per_mb = "k_deblock2<planes=luma>", "deblock_luma", 512
+    if stage == "deblock":
+        # one launch filters both planes (luma and chroma workgroups, or both in every wave pair)
+        kname = "k_deblock2_planes"
     alg_bytes = per_mb * mb_per_launch
     if stage == "entropy":
         alg_bytes += nbytes / max(1, args.steps)
