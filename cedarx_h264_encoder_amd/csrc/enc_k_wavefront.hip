@@ -1,16 +1,17 @@
 // cedarx_h264_encoder_amd/csrc/enc_k_wavefront.hip
 // The two macroblock-ORDERED stages of H.264 as gfx950 wavefront kernels:
-//   k_intra_recon  closed-loop intra prediction + transform + reconstruction
-//                  (needs left / top / top-right reconstructed neighbours)
-//   k_deblock      in-loop deblocking filter, clause 8.7, raster MB order
-//                  semantics (an MB's filters read samples its left / top /
-//                  top-right neighbours have already filtered)
-// Both have the dependency (x, y) <- (x-1, y), (x, y-1), (x+1, y-1), i.e. a 2-MB
-// lag per row. One workgroup of WF_WAVES waves owns one unit (stream, slice);
-// rows are dealt to waves and every row publishes its progress in LDS, so a
-// row proceeds as soon as the row above is two macroblocks ahead. All
-// synchronisation is workgroup scope (one CU): no cross-CU hand-off, no grid
-// barrier, nothing that can deadlock on residency. Many units = many CUs.
+//   k_intra_recon2     closed-loop intra prediction + transform + reconstruction
+//                      (needs left / top / top-right reconstructed neighbours)
+//   k_deblock2_planes  in-loop deblocking filter, clause 8.7, raster MB order
+//                      semantics (an MB's filters read samples its left / top /
+//                      top-right neighbours have already filtered)
+// Both have the dependency (x, y) <- (x-1, y), (x, y-1), (x+1, y-1): an anti-diagonal
+// wavefront, a 2-MB lag per row. A band of 4 macroblock rows is swept by a small team of
+// specialised waves (compute waves that only touch LDS, a mover wave for memory); bands
+// hand rows on through LDS inside a workgroup and through a write-through buffer between
+// the workgroups (CUs) that share one unit (stream, slice). Every wait is a bounded spin.
+// Frames overlap too: progress words in memory let the next frame's analysis follow this
+// frame's deblocking.
 //
 // The reference delegates both stages to silicon (kernel/cedar.c:1135-1153
 // programs REC/REF/MBINFO addresses, :1176 triggers); deblocking policy is the
@@ -89,9 +90,9 @@ DEVI int hsign(int i, int a)
 }
 
 // ------------------------------------------------------------------------
-// k_intra_recon: each wave sweeps a band of 4 macroblock rows; lane group
-// g = lane>>4 works on row band+g, two macroblocks behind group g-1 (the same
-// skew as k_deblock), so one instruction stream reconstructs 4 macroblocks.
+// Intra reconstruction tiles (k_intra_recon2, further down): each band of 4 macroblock rows
+// is swept left to right, lane group g = lane>>4 works on row band+g, two macroblocks behind
+// group g-1 (the top-right dependency), so all 64 lanes are busy.
 //   Intra 4x4:   the 16 lanes of a group are the 16 samples of the current 4x4
 //                block; the block loop is the serial chain the standard imposes.
 //                Transforms run across lanes with DPP (quad_perm / row_mirror),
@@ -103,454 +104,6 @@ DEVI int hsign(int i, int a)
 // ------------------------------------------------------------------------
 #define IT_STRIDE 32 // luma tile: sample (x,y) at [(1+y)*32 + 8 + x], x in [-1,19], y in [-1,15]
 #define IC_STRIDE 32 // chroma tile (nv12): sample (x,y,c) at [(1+y)*32 + 8 + 2x + c], x,y in [-1,7]
-
-struct IntraGroupLds {
-	uint8_t t[17 * IT_STRIDE];
-	uint8_t c[9 * IC_STRIDE];
-	uint8_t src[256];
-	uint8_t srcc[128];
-	int dc[16];
-	int dcl[16];
-	int cdc[8];
-	int cdl[8];
-};
-
-// #define IR_TIMING 1
-template <int NWAVES>
-__global__ __launch_bounds__(64 * NWAVES) void k_intra_recon(Params p)
-{
-	__shared__ __attribute__((aligned(16))) IntraGroupLds s_g[NWAVES * 4];
-	__shared__ int s_prog[MAX_ROWS];
-	__shared__ int s_ticket;
-
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int g = lane >> 4, l = lane & 15;
-	const int NWG = p.wf_split_intra; // workgroups sharing this unit's wavefront (see k_deblock)
-	uint32_t *sync = p.wf_sync; // region 0 = intra_recon
-	if (threadIdx.x == 0)
-		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
-	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
-		s_prog[i] = 0;
-	__syncthreads();
-	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
-	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
-	int r0, r1;
-	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
-	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
-	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
-	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
-	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
-	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
-	uint32_t xseen = 0;
-
-	IntraGroupLds &L = s_g[wave * 4 + g];
-	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
-	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
-	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
-	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
-	const int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
-	const int nbands = (r1 - r0 + 3) >> 2;
-	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
-	const int pi = l >> 2, pj = l & 3;                 // sample / lane position in a 4x4 block
-	const int Pm[4] = { 0, 2, 1, 3 };
-	const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
-	(void)Pm;
-	const int rpos = 4 * kv + kh;                      // raster coefficient position held by this lane
-	const int pclass = kPosClass[rpos];
-	int zz = 0;                                        // its zig-zag scan index
-#pragma unroll
-	for (int z = 0; z < 16; z++)
-		zz = kZigzag[z] == rpos ? z : zz;
-	// this lane's column of the 4x4 predictor table (9 modes), packed in registers
-	uint32_t ptab0 = 0, ptab1 = 0, ptab2 = 0;
-#pragma unroll
-	for (int m = 0; m < 4; m++) {
-		ptab0 |= (uint32_t)p.pred4_tab[m * 16 + l] << (8 * m);
-		ptab1 |= (uint32_t)p.pred4_tab[(4 + m) * 16 + l] << (8 * m);
-	}
-	ptab2 = p.pred4_tab[8 * 16 + l];
-	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
-	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
-	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
-
-	for (int band = b_lo + wave; band < b_hi; band += NWAVES) {
-		const int my = r0 + 4 * band + g;
-		const bool row_ok = my < r1;
-		const bool top_mb = my > r0;
-		const bool xwg_band = band == b_lo && b_lo > 0;                    // row above lives in another workgroup
-		const bool xwg_top = g == 0 && xwg_band;
-		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands; // this row feeds the next workgroup
-#ifdef IR_TIMING
-		long long tl = 0, t4 = 0, t16 = 0, tc = 0, twb = 0, tt0 = __builtin_readcyclecounter();
-#endif
-		for (int step = 0; step < p.mb_w + 6; step++) {
-#ifdef IR_TIMING
-			long long c0 = __builtin_readcyclecounter();
-#endif
-			const int mx = step - 2 * g;
-			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
-			const bool left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
-			const int x0 = mx * 16, y0 = my * 16;
-			const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
-
-			if (act && left_mb) { // left neighbours = last column of the previous macroblock
-				L.t[(1 + l) * IT_STRIDE + 7] = L.t[(1 + l) * IT_STRIDE + 23];
-				if (l < 8)
-					*(uint16_t *)(L.c + (1 + l) * IC_STRIDE + 6) = *(const uint16_t *)(L.c + (1 + l) * IC_STRIDE + 22);
-			}
-			if (band > b_lo && step < p.mb_w)
-				wait_progress(s_prog, 4 * band - 1, step + 2 < p.mb_w ? step + 2 : p.mb_w);
-			else if (xwg_band && step < p.mb_w) {
-				const uint32_t need = (uint32_t)(step + 2 < p.mb_w ? step + 2 : p.mb_w);
-				if (xseen < need)
-					xseen = xwait(&xprog[wj - 1], xabort, xerr, need);
-			}
-			MbInfo mi = p.mbi[mbaddr];
-			// all 16 Intra4x4 modes of this macroblock, one nibble each (no cross-lane
-			// shuffle on the serial chain)
-			uint64_t modes64 = 0;
-			{
-				const u32x4 mv = *(const u32x4 *)(p.i4modes + mbaddr * 16);
-				const uint32_t mw[4] = { mv.x, mv.y, mv.z, mv.w };
-#pragma unroll
-				for (int k = 0; k < 16; k++)
-					modes64 |= (uint64_t)((mw[k >> 2] >> (8 * (k & 3))) & 15u) << (4 * k);
-			}
-			if (act) {
-				{
-					const u32x4 v = *(const u32x4 *)(src_y + (size_t)(y0 + l) * p.cw + x0);
-					*(u32x4 *)(L.src + l * 16) = v;
-				}
-				if (l < 8)
-					*(u32x4 *)(L.srcc + l * 16) = *(const u32x4 *)(src_uv + (size_t)(my * 8 + l) * p.cw + x0);
-				if (top_mb && xwg_top) {
-					// neighbours above come from the other workgroup's write-through buffer
-					const uint64_t *hb = hb_in + (size_t)mx * WF_HBUF_GRANULES;
-					if (l == 8 || l == 9) {
-						*(uint64_t *)(L.t + 8 + (l - 8) * 8) = xload64(hb + (l - 8));
-					} else if (l == 10 && tr_mb) {
-						*(uint32_t *)(L.t + 24) = (uint32_t)xload64(hb + WF_HBUF_GRANULES);       // next MB, first 4 samples
-					} else if (l == 11 && left_mb) {
-						L.t[7] = (uint8_t)(xload64(hb - WF_HBUF_GRANULES + 1) >> 56);              // previous MB, last sample
-					} else if (l == 12 || l == 13) {
-						*(uint64_t *)(L.c + 8 + (l - 12) * 8) = xload64(hb + 2 + (l - 12));
-					} else if (l == 14 && left_mb) {
-						*(uint16_t *)(L.c + 6) = (uint16_t)(xload64(hb - WF_HBUF_GRANULES + 3) >> 48); // previous MB, last CbCr pair
-					}
-				} else if (top_mb) {
-					if (l == 8) {
-						const uint64_t *tp = (const uint64_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0);
-						*(uint64_t *)(L.t + 8) = tp[0];
-						*(uint64_t *)(L.t + 16) = tp[1];
-					} else if (l == 9 && tr_mb) {
-						*(uint32_t *)(L.t + 24) = *(const uint32_t *)(rec_y + (size_t)(y0 - 1) * p.cw + x0 + 16);
-					} else if (l == 10 && left_mb) {
-						L.t[7] = rec_y[(size_t)(y0 - 1) * p.cw + x0 - 1];
-					} else if (l == 11) {
-						const uint64_t *tp = (const uint64_t *)(rec_uv + (size_t)(my * 8 - 1) * p.cw + x0);
-						*(uint64_t *)(L.c + 8) = tp[0];
-						*(uint64_t *)(L.c + 16) = tp[1];
-					} else if (l == 12 && left_mb) {
-						*(uint16_t *)(L.c + 6) = *(const uint16_t *)(rec_uv + (size_t)(my * 8 - 1) * p.cw + x0 - 2);
-					}
-				}
-			}
-			WAVE_SYNC();
-
-			int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
-			int16_t *cf_lane = cf + COEF_LUMA + zz;         // this lane's level slot of block 0
-			uint8_t *nnz_mb = p.nnz + mbaddr * NNZ_PER_MB;
-			const bool is4 = act && mi.type == MB_I4x4, is16 = act && mi.type == MB_I16x16;
-			int cbp = 0;
-			uint32_t nzmask16 = 0; // luma blocks with coefficients, bit = raster block
-
-#ifdef IR_TIMING
-			long long c1 = __builtin_readcyclecounter();
-#endif
-			// ---- Intra 4x4: serial over the 16 blocks, lane = sample ----
-			if (__any(is4)) {
-				if (is4)
-					cf[COEF_DC16 + l] = 0;
-				for (int idx = 0; idx < 16; idx++) {
-					const int bx = blk_x(idx), by = blk_y(idx);
-					int level = 0;
-					if (is4) {
-						const int tx = 8 + 4 * bx, ty = 1 + 4 * by;
-						bool ht, hl, htr;
-						blk4_avail(idx, top_mb, left_mb, tr_mb, ht, hl, htr);
-						const int mode = (int)((modes64 >> (4 * idx)) & 15u);
-						const uint8_t *T = L.t;
-						// edge entry k -> tile address. E[0]=E[1]=l3 E[2]=l2 E[3]=l1 E[4]=l0 E[5]=tl
-						// E[6..13]=t0..t7 (t4..7 = t3 when top-right is unavailable) E[14]=t7
-						const int tkmax = htr ? 7 : 3;
-						auto eaddr = [&](int k) { // min/max arithmetic only
-							k = max(1, min(13, k));
-							const int row = ty - 1 + max(0, 5 - k);
-							const int col = tx - 1 + max(0, min(k - 6, tkmax) + 1);
-							return row * IT_STRIDE + col;
-						};
-						const uint32_t pw = mode < 4 ? ptab0 : mode < 8 ? ptab1 : ptab2;
-						const int ent = (int)((pw >> (8 * (mode & 3))) & 0xffu);
-						const int kind = ent >> 4, k = ent & 15;
-						const int ea = T[eaddr(k - 1)], eb = T[eaddr(k)], ec = T[eaddr(k + 1)];
-						int st_ = 0, sl_ = 0;
-#pragma unroll
-						for (int q = 0; q < 4; q++) {
-							st_ += T[(ty - 1) * IT_STRIDE + tx + q];
-							sl_ += T[(ty + q) * IT_STRIDE + tx - 1];
-						}
-						const int dcv = (ht && hl) ? (st_ + sl_ + 4) >> 3 : hl ? (sl_ + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
-						const int pv = sel(nz_mask(kind ^ 3), // kind 3 = DC
-								   sel(nz_mask(kind ^ 2), sel(nz_mask(kind ^ 1), eb, (eb + ec + 1) >> 1),
-								       (ea + 2 * eb + ec + 2) >> 2),
-								   dcv);
-						const int res = (int)L.src[(4 * by + pi) * 16 + 4 * bx + pj] - pv;
-						const int w = fdct_lanes(res, ci, cj);
-						level = quant1(w, my_mf, f_intra, p.qbits);
-						cf_lane[idx * 16] = (int16_t)level;
-						const int d = (level * my_dv) << p.qshift;
-						const int r = idct_lanes(d, ci, cj);
-						L.t[(ty + pi) * IT_STRIDE + tx + pj] = (uint8_t)clip255(pv + r);
-					}
-					const uint64_t bal = __ballot(is4 && level != 0);
-					const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
-					if (is4) {
-						if (l == 0)
-							nnz_mb[bx + 4 * by] = (uint8_t)nn;
-						cbp |= nn ? (1 << (idx >> 2)) : 0;
-						nzmask16 |= nn ? (1u << (bx + 4 * by)) : 0;
-					}
-					WAVE_SYNC();
-				}
-			}
-
-#ifdef IR_TIMING
-			long long c2 = __builtin_readcyclecounter();
-#endif
-			// ---- Intra 16x16: lane = 4x4 block (coding order) ----
-			if (__any(is16)) {
-				const int bx = blk_x(l), by = blk_y(l);
-				const uint8_t *T = L.t;
-				int d[16];
-				int nn = 0, dcv = 128, pa = 0, pb = 0, pc = 0;
-				// prediction is recomputed where needed instead of being kept in registers
-				auto pred16 = [&](int x, int y) {
-					return mi.i16_mode == 0 ? (int)T[8 + x]
-					     : mi.i16_mode == 1 ? (int)T[(1 + y) * IT_STRIDE + 7]
-					     : mi.i16_mode == 2 ? dcv
-					     : clip255((pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5);
-				};
-				if (is16) {
-					int dcsum = 0, H = 0, V = 0;
-					for (int k = 0; k < 16; k++)
-						dcsum += (top_mb ? T[8 + k] : 0) + (left_mb ? T[(1 + k) * IT_STRIDE + 7] : 0);
-					dcv = (top_mb && left_mb) ? (dcsum + 16) >> 5 : (top_mb || left_mb) ? (dcsum + 8) >> 4 : 128;
-					for (int k = 0; k < 8; k++) {
-						H += (k + 1) * ((int)T[8 + 8 + k] - (int)T[8 + 6 - k]);
-						V += (k + 1) * ((int)T[(1 + 8 + k) * IT_STRIDE + 7] - (int)T[(1 + 6 - k) * IT_STRIDE + 7]);
-					}
-					pa = 16 * ((int)T[16 * IT_STRIDE + 7] + (int)T[8 + 15]);
-					pb = (5 * H + 32) >> 6;
-					pc = (5 * V + 32) >> 6;
-					int w[16];
-					{
-						int res[16];
-#pragma unroll
-						for (int i = 0; i < 16; i++) {
-							const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-							res[i] = (int)L.src[y * 16 + x] - pred16(x, y);
-						}
-						fdct4x4(res, w);
-					}
-					L.dc[bx + 4 * by] = w[0];
-					cf[COEF_LUMA + l * 16] = 0;
-#pragma unroll
-					for (int i = 1; i < 16; i++) {
-						const int r = kZigzag[i], c = kPosClass[r];
-						const int lq = quant1(w[r], p.mf[c], f_intra, p.qbits);
-						cf[COEF_LUMA + l * 16 + i] = (int16_t)lq;
-						nn += lq != 0;
-						d[r] = (lq * p.dv[c]) << p.qshift;
-					}
-				}
-				WAVE_SYNC();
-				if (is16) { // forward Hadamard output (i,j) = raster lane
-					const int i = l >> 2, j = l & 3;
-					int s = 0;
-#pragma unroll
-					for (int a = 0; a < 4; a++)
-#pragma unroll
-						for (int b = 0; b < 4; b++)
-							s += hsign(i, a) * hsign(j, b) * L.dc[4 * a + b];
-					L.dcl[l] = quant1((s + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
-				}
-				WAVE_SYNC();
-				if (is16) {
-					cf[COEF_DC16 + l] = (int16_t)L.dcl[kZigzag[l]];
-					int s = 0;
-#pragma unroll
-					for (int a = 0; a < 4; a++)
-#pragma unroll
-						for (int b = 0; b < 4; b++)
-							s += hsign(by, a) * hsign(bx, b) * L.dcl[4 * a + b];
-					const int ls = 16 * p.dv[0];
-					d[0] = p.qp >= 36 ? (s * ls) << (p.qshift - 6) : (s * ls + (1 << (5 - p.qshift))) >> (6 - p.qshift);
-					int pred[16], out[16];
-#pragma unroll
-					for (int i = 0; i < 16; i++)
-						pred[i] = pred16(4 * bx + (i & 3), 4 * by + (i >> 2));
-					idct4x4_add(d, pred, out);
-					// all predictions of the group are read before any lane writes the tile
-					__builtin_amdgcn_wave_barrier();
-#pragma unroll
-					for (int k = 0; k < 16; k++)
-						L.t[(1 + 4 * by + (k >> 2)) * IT_STRIDE + 8 + 4 * bx + (k & 3)] = (uint8_t)out[k];
-					p.nnz[mbaddr * NNZ_PER_MB + bx + 4 * by] = (uint8_t)nn;
-				}
-				const uint64_t bal = __ballot(is16 && nn != 0);
-				if (is16)
-					cbp = ((uint32_t)(bal >> (16 * g)) & 0xffffu) ? 15 : 0;
-			}
-
-#ifdef IR_TIMING
-			long long c3 = __builtin_readcyclecounter();
-#endif
-			// ---- chroma: lanes 0..7 of the group = (plane c, block blk) ----
-			int cnn = 0, cdcnz = 0;
-			{
-				const bool is_c = act && l < 8;
-				const int c = l >> 2, blk = l & 3;
-				const int bx = blk & 1, by = blk >> 1;
-				const uint8_t *T = L.c;
-				int cd[16];
-				int dcv = 128, pa = 0, pb = 0, pc = 0;
-#define CT(xx, yy) T[(1 + (yy)) * IC_STRIDE + 8 + 2 * (xx) + c]
-				auto predc = [&](int x, int y) {
-					return mi.chroma_mode == 0 ? dcv
-					     : mi.chroma_mode == 1 ? (int)CT(-1, y)
-					     : mi.chroma_mode == 2 ? (int)CT(x, -1)
-					     : clip255((pa + pb * (x - 3) + pc * (y - 3) + 16) >> 5);
-				};
-				if (is_c) {
-					int stp = 0, slf = 0, H = 0, V = 0;
-					for (int k = 0; k < 4; k++) {
-						stp += CT(4 * bx + k, -1);
-						slf += CT(-1, 4 * by + k);
-						H += (k + 1) * ((int)CT(4 + k, -1) - (int)CT(2 - k, -1));
-						V += (k + 1) * ((int)CT(-1, 4 + k) - (int)CT(-1, 2 - k));
-					}
-					bool use_t = top_mb, use_l = left_mb;
-					if (bx == 1 && by == 0 && top_mb)
-						use_l = false;
-					if (bx == 0 && by == 1 && left_mb)
-						use_t = false;
-					dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
-					pa = 16 * ((int)CT(-1, 7) + (int)CT(7, -1));
-					pb = (34 * H + 32) >> 6;
-					pc = (34 * V + 32) >> 6;
-					int w[16];
-					{
-						int res[16];
-#pragma unroll
-						for (int i = 0; i < 16; i++) {
-							const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-							res[i] = (int)L.srcc[y * 16 + 2 * x + c] - predc(x, y);
-						}
-						fdct4x4(res, w);
-					}
-					L.cdc[l] = w[0];
-					cf[COEF_CAC + (4 * c + blk) * 16] = 0;
-#pragma unroll
-					for (int i = 1; i < 16; i++) {
-						const int r = kZigzag[i], cl = kPosClass[r];
-						const int lq = quant1(w[r], p.mfc[cl], f_intra_c, p.qbits_c);
-						cf[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)lq;
-						cnn += lq != 0;
-						cd[r] = (lq * p.dvc[cl]) << p.qshift_c;
-					}
-				}
-				WAVE_SYNC();
-				if (is_c) {
-					const int *dcs = L.cdc + 4 * c;
-					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
-					const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
-					const int lq = quant1(hd, p.mfc[0], 2 * f_intra_c, p.qbits_c + 1);
-					L.cdl[l] = lq;
-					cf[COEF_CDC + 4 * c + blk] = (int16_t)lq;
-					cdcnz = lq != 0;
-				}
-				WAVE_SYNC();
-				if (is_c) {
-					const int *ls = L.cdl + 4 * c;
-					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
-					const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
-					cd[0] = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
-					int pred[16], out[16];
-#pragma unroll
-					for (int i = 0; i < 16; i++)
-						pred[i] = predc(4 * bx + (i & 3), 4 * by + (i >> 2));
-					idct4x4_add(cd, pred, out);
-#pragma unroll
-					for (int i = 0; i < 16; i++)
-						L.c[(1 + 4 * by + (i >> 2)) * IC_STRIDE + 8 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
-					p.nnz[mbaddr * NNZ_PER_MB + 16 + l] = (uint8_t)cnn;
-				}
-#undef CT
-			}
-			{
-				const uint64_t acm = __ballot(cnn != 0), dcm = __ballot(cdcnz != 0);
-				const uint32_t ac = (uint32_t)(acm >> (16 * g)) & 0xffffu, dcb = (uint32_t)(dcm >> (16 * g)) & 0xffffu;
-				cbp |= ac ? 0x20 : (dcb ? 0x10 : 0);
-			}
-			WAVE_SYNC();
-
-#ifdef IR_TIMING
-			long long c4 = __builtin_readcyclecounter();
-#endif
-			// ---- write back reconstruction rows and the record ----
-			if (act) {
-				{
-					const uint64_t *rp = (const uint64_t *)(L.t + (1 + l) * IT_STRIDE + 8);
-					uint64_t *gp = (uint64_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
-					gp[0] = rp[0];
-					gp[1] = rp[1];
-				}
-				if (l < 8) {
-					const uint64_t *rp = (const uint64_t *)(L.c + (1 + l) * IC_STRIDE + 8);
-					uint64_t *gp = (uint64_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0);
-					gp[0] = rp[0];
-					gp[1] = rp[1];
-				}
-				if (l == 0) {
-					mi.cbp = (int8_t)cbp;
-					p.mbi[mbaddr] = mi;
-				}
-			}
-			if (b_hi < nbands && band == b_hi - 1) { // wave-uniform: this band feeds the next workgroup
-				if (is_xprod && act && l < 4) {
-					const uint8_t *src = l < 2 ? L.t + 16 * IT_STRIDE + 8 + l * 8 : L.c + 8 * IC_STRIDE + 8 + (l - 2) * 8;
-					xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
-				}
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				if (is_xprod && act && l == 0)
-					xstore32(&xprog[wj], (uint32_t)(mx + 1));
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (act && l == 0)
-				__hip_atomic_store(&s_prog[my - r0], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef IR_TIMING
-			tl += c1 - c0; t4 += c2 - c1; t16 += c3 - c2; tc += c4 - c3; twb += __builtin_readcyclecounter() - c4;
-#endif
-		}
-#ifdef IR_TIMING
-		if (lane == 0 && s_ticket <= 1 && wave <= 1 && band < b_lo + NWAVES) {
-			const int n = p.mb_w + 6;
-			printf("intra wg %d wave %d: total %lld load %lld i4 %lld i16 %lld chroma %lld writeback %lld\n", s_ticket, wave,
-			       (__builtin_readcyclecounter() - tt0) / n, tl / n, t4 / n, t16 / n, tc / n, twb / n);
-		}
-#endif
-	}
-}
 
 // ------------------------------------------------------------------------
 // k_deblock2: in-loop deblocking as a macroblock wavefront. A band of 4 macroblock
@@ -1838,17 +1391,9 @@ int Launch::deblock(const Params &p, void *stream, int planes)
 int Launch::intra_recon(const Params &p, void *stream)
 {
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split_intra);
-	static int version = 0;
-	if (!version) {
-		const char *e = getenv("CEDAR_INTRA_V");
-		version = e ? atoi(e) : 2;
-	}
-	// wavefront workgroups are throughput-bound on their CU: enough LDS (static, or unused
-	// dynamic) that two of them can never share one CU (160 KiB per CU)
-	if (version == 2)
-		hipLaunchKernelGGL(k_intra_recon2, grid, dim3(64 * 3 * IR_TRIPLES), 64 * 1024, (hipStream_t)stream, p);
-	else
-		hipLaunchKernelGGL(k_intra_recon<8>, grid, dim3(64 * 8), 40 * 1024, (hipStream_t)stream, p);
+	// wavefront workgroups are throughput-bound on their CU: enough (unused dynamic) LDS that
+	// two of them can never share one CU (160 KiB per CU)
+	hipLaunchKernelGGL(k_intra_recon2, grid, dim3(64 * 3 * IR_TRIPLES), 64 * 1024, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 
