@@ -41,6 +41,7 @@ constexpr int WF_MAX_SPLIT = 8;   // workgroups sharing one unit's wavefront
 constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress
 constexpr int PROG_BANDS = 128;     // deblock bands (4 macroblock rows) per unit with a progress word
 constexpr int PROG_ALL = 0xffff;     // progress value: everything through
+constexpr int INTER_WAVES = 4;       // macroblocks (waves) per k_inter workgroup: a 1080p picture is workgroup-launch bound at 1
 constexpr int IN_K_STREAMS = 8;     // up to this many streams pass their frame pointers as kernel arguments
 constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
@@ -117,6 +118,8 @@ struct Params {
 	const uint32_t *prev_db;         // the previous frame's prog_db (what k_gate waits for)
 	uint32_t prog_tag, prev_tag;
 	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + 2*y < s1 (stripe_s1 <= 0: the whole picture)
+	const uint32_t *stripe_tab;      // [row_num + 1] macroblocks of the stripe in the rows before row r (per stream)
+	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
@@ -157,7 +160,7 @@ struct Launch {
 	static int input(const Params &p, void *stream);
 	static int intra_decide(const Params &p, void *stream);
 	static int intra_recon(const Params &p, void *stream);
-	static int inter(const Params &p, void *stream);   // diagonals [stripe_s0, stripe_s1)
+	static int inter(const Params &p, void *stream, int n_mbs); // n_mbs macroblocks: the picture, or the diagonals [stripe_s0, stripe_s1)
 	// 1 wave: publish prog_inter = publish_d (if >= 0), then wait until every deblock band of the
 	// previous frame has written back all macroblocks with x + 2*y < need_d (if > 0)
 	static int gate(const Params &p, void *stream, int publish_d, int need_d);

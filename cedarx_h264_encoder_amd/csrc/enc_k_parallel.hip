@@ -107,41 +107,67 @@ int Launch::input(const Params &p, void *stream)
 #define REF_STRIDE 48
 #define REFC_STRIDE 64
 
-// k_inter covers the diagonals stripe_s0 <= x + 2*y < stripe_s1 of every stream (the whole
-// picture when stripe_s1 <= 0). Returns false for the blocks of a stripe that fall outside.
-DEVI bool stripe_mb(const Params &p, int &mx, int &my, int &st)
+// k_inter: macroblock number i of this launch -> (mx, my, st). A launch covers the whole
+// picture (stripe_s1 <= 0) or the diagonals stripe_s0 <= x + 2*y < stripe_s1 of every stream,
+// enumerated row by row without holes (stripe_tab = running count per row). False past the end.
+DEVI bool inter_mb(const Params &p, uint32_t i, int &mx, int &my, int &st)
 {
 	if (p.stripe_s1 <= 0) {
-		xcd_mb(p, mx, my, st);
-		return true;
+		const uint32_t per_stream = (uint32_t)(p.mb_w * p.row_num);
+		st = (int)(i / per_stream);
+		const uint32_t m = i - (uint32_t)st * per_stream;
+		my = p.row_first + (int)(m / (uint32_t)p.mb_w);
+		mx = (int)(m % (uint32_t)p.mb_w);
+		return st < p.n_streams;
 	}
-	const uint32_t nb = gridDim.x, hb = blockIdx.x;
-	const uint32_t xcd = hb & 7u, i = hb >> 3, q = nb >> 3, r = nb & 7u;
-	const uint32_t lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-	const uint32_t w = (uint32_t)(p.stripe_s1 - p.stripe_s0), per_stream = w * (uint32_t)p.row_num;
-	st = (int)(lb / per_stream);
-	const uint32_t m = lb - (uint32_t)st * per_stream;
-	my = p.row_first + (int)(m / w);
-	mx = p.stripe_s0 - 2 * my + (int)(m % w);
-	return mx >= 0 && mx < p.mb_w;
+	const uint32_t per_stream = p.stripe_tab[p.row_num];
+	st = (int)(i / per_stream);
+	const uint32_t m = i - (uint32_t)st * per_stream;
+	int lo = 0, hi = p.row_num; // last row r with tab[r] <= m
+	while (hi - lo > 1) {
+		const int mid = (lo + hi) >> 1;
+		if (p.stripe_tab[mid] <= m)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	my = p.row_first + lo;
+	const int xs = p.stripe_s0 - 2 * my;
+	mx = (xs > 0 ? xs : 0) + (int)(m - p.stripe_tab[lo]);
+	return st < p.n_streams;
 }
 
-__global__ __launch_bounds__(64) void k_inter(Params p)
+__global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t s_ref[48 * REF_STRIDE + 64];
-	__shared__ __attribute__((aligned(16))) uint8_t s_refc[25 * REFC_STRIDE];
-	__shared__ __attribute__((aligned(16))) uint8_t s_cur[256];
-	__shared__ __attribute__((aligned(16))) uint8_t s_curc[128];
-	__shared__ __attribute__((aligned(16))) int16_t s_coef[COEF_PER_MB];
-	__shared__ __attribute__((aligned(16))) uint8_t s_recy[256];
-	__shared__ __attribute__((aligned(16))) uint8_t s_recc[128];
-	__shared__ int s_dc[8];
-	__shared__ int s_cdc[8];
+	// one wave per macroblock, INTER_WAVES macroblocks per workgroup (each wave has its own
+	// slice of every array; the barriers below only ever order a wave with itself)
+	__shared__ __attribute__((aligned(16))) uint8_t sa_ref[INTER_WAVES][48 * REF_STRIDE + 64];
+	__shared__ __attribute__((aligned(16))) uint8_t sa_refc[INTER_WAVES][25 * REFC_STRIDE];
+	__shared__ __attribute__((aligned(16))) uint8_t sa_cur[INTER_WAVES][256];
+	__shared__ __attribute__((aligned(16))) uint8_t sa_curc[INTER_WAVES][128];
+	__shared__ __attribute__((aligned(16))) int16_t sa_coef[INTER_WAVES][COEF_PER_MB];
+	__shared__ __attribute__((aligned(16))) uint8_t sa_recy[INTER_WAVES][256];
+	__shared__ __attribute__((aligned(16))) uint8_t sa_recc[INTER_WAVES][128];
+	__shared__ int sa_dc[INTER_WAVES][8];
+	__shared__ int sa_cdc[INTER_WAVES][8];
 
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint8_t *const s_ref = sa_ref[wave], *const s_refc = sa_refc[wave], *const s_cur = sa_cur[wave], *const s_curc = sa_curc[wave];
+	int16_t *const s_coef = sa_coef[wave];
+	uint8_t *const s_recy = sa_recy[wave], *const s_recc = sa_recc[wave];
+	int *const s_dc = sa_dc[wave], *const s_cdc = sa_cdc[wave];
+	// XCD-aware workgroup order (see xcd_mb): workgroups sharing an XCD own one contiguous run
+	const uint32_t nb = gridDim.x, hb = blockIdx.x;
+	const uint32_t xcd = hb & 7u, bi = hb >> 3, q = nb >> 3, r = nb & 7u;
+	const uint32_t lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bi;
 	int mx, my, st;
-	if (!stripe_mb(p, mx, my, st))
-		return;
+	// an idle wave of the last workgroup redoes macroblock 0 and writes to the dummy slots
+	const bool valid = inter_mb(p, lb * INTER_WAVES + (uint32_t)wave, mx, my, st);
+	if (!valid) {
+		mx = 0;
+		my = p.row_first;
+		st = 0;
+	}
 	const int x0 = mx * 16, y0 = my * 16;
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
@@ -151,9 +177,10 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
 	const uint8_t *ref_y = p.ref_y + (size_t)st * p.plane_y_stride;
 	const uint8_t *ref_uv = p.ref_uv + (size_t)st * p.plane_uv_stride;
-	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
-	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
-	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
+	uint8_t *rec_y = valid ? p.rec_y + (size_t)st * p.plane_y_stride + (size_t)y0 * p.cw + x0 : p.dummy_rec;
+	uint8_t *rec_uv = valid ? p.rec_uv + (size_t)st * p.plane_uv_stride + (size_t)(my * 8) * p.cw + x0 : p.dummy_rec + (size_t)16 * p.cw;
+	// records, counts and levels of the dummy macroblock live one past the last stream
+	const size_t mbaddr = valid ? (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx : (size_t)p.n_streams * p.n_mb;
 
 	// ---- stage tiles through LDS with 16-byte loads ----
 	if (lane < 16)
@@ -342,9 +369,9 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	if (lane < COEF_PER_MB * 2 / 16)
 		*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)s_coef + lane * 16);
 	if (lane < 16)
-		*(u32x4 *)(rec_y + (size_t)(y0 + lane) * p.cw + x0) = *(const u32x4 *)(s_recy + lane * 16);
+		*(u32x4 *)(rec_y + (size_t)lane * p.cw) = *(const u32x4 *)(s_recy + lane * 16);
 	else if (lane < 24)
-		*(u32x4 *)(rec_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
+		*(u32x4 *)(rec_uv + (size_t)(lane - 16) * p.cw) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
 	if (lane < 16)
 		p.i4modes[mbaddr * 16 + lane] = 2;
 	if (lane == 0) {
@@ -359,10 +386,9 @@ __global__ __launch_bounds__(64) void k_inter(Params p)
 	}
 }
 
-int Launch::inter(const Params &p, void *stream)
+int Launch::inter(const Params &p, void *stream, int n_mbs)
 {
-	dim3 grid((p.stripe_s1 > 0 ? p.stripe_s1 - p.stripe_s0 : p.mb_w) * p.row_num * p.n_streams);
-	hipLaunchKernelGGL(k_inter, grid, dim3(64), 0, (hipStream_t)stream, p);
+	hipLaunchKernelGGL(k_inter, dim3((n_mbs + INTER_WAVES - 1) / INTER_WAVES), dim3(64 * INTER_WAVES), 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 

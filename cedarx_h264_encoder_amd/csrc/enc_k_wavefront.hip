@@ -212,7 +212,12 @@ DEVI void lds_wait_ge(const int *word, int need, uint32_t *err)
 			__hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			break;
 		}
-		__builtin_amdgcn_s_sleep(0);
+		// back off after ~50 us: the partner is usually a few hundred cycles away, but with frames
+		// pipelined a whole workgroup can wait for a millisecond for its frame's analysis
+		if (spins < 2048)
+			__builtin_amdgcn_s_sleep(0);
+		else
+			__builtin_amdgcn_s_sleep(32);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }

@@ -186,6 +186,10 @@ struct cedar_enc {
 	uint8_t *d_pred4 = nullptr;
 	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint64_t *d_wf_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint8_t *d_dummy_rec = nullptr;  // 24 rows: what idle k_inter waves reconstruct into
+	uint32_t *d_stripe_tab = nullptr; // [inter_bands][row_num + 1] running macroblock counts of the diagonal stripes
+	std::vector<int> stripe_s;        // [inter_bands + 1] stripe boundaries (diagonals)
+	std::vector<int> stripe_n;        // macroblocks per stripe and stream
 	uint32_t *d_prog[CEDAR_ENC_PIPELINE_DEPTH] = {}; // [0] prog_inter, [16..) prog_db[2][n_units]
 	bool row_pipe = false;      // consecutive frames overlap along the wavefront diagonals (few units)
 	int db_streams = 1;         // deblock streams that really run beside s_main and each other
@@ -267,7 +271,7 @@ void free_all(cedar_enc *e)
 	}
 	F(e->d_slot); F(e->d_mb_bits); F(e->d_skip); F(e->d_bit_off); F(e->d_run); F(e->d_unit_bits);
 	F(e->d_rbsp); F(e->d_esc); F(e->d_nal_off); F(e->d_nal_size); F(e->d_stream_size);
-	F(e->d_hdr); F(e->d_prefix); F(e->d_pred4);
+	F(e->d_hdr); F(e->d_prefix); F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab);
 	H(e->h_luma); H(e->h_chroma);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_wf_err); H((void *)e->fl[i].h_done);
@@ -599,10 +603,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		if ((rc = dalloc(e, &e->d_src_y[i], plane_y * S))) return rc;
 		if ((rc = dalloc(e, &e->d_src_uv[i], plane_uv * S))) return rc;
-		if ((rc = dalloc(e, &e->d_mbi[i], (size_t)P.n_mb * S))) return rc;
-		if ((rc = dalloc(e, &e->d_i4[i], (size_t)P.n_mb * S * 16))) return rc;
-		if ((rc = dalloc(e, &e->d_nnz[i], (size_t)P.n_mb * S * NNZ_PER_MB))) return rc;
-		if ((rc = dalloc(e, &e->d_coef[i], (size_t)P.n_mb * S * COEF_PER_MB))) return rc;
+		// + 1 macroblock: the dummy slot idle k_inter waves write to
+		if ((rc = dalloc(e, &e->d_mbi[i], (size_t)P.n_mb * S + 1))) return rc;
+		if ((rc = dalloc(e, &e->d_i4[i], ((size_t)P.n_mb * S + 1) * 16))) return rc;
+		if ((rc = dalloc(e, &e->d_nnz[i], ((size_t)P.n_mb * S + 1) * NNZ_PER_MB))) return rc;
+		if ((rc = dalloc(e, &e->d_coef[i], ((size_t)P.n_mb * S + 1) * COEF_PER_MB))) return rc;
 	}
 	if ((rc = dalloc(e, &e->d_slot, (size_t)P.n_mb * S * SLOT_WORDS))) return rc;
 	if ((rc = dalloc(e, &e->d_mb_bits, (size_t)P.n_mb * S))) return rc;
@@ -745,6 +750,33 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		int nb = envb ? atoi(envb) : 5;
 		if (nb > 64) nb = 64;
 		e->inter_bands = e->row_pipe ? (nb < 1 ? 1 : nb) : 1;
+	}
+	{
+		// diagonal stripes s = x + 2*y of a P picture and, per stripe, how many of its macroblocks
+		// lie in the rows before row r: k_inter enumerates a stripe without holes
+		const int nb = e->inter_bands;
+		const int d_lo = 2 * P.row_first, d_hi = P.mb_w - 1 + 2 * (P.row_first + P.row_num - 1) + 1;
+		e->stripe_s.assign((size_t)nb + 1, 0);
+		e->stripe_n.assign((size_t)nb, 0);
+		std::vector<uint32_t> tab((size_t)nb * (P.row_num + 1), 0);
+		for (int k = 0; k <= nb; k++)
+			e->stripe_s[k] = d_lo + (int)((long)(d_hi - d_lo) * k / nb);
+		for (int k = 0; k < nb; k++) {
+			uint32_t run = 0;
+			for (int r = 0; r <= P.row_num; r++) {
+				tab[(size_t)k * (P.row_num + 1) + r] = run;
+				const int y = P.row_first + r;
+				auto cl = [&](int v) { return v < 0 ? 0 : v > P.mb_w ? P.mb_w : v; };
+				run += (uint32_t)(cl(e->stripe_s[k + 1] - 2 * y) - cl(e->stripe_s[k] - 2 * y));
+			}
+			e->stripe_n[k] = (int)tab[(size_t)k * (P.row_num + 1) + P.row_num];
+		}
+		if (e->d_stripe_tab) { hipFree(e->d_stripe_tab); e->d_stripe_tab = nullptr; }
+		if ((rc = dalloc(e, &e->d_stripe_tab, tab.size()))) return rc;
+		HIP_TRY(e, hipMemcpy(e->d_stripe_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		if (!e->d_dummy_rec && (rc = dalloc(e, &e->d_dummy_rec, (size_t)24 * P.cw))) return rc;
+		e->P.dummy_rec = e->d_dummy_rec;
+		e->P.stripe_tab = nullptr;
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
@@ -1000,19 +1032,19 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 			// diagonal stripes s = x + 2*y: the order in which the deblock wavefront of the
 			// previous frame releases the reference and in which this frame's own can follow
 			const int nb = e->inter_bands;
-			const int d_lo = 2 * P.row_first, d_hi = P.mb_w - 1 + 2 * (P.row_first + P.row_num - 1) + 1;
 			for (int k = 0; k < nb; k++) {
-				P.stripe_s0 = d_lo + (int)((long)(d_hi - d_lo) * k / nb);
-				P.stripe_s1 = d_lo + (int)((long)(d_hi - d_lo) * (k + 1) / nb);
+				P.stripe_s0 = e->stripe_s[k];
+				P.stripe_s1 = e->stripe_s[k + 1];
+				P.stripe_tab = e->d_stripe_tab + (size_t)k * (P.row_num + 1);
 				if (Launch::gate(P, s_ana, k > 0 ? P.stripe_s0 : -1, P.stripe_s1 + 5))
 					return fail(e, -EIO, "k_gate launch failed");
-				if (Launch::inter(P, s_ana))
+				if (e->stripe_n[k] > 0 && Launch::inter(P, s_ana, e->stripe_n[k] * S))
 					return fail(e, -EIO, "k_inter launch failed");
 			}
 			if (Launch::gate(P, s_ana, PROG_ALL, 0))
 				return fail(e, -EIO, "k_gate launch failed");
 			P.stripe_s0 = P.stripe_s1 = 0;
-		} else if (Launch::inter(P, s_ana)) {
+		} else if (Launch::inter(P, s_ana, P.mb_w * P.row_num * S)) {
 			return fail(e, -EIO, "k_inter launch failed");
 		}
 		tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
