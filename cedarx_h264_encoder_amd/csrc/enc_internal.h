@@ -104,7 +104,8 @@ struct Params {
 	// abort flag and per-workgroup progress words (zeroed before every launch),
 	// and the write-through hand-off buffer for the rows crossing a workgroup boundary
 	uint32_t *wf_sync;               // [3][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock (luma), 2 deblock chroma
-	uint64_t *wf_hbuf;               // [n_units][wf_split-1][mb_w][WF_HBUF_GRANULES]
+	uint64_t *wf_hbuf;               // [n_units][WF_MAX_SPLIT-1][mb_w][WF_HBUF_GRANULES] deblock
+	uint64_t *wf_hbuf_intra;         // same shape, intra reconstruction (the two kernels of an IDR picture overlap)
 	int32_t wf_split;                // workgroups per unit: deblock
 	int32_t wf_split_intra;          // workgroups per unit: intra recon
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
@@ -115,6 +116,7 @@ struct Params {
 	// and the stale value of the frame that used the slot before reads as "nothing yet".
 	uint32_t *prog_inter;            // [1] D of this frame's analysis + reconstruction (all streams)
 	uint32_t *prog_db;               // [2][n_units][PROG_BANDS] D of every deblock band written back: luma, then chroma
+	uint32_t *prog_intra;            // [n_units][PROG_BANDS] D of every intra-reconstruction band written back (IDR pictures)
 	const uint32_t *prev_db;         // the previous frame's prog_db (what k_gate waits for)
 	uint32_t prog_tag, prev_tag;
 	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + 2*y < s1 (stripe_s1 <= 0: the whole picture)

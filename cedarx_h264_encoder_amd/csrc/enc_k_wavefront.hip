@@ -492,14 +492,30 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
 		uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
 		auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
-			const uint32_t need = (uint32_t)(t + diag0 + 1);
+			// Intra prediction reads UNFILTERED neighbours and deblocking works in place: filtering
+			// (x, y) changes all of it, row 15 and column 15 included, which intra (x+1, y),
+			// (x-1, y+1), (x, y+1) and (x+1, y+1) still need: in an intra picture the deblock
+			// wavefront stays behind the last of them, three more diagonals.
+			const uint32_t need = (uint32_t)(t + diag0 + (IDR ? 4 : 1));
 			if (inter_seen >= need)
 				return;
+			// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the
+			// intra wavefront publishes per band; this band's rows and the row above them count.
+			const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
+			if (IDR && p.prog_intra) { // the band itself, the one above (top rows) and the one below (its consumers)
+				w0 = p.prog_intra + unit * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1);
+				w1 = band > 0 ? w0 - 1 : w0;
+				w2 = band + 1 < nbands && band + 1 < PROG_BANDS ? w0 + 1 : w0;
+			}
 			uint32_t spins = 0;
 			while (true) {
-				const uint32_t v = __hip_atomic_load(p.prog_inter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((int32_t)(v - (p.prog_tag | need)) >= 0) {
-					inter_seen = v & 0xffffu;
+				const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t want = p.prog_tag | need;
+				if ((int32_t)(v0 - want) >= 0 && (int32_t)(v1 - want) >= 0 && (int32_t)(v2 - want) >= 0) {
+					const uint32_t a = v0 & 0xffffu, b = v1 & 0xffffu, c = v2 & 0xffffu;
+					inter_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
 					break;
 				}
 				if (++spins > (1u << 22)) {
@@ -823,8 +839,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
-	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
-	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint64_t *hb_out = p.wf_hbuf_intra + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf_intra + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
 	uint32_t xseen = 0;
 
 	Ir2GroupLds &L = s_g[trip * 4 + g];
@@ -1341,12 +1357,26 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			}
 		};
 
+		// frame pipelining: this picture's deblocking (another kernel, already resident) follows the
+		// write-back of every band along the diagonals x + 2*y, see k_gate / deblock2_body
+		const int diag0 = 2 * (r0 + 4 * band);
+		auto publish_diag = [&](uint32_t d) {
+			if (!p.prog_intra)
+				return;
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			if (lane == 0)
+				__hip_atomic_store(p.prog_intra + unit * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1),
+						   p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		};
 		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
 			if (t >= 1) {
 				lds_wait_ge(&s_done_y[trip], base + t, xerr);
 				lds_wait_ge(&s_done_c[trip], base + t, xerr);
 			}
 			publish();
+			if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
+				publish_diag((uint32_t)(t - 1 + diag0));
 			if (t + 1 < nsteps) {
 				if (!R.top_ok)
 					load_step(t + 1, true, R);
@@ -1368,6 +1398,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				mover_iter(t + 1, RA);
 		}
 		publish();
+		publish_diag((uint32_t)PROG_ALL);
 	}
 }
 

@@ -666,9 +666,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)3 * WF_SYNC_WORDS))) return rc;
-		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc;
-		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 2 * n_units * PROG_BANDS))) return rc;
-		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 2 * (size_t)n_units * PROG_BANDS)));
+		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
+		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 3 * n_units * PROG_BANDS))) return rc;
+		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 3 * (size_t)n_units * PROG_BANDS)));
 	}
 	{
 		e->prev_slot = e->prev2_slot = -1;
@@ -813,8 +813,10 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.pred4_tab = e->d_pred4;
 	P.wf_sync = e->d_wf_sync[0];
 	P.wf_hbuf = e->d_wf_hbuf[0];
+	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES;
 	P.prog_inter = nullptr;
 	P.prog_db = nullptr;
+	P.prog_intra = nullptr;
 	P.prev_db = nullptr;
 	P.stripe_s0 = 0;
 	P.stripe_s1 = 0;
@@ -916,12 +918,14 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	P.coef = e->d_coef[ds];
 	P.wf_sync = e->d_wf_sync[ds];
 	P.wf_hbuf = e->d_wf_hbuf[ds];
+	P.wf_hbuf_intra = e->d_wf_hbuf[ds] + (size_t)S * e->ext.slice_num * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
 	P.out = e->d_out[ds];
 	const int prev = e->prev_slot, prev2 = e->prev2_slot;
 	const bool pipe = e->row_pipe;
 	if (pipe) {
 		P.prog_inter = e->d_prog[ds];
 		P.prog_db = e->d_prog[ds] + 16;
+		P.prog_intra = e->d_prog[ds] + 16 + 2 * (size_t)S * e->ext.slice_num * PROG_BANDS;
 		P.prev_db = prev >= 0 ? e->d_prog[prev] + 16 : nullptr;
 		P.prog_tag = (uint32_t)(e->frame_count + 1) << 16;
 		P.prev_tag = (uint32_t)e->frame_count << 16;
