@@ -815,8 +815,27 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	__shared__ int s_prog[MAX_ROWS];
 	__shared__ int s_staged[IR_TRIPLES], s_done_y[IR_TRIPLES], s_done_c[IR_TRIPLES];
 	__shared__ int s_ticket;
+	// Intra4x4 predictors as tile offsets: entry [tr][mode][lane] = kind << 24 | the offsets (int8,
+	// relative to the block's first sample in the tile) of edge samples E[k-1], E[k], E[k+1];
+	// tr = 1 when the block's top-right neighbours exist, else E[t4..t7] fold onto t3
+	__shared__ uint32_t s_ptab[2 * 9 * 16];
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int i = threadIdx.x; i < 2 * 9 * 16; i += blockDim.x) {
+		const int tkmax = i >= 9 * 16 ? 7 : 3;
+		const int ent = p.pred4_tab[i % (9 * 16)];
+		const int kind = ent >> 4, k0 = ent & 15;
+		uint32_t w = (uint32_t)kind << 24;
+#pragma unroll
+		for (int j = 0; j < 3; j++) {
+			const int k = max(1, min(13, k0 - 1 + j));
+			// edge entry k -> tile position: E[1..4] = left column bottom-up, E[5] = top-left,
+			// E[6..13] = top row t0..t7
+			const int rel = (max(0, 5 - k) - 1) * IT_STRIDE + max(0, min(k - 6, tkmax) + 1) - 1;
+			w |= (uint32_t)(rel & 0xff) << (8 * j);
+		}
+		s_ptab[i] = w;
+	}
 	// waves land on SIMD wave%4: the three waves of a triple sit on three different SIMDs
 	const int role = wave / IR_TRIPLES, trip = wave % IR_TRIPLES; // 0 luma, 1 chroma, 2 mover
 	const int g = lane >> 4, l = lane & 15;
@@ -863,15 +882,6 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 #pragma unroll
 	for (int z = 0; z < 16; z++)
 		zz = kZigzag[z] == rpos ? z : zz;
-	uint32_t ptab0 = 0, ptab1 = 0, ptab2 = 0;
-	if (role == 0) {
-#pragma unroll
-		for (int m = 0; m < 4; m++) {
-			ptab0 |= (uint32_t)p.pred4_tab[m * 16 + l] << (8 * m);
-			ptab1 |= (uint32_t)p.pred4_tab[(4 + m) * 16 + l] << (8 * m);
-		}
-		ptab2 = p.pred4_tab[8 * 16 + l];
-	}
 	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
 	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
 	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
@@ -932,32 +942,34 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				if (__any(is4)) {
 					if (is4)
 						cf[COEF_DC16 + l] = 0;
+					// neighbour availability of all 16 blocks as bit masks over the coding index
+					// (clause 6.4.11.4): inside the macroblock it is a constant, at its border the
+					// macroblock's own neighbours decide
+					constexpr uint32_t kByGt0 = 0xffccu, kBxGt0 = 0xfafau;          // blocks not in the first row / column
+					constexpr uint32_t kTrInside = 0x5744u;                          // 2,6,8,9,10,12,14
+					constexpr uint32_t kTopRowNotLast = (1u << 0) | (1u << 1) | (1u << 4); // by == 0, bx < 3
+					const uint32_t ht16 = kByGt0 | (top_mb ? 0xffffu : 0u), hl16 = kBxGt0 | (left_mb ? 0xffffu : 0u);
+					const uint32_t htr16 = kTrInside | (top_mb ? kTopRowNotLast : 0u) | (tr_mb ? 1u << 5 : 0u);
+					const uint8_t *T = L.t;
+					// the table entry of block idx+1 is fetched while block idx is computed
+					uint32_t tabw = s_ptab[(((htr16 & 1u) ? 9 : 0) + (int)(modes64 & 15u)) * 16 + l];
 					for (int idx = 0; idx < 16; idx++) {
 						const int bx = blk_x(idx), by = blk_y(idx);
 						int level = 0;
+						const uint32_t cur = tabw;
+						{
+							const int nidx = (idx + 1) & 15;
+							const int nmode = (int)((modes64 >> (4 * nidx)) & 15u);
+							tabw = s_ptab[((((htr16 >> nidx) & 1u) ? 9 : 0) + (nmode < 9 ? nmode : 2)) * 16 + l];
+						}
 						if (is4) {
-							const int tx = 8 + 4 * bx, ty = 1 + 4 * by;
-							bool ht, hl, htr;
-							blk4_avail(idx, top_mb, left_mb, tr_mb, ht, hl, htr);
-							const int mode = (int)((modes64 >> (4 * idx)) & 15u);
-							const uint8_t *T = L.t;
-							const int tkmax = htr ? 7 : 3;
-							auto eaddr = [&](int k) {
-								k = max(1, min(13, k));
-								const int row = ty - 1 + max(0, 5 - k);
-								const int col = tx - 1 + max(0, min(k - 6, tkmax) + 1);
-								return row * IT_STRIDE + col;
-							};
-							const uint32_t pw = mode < 4 ? ptab0 : mode < 8 ? ptab1 : ptab2;
-							const int ent = (int)((pw >> (8 * (mode & 3))) & 0xffu);
-							const int kind = ent >> 4, k = ent & 15;
-							const int ea = T[eaddr(k - 1)], eb = T[eaddr(k)], ec = T[eaddr(k + 1)];
-							int st_ = 0, sl_ = 0;
-#pragma unroll
-							for (int q = 0; q < 4; q++) {
-								st_ += T[(ty - 1) * IT_STRIDE + tx + q];
-								sl_ += T[(ty + q) * IT_STRIDE + tx - 1];
-							}
+							const int a0 = (1 + 4 * by) * IT_STRIDE + 8 + 4 * bx; // the block's first sample
+							const int kind = (int)(cur >> 24);
+							const int ea = T[a0 + (int)(int8_t)(cur & 0xff)], eb = T[a0 + (int)(int8_t)((cur >> 8) & 0xff)],
+								  ec = T[a0 + (int)(int8_t)((cur >> 16) & 0xff)];
+							const int st_ = (int)__builtin_amdgcn_sad_u8(*(const uint32_t *)(T + a0 - IT_STRIDE), 0u, 0u);
+							const int sl_ = (int)T[a0 - 1] + (int)T[a0 + IT_STRIDE - 1] + (int)T[a0 + 2 * IT_STRIDE - 1] + (int)T[a0 + 3 * IT_STRIDE - 1];
+							const bool ht = (ht16 >> idx) & 1u, hl = (hl16 >> idx) & 1u;
 							const int dcv = (ht && hl) ? (st_ + sl_ + 4) >> 3 : hl ? (sl_ + 2) >> 2 : ht ? (st_ + 2) >> 2 : 128;
 							const int pv = sel(nz_mask(kind ^ 3),
 									   sel(nz_mask(kind ^ 2), sel(nz_mask(kind ^ 1), eb, (eb + ec + 1) >> 1),
@@ -969,7 +981,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 							cf_lane[idx * 16] = (int16_t)level;
 							const int d = (level * my_dv) << p.qshift;
 							const int r = idct_lanes(d, ci, cj);
-							L.t[(ty + pi) * IT_STRIDE + tx + pj] = (uint8_t)clip255(pv + r);
+							L.t[a0 + pi * IT_STRIDE + pj] = (uint8_t)clip255(pv + r);
 						}
 						const uint64_t bal = __ballot(is4 && level != 0);
 						const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
