@@ -661,7 +661,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 			slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
 			if ((b - a + 3) / 4 > nb_max) nb_max = (b - a + 3) / 4;
 		}
-		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 8 ? 8 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
+		// Up to 8 units the frames are pipelined (below), which wants the resident deblock
+		// workgroups of 3 frames within half of the CUs: 1080p x 4 streams 55 M MB/s with 4 parts
+		// pipelined against 40 M with 8 parts back to back; x 8: 69 M (2 parts, pipelined) against
+		// 62-67 M; x 16: pipelining loses (80 M against 91 M), frames run back to back from there.
+		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
 		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 2) / 3);
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
@@ -706,7 +710,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		int cus = 0;
 		HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
 		const char *env = getenv("CEDAR_ROW_PIPE");
-		bool want = env ? atoi(env) != 0 : 2 * n_units * e->wf_split * DB_STREAMS <= cus / 2;
+		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * DB_STREAMS <= cus / 2;
 		int usable = 0;
 		for (int i = 0; want && i < DB_STREAMS; i++) {
 			bool ok = false, ok2 = true;

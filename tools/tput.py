@@ -4,10 +4,14 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cedarx_h264_encoder_amd as ce
-W, H = 1920, 1080
+W, H = int(os.environ.get("TPUT_W", "1920")), int(os.environ.get("TPUT_H", "1080"))
+SLICES = int(os.environ.get("TPUT_SLICES", "1"))
+QP = int(os.environ.get("TPUT_QP", "24"))
+MBS = ((W + 15) // 16) * ((H + 15) // 16)
 dev = torch.device("cuda", 0)
 frames = []
-for s in range(8):
+NSRC = 8 if W * H <= 1920 * 1088 else 2
+for s in range(NSRC):
     fr = []
     for f in range(26):
         y, uv = ce.gen_pattern("B", W, H, f, s << 8)
@@ -15,11 +19,11 @@ for s in range(8):
     frames.append(fr)
 torch.cuda.synchronize()
 for S in [int(x) for x in sys.argv[1:]] or [1]:
-    enc = ce.CedarEncoder(width=W, height=H, qp=24, keyframe_interval=int(os.environ.get("KEYINT", "25")), n_streams=S)
+    enc = ce.CedarEncoder(width=W, height=H, qp=QP, keyframe_interval=int(os.environ.get("KEYINT", "25")), n_streams=S, slice_count=SLICES)
     depth = enc.pipeline_depth
     def feed(i):
         for s in range(S):
-            y, uv = frames[s % 8][i % 26 if i % 25 else 0]
+            y, uv = frames[s % NSRC][i % 26 if i % 25 else 0]
             enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
         enc.submit()
     for i in range(25):
@@ -33,5 +37,5 @@ for S in [int(x) for x in sys.argv[1:]] or [1]:
     while q:
         enc.collect(); q -= 1
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("S=%d depth %d: %.3f ms/step, %.2f M MB/s" % (S, depth, dt / n * 1e3, S * 8160 * n / dt / 1e6), flush=True)
+    print("%dx%d slices %d S=%d depth %d: %.3f ms/step, %.2f M MB/s" % (W, H, SLICES, S, depth, dt / n * 1e3, S * MBS * n / dt / 1e6), flush=True)
     enc.close()
