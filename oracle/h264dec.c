@@ -118,5 +118,7 @@ int main(int argc, char **argv)
 		printf(", PSNR Y %.2f dB C %.2f dB", psnr(sse_y, n_y), psnr(sse_c, n_c));
 	printf("\n");
 	h264o_dec_close(d);
+	free(buf);
+	free(src);
 	return 0;
 }

@@ -106,5 +106,8 @@ int main(int argc, char **argv)
 		}
 	}
 	h264o_close(enc);
+	free(luma);
+	free(chroma);
+	free(out);
 	return 0;
 }

@@ -456,7 +456,7 @@ static void scale4x4(const int16_t *lv, int qp, int first, int c[4][4])
 		int ls = level_scale(qp, i, j);
 
 		if (qp >= 24)
-			c[i][j] = (lv[k] * ls) << (qp / 6 - 4);
+			c[i][j] = (lv[k] * ls) * (1 << (qp / 6 - 4));
 		else
 			c[i][j] = (lv[k] * ls + (1 << (3 - qp / 6))) >> (4 - qp / 6);
 	}
@@ -687,7 +687,7 @@ static int decode_residual_and_recon(h264o_dec *d, br *b, dmb *m, int mx, int my
 				int ls = level_scale(qp, 0, 0);
 
 				if (qp >= 36)
-					dcy[i][j] = (g[i][j] * ls) << (qp / 6 - 6);
+					dcy[i][j] = (g[i][j] * ls) * (1 << (qp / 6 - 6));
 				else
 					dcy[i][j] = (g[i][j] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
 			}
@@ -750,10 +750,10 @@ static int decode_residual_and_recon(h264o_dec *d, br *b, dmb *m, int mx, int my
 			int f3 = cdc[c][0] - cdc[c][1] - cdc[c][2] + cdc[c][3];
 			int ls = level_scale(qpc, 0, 0);
 
-			dcc[c][0] = ((f0 * ls) << (qpc / 6)) >> 5;
-			dcc[c][1] = ((f1 * ls) << (qpc / 6)) >> 5;
-			dcc[c][2] = ((f2 * ls) << (qpc / 6)) >> 5;
-			dcc[c][3] = ((f3 * ls) << (qpc / 6)) >> 5;
+			dcc[c][0] = ((f0 * ls) * (1 << (qpc / 6))) >> 5;
+			dcc[c][1] = ((f1 * ls) * (1 << (qpc / 6))) >> 5;
+			dcc[c][2] = ((f2 * ls) * (1 << (qpc / 6))) >> 5;
+			dcc[c][3] = ((f3 * ls) * (1 << (qpc / 6))) >> 5;
 		}
 		for (c = 0; c < 2; c++)
 			for (blk = 0; blk < 4; blk++) {
@@ -993,7 +993,7 @@ static void dec_filter(uint8_t *q0p, int step, int bs, int chroma, int indexA, i
 		int ap = chroma ? 0 : abs(p[2] - p[0]), aq = chroma ? 0 : abs(q[2] - q[0]);
 
 		tc = chroma ? tc0 + 1 : tc0 + (ap < beta) + (aq < beta);
-		delta = clip3(-tc, tc, ((((q[0] - p[0]) << 2) + (p[1] - q[1]) + 4) >> 3));
+		delta = clip3(-tc, tc, ((((q[0] - p[0]) * 4) + (p[1] - q[1]) + 4) >> 3));
 		q0p[-step] = (uint8_t)clip8(p[0] + delta);
 		q0p[0] = (uint8_t)clip8(q[0] - delta);
 		if (!chroma && ap < beta)

@@ -795,7 +795,7 @@ static void chroma_residual(h264o_enc *e, h264o_mb *mb, int mx, int my,
 			fd[2] = c0 + c1 - c2 - c3;
 			fd[3] = c0 - c1 - c2 + c3;
 			for (b = 0; b < 4; b++)
-				dcr[b] = ((fd[b] * h264o_dequant_v[rem][0] * 16) << qs) >> 5;
+				dcr[b] = ((fd[b] * h264o_dequant_v[rem][0] * 16) * (1 << qs)) >> 5;
 		}
 		for (b = 0; b < 4; b++) {
 			int bx = b & 1, by = b >> 1;
@@ -806,7 +806,7 @@ static void chroma_residual(h264o_enc *e, h264o_mb *mb, int mx, int my,
 			for (i = 1; i < 16; i++) {
 				int r = h264o_zigzag4x4[i];
 
-				d[r] = (mb->cac[c][b][i] * h264o_dequant_v[rem][h264o_pos_class[r]]) << qs;
+				d[r] = (mb->cac[c][b][i] * h264o_dequant_v[rem][h264o_pos_class[r]]) * (1 << qs);
 			}
 			for (i = 0; i < 16; i++)
 				blk[i] = predc[c][8 * (4 * by + (i >> 2)) + 4 * bx + (i & 3)];
@@ -838,7 +838,7 @@ static int luma_block_16(const h264o_enc *e, const int16_t res[16], int16_t lv[1
 		lv[i] = (int16_t)l;
 		if (l)
 			n++;
-		d[r] = (l * h264o_dequant_v[rem][h264o_pos_class[r]]) << qs;
+		d[r] = (l * h264o_dequant_v[rem][h264o_pos_class[r]]) * (1 << qs);
 	}
 	idct4x4_add_i32(d, rec, stride); /* rec holds the prediction on entry */
 	return n;
@@ -1061,7 +1061,7 @@ static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0)
 					int ls = 16 * h264o_dequant_v[rem][0];
 
 					if (qp >= 36)
-						dcr[4 * k + i] = (fv[k] * ls) << (qs - 6);
+						dcr[4 * k + i] = (fv[k] * ls) * (1 << (qs - 6));
 					else
 						dcr[4 * k + i] = (fv[k] * ls + (1 << (5 - qs))) >> (6 - qs);
 				}
@@ -1076,7 +1076,7 @@ static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0)
 			for (i = 1; i < 16; i++) {
 				int r = h264o_zigzag4x4[i];
 
-				d[r] = (mb->luma[idx][i] * h264o_dequant_v[rem][h264o_pos_class[r]]) << qs;
+				d[r] = (mb->luma[idx][i] * h264o_dequant_v[rem][h264o_pos_class[r]]) * (1 << qs);
 			}
 			for (y = 0; y < 4; y++)
 				for (x = 0; x < 4; x++)
@@ -1264,7 +1264,7 @@ static void filter_luma_line(uint8_t *pix, int step, int bs, int alpha, int beta
 	aq = abs(q2 - q0);
 	if (bs < 4) {
 		int tc = tc0 + (ap < beta) + (aq < beta);
-		int delta = (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3;
+		int delta = (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3;
 
 		delta = delta < -tc ? -tc : delta > tc ? tc : delta;
 		pix[-step] = (uint8_t)clip255(p0 + delta);
@@ -1311,7 +1311,7 @@ static void filter_chroma_line(uint8_t *pix, int step, int bs, int alpha, int be
 		return;
 	if (bs < 4) {
 		int tc = tc0 + 1;
-		int delta = (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3;
+		int delta = (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3;
 
 		delta = delta < -tc ? -tc : delta > tc ? tc : delta;
 		pix[-step] = (uint8_t)clip255(p0 + delta);

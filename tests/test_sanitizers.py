@@ -1,0 +1,41 @@
+"""The scalar encoder and the test decoder under AddressSanitizer + UBSan (CPU build only:
+the GPU pool runs no sanitizers). A clip with ragged geometry, several slices and both
+picture types goes through both tools; any report makes the tool exit non-zero."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle")
+
+
+@pytest.fixture(scope="module")
+def san_tools():
+    r = subprocess.run(["make", "-C", ORACLE, "san"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])
+    return os.path.join(ORACLE, "build", "h264enc_scalar_san"), os.path.join(ORACLE, "build", "h264dec_san")
+
+
+@pytest.mark.parametrize("w,h,slices,qp", [(70, 50, 1, 24), (176, 144, 3, 30), (64, 48, 2, 47)])
+def test_scalar_encoder_and_decoder_are_sanitizer_clean(san_tools, tmp_path, w, h, slices, qp):
+    enc, dec = san_tools
+    clip = b"".join(np.concatenate(ol.gen_frame("C", w, h, f)).tobytes() for f in range(5))
+    out = tmp_path / "o.264"
+    env = dict(os.environ, H264ENC_QP=str(qp), H264ENC_KEYINT="3", H264ENC_SLICES=str(slices),
+               ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([enc, "-", str(w), str(h), str(out)], input=clip, capture_output=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
+    # same bytes as the regular build of the library
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=3, slice_count=slices))
+    want = b"".join(oe.encode(*ol.gen_frame("C", w, h, f)) for f in range(5))
+    assert out.read_bytes() == want
+    r = subprocess.run([dec, str(out), str(tmp_path / "o.nv12")], capture_output=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
+    assert os.path.getsize(tmp_path / "o.nv12") >= 5 * w * h * 3 // 2
