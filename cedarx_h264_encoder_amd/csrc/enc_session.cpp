@@ -29,6 +29,11 @@ using namespace cedar;
 
 namespace {
 
+// One pipelined session per device and process: two of them would queue polling kernels of
+// one behind polling kernels of the other on shared hardware queues and wait for each other
+// until the spin bounds. Further sessions run their frames back to back.
+std::atomic<int> g_pipelined_sessions[64];
+
 constexpr int DB_STREAMS = 3;
 constexpr int AN_STREAMS = 3;
 
@@ -192,6 +197,7 @@ struct cedar_enc {
 	std::vector<int> stripe_n;        // macroblocks per stripe and stream
 	uint32_t *d_prog[CEDAR_ENC_PIPELINE_DEPTH] = {}; // [0] prog_inter, [16..) prog_db[2][n_units]
 	bool row_pipe = false;      // consecutive frames overlap along the wavefront diagonals (few units)
+	bool holds_pipe_token = false;
 	int db_streams = 1;         // deblock streams that really run beside s_main and each other
 	int inter_bands = 1;
 	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
@@ -711,6 +717,13 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
 		const char *env = getenv("CEDAR_ROW_PIPE");
 		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * DB_STREAMS <= cus / 2;
+		if (want && !e->holds_pipe_token) {
+			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
+				e->holds_pipe_token = true;
+			else
+				g_pipelined_sessions[e->device & 63].fetch_sub(1);
+		}
+		want = want && e->holds_pipe_token;
 		int usable = 0;
 		for (int i = 0; want && i < DB_STREAMS; i++) {
 			bool ok = false, ok2 = true;
@@ -1234,6 +1247,8 @@ extern "C" void cedar_enc_close(cedar_enc *e)
 		hipSetDevice(e->device);
 		hipDeviceSynchronize();
 	}
+	if (e->holds_pipe_token)
+		g_pipelined_sessions[e->device & 63].fetch_sub(1);
 	free_all(e);
 	delete e;
 }

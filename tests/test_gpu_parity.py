@@ -369,3 +369,35 @@ def test_gop_cadence_headers_and_sizes(ce):
             kinds.append([au[i + 4] & 0x1f for i in range(len(au) - 4) if au[i:i + 4] == b"\0\0\0\1"])
         assert kinds[0] == [7, 8, 5]
         assert kinds[1:] == [[1], [1], [5], [1], [1], [5]]
+
+
+def test_two_sessions_interleaved_pipelined(ce):
+    """Only one session per device pipelines its frames on the device (two would queue polling
+    kernels behind each other); a second one still accepts frames in flight and both deliver
+    the oracle's bytes when driven alternately."""
+    w, h = 320, 240
+    frames = [ol.gen_frame("B", w, h, f) for f in range(9)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=4))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4) as a, \
+            ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4) as b:
+        outs = {id(a): [], id(b): []}
+        depth = min(a.pipeline_depth, b.pipeline_depth)
+        q = 0
+        for fr in frames:
+            if q == depth:
+                for enc in (a, b):
+                    enc.collect()
+                    outs[id(enc)].append(enc.output())
+                q -= 1
+            for enc in (a, b):
+                enc.set_input(*fr)
+                enc.submit()
+            q += 1
+        while q:
+            for enc in (a, b):
+                enc.collect()
+                outs[id(enc)].append(enc.output())
+            q -= 1
+    assert outs[id(a)] == want
+    assert outs[id(b)] == want
