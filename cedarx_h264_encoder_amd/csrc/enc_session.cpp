@@ -716,7 +716,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		int cus = 0;
 		HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
 		const char *env = getenv("CEDAR_ROW_PIPE");
-		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * DB_STREAMS <= cus / 2;
+		const char *envd = getenv("CEDAR_DEBLOCK_STREAMS");
+		// measured (1080p, 1 stream, M MB/s): analysis x deblock streams 1x2 16.8, 2x2 15.3-16.7,
+		// 2x3 15.8, 3x3 15.9, 1x3 12: the leanest set that overlaps two deblock kernels wins
+		const int db_max = envd ? atoi(envd) : 2;
+		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * db_max <= cus / 2;
 		if (want && !e->holds_pipe_token) {
 			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
 				e->holds_pipe_token = true;
@@ -725,7 +729,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		}
 		want = want && e->holds_pipe_token;
 		int usable = 0;
-		for (int i = 0; want && i < DB_STREAMS; i++) {
+		for (int i = 0; want && i < DB_STREAMS && usable < db_max; i++) {
 			bool ok = false, ok2 = true;
 			if (Launch::probe_overlap(e->s_db[i], e->s_main, e->d_prog[0], &ok))
 				return fail(e, -EIO, "stream probe failed");
@@ -746,7 +750,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		// stream already accepted (a frame's gate kernels spin while the next frame's run)
 		int an = 1;
 		const char *enva = getenv("CEDAR_ANALYSIS_STREAMS");
-		const int an_max = enva ? atoi(enva) : AN_STREAMS;
+		const int an_max = enva ? atoi(enva) : 1;
 		for (int i = 1; e->row_pipe && i < AN_STREAMS && an < an_max; i++) {
 			bool ok = true, o = false;
 			for (int j = 0; ok && j < e->db_streams; j++)

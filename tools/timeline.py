@@ -41,3 +41,11 @@ if len(ins) > 12:
     for s_, e_, n_, q_ in rows:
         if a <= s_ < b and ("k_input" in n_ or "deblock" in n_ or "intra" in n_ or ("k_gate" in n_ and e_ - s_ > 30000)):
             print("  +%8.1f .. %8.1f us  %-12s %s" % ((s_ - a) / 1e3, (e_ - a) / 1e3, q_, n_.split("(")[0][:40]))
+# around the first IDR of the steady-state window
+idr = [r for r in rows if "intra_recon" in r[2]]
+if idr:
+    c = idr[0][0]
+    print("around an IDR:")
+    for s_, e_, n_, q_ in rows:
+        if c - 1.2e6 <= s_ < c + 5.5e6 and ("k_input" in n_ or "deblock" in n_ or "intra" in n_):
+            print("  %+9.1f .. %+9.1f us  %-10s %s" % ((s_ - c) / 1e3, (e_ - c) / 1e3, q_, n_.split("(")[0][:36]))
