@@ -733,6 +733,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 			bool ok = false, ok2 = true;
 			if (Launch::probe_overlap(e->s_db[i], e->s_main, e->d_prog[0], &ok))
 				return fail(e, -EIO, "stream probe failed");
+			// ... and beside the entropy stream, or every frame's bitstream would queue behind a
+			// deblock kernel that is resident for a whole frame time
+			if (ok && (Launch::probe_overlap(e->s_db[i], e->s_ent, e->d_prog[0], &ok2) || !ok2))
+				ok = false;
+			ok2 = true;
 			for (int j = 0; ok && j < usable; j++) // and beside the deblock streams already accepted
 				if (Launch::probe_overlap(e->s_db[i], e->s_db[j], e->d_prog[0], &ok2) || !ok2)
 					ok = false;
