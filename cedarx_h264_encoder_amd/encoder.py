@@ -243,8 +243,15 @@ class CedarEncoder:
         return self.output(stream)
 
     # -- instrumentation --
-    def set_profiling(self, on=True):
-        self._L.cedar_enc_set_profiling(self._h, 1 if on else 0)
+    def set_profiling(self, on=True, stages=None):
+        """HIP-event timing of the stages: all of them, or only the named ones (cheaper)."""
+        if on and stages:
+            mask = 0
+            for name in stages:
+                mask |= 1 << (1 + STAGES.index(name))
+            self._L.cedar_enc_set_profiling(self._h, mask)
+        else:
+            self._L.cedar_enc_set_profiling(self._h, 1 if on else 0)
 
     def stats(self):
         s = _Stats()
