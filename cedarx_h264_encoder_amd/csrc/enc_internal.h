@@ -166,6 +166,9 @@ struct Launch {
 	// 1 wave: publish prog_inter = publish_d (if >= 0), then wait until every deblock band of the
 	// previous frame has written back all macroblocks with x + 2*y < need_d (if > 0)
 	static int gate(const Params &p, void *stream, int publish_d, int need_d);
+	// d_out[0 .. stream_size[n_streams]) and the size words -> pinned host memory, by the GPU itself
+	// (coalesced 16-byte stores over PCIe): no hipMemcpyAsync on the per-frame path
+	static int copy_out(const Params &p, void *stream, uint8_t *host_out, uint32_t *host_sizes);
 	// 1 thread: *word = value with system scope (completion flags in pinned host memory)
 	static int flag(void *stream, uint32_t *word, uint32_t value);
 	// concurrency probe: does a kernel on `waiter` see a flag set by a later launch on `setter`?

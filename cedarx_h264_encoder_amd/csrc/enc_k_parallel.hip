@@ -440,6 +440,26 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// k_copy_out: the frame's bitstreams (compact, all streams back to back) and their sizes go
+// to the caller's pinned buffers by plain coalesced stores; host_out / host_sizes are device
+// views of mapped host memory. hipMemcpyAsync did this before: its staging stalled a submit
+// for ~7 ms three times while a pipeline of frames warmed up, and the size had to be guessed.
+__global__ __launch_bounds__(256) void k_copy_out(Params p, uint8_t *host_out, uint32_t *host_sizes)
+{
+	const uint32_t total = p.stream_size[p.n_streams];
+	const uint32_t n16 = ((total < (uint32_t)p.out_cap ? total : (uint32_t)p.out_cap) + 15u) >> 4;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x)
+		((u32x4 *)host_out)[i] = ((const u32x4 *)p.out)[i];
+	if (blockIdx.x == 0 && (int)threadIdx.x < p.n_streams + 2)
+		host_sizes[threadIdx.x] = p.stream_size[threadIdx.x];
+}
+
+int Launch::copy_out(const Params &p, void *stream, uint8_t *host_out, uint32_t *host_sizes)
+{
+	hipLaunchKernelGGL(k_copy_out, dim3(p.n_streams > 4 ? 256 : 64), dim3(256), 0, (hipStream_t)stream, p, host_out, host_sizes);
+	return (int)hipGetLastError();
+}
+
 __global__ void k_flag(uint32_t *word, uint32_t value)
 {
 	__hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -142,8 +142,8 @@ struct InFlight {
 	bool with_ps = false;  // SPS+PPS precede this frame's slices
 	hipEvent_t done_main = nullptr, done_ent = nullptr; // done_main: reconstruction deblocked (stream s_db)
 	int ds = 0; // device slot (frame number % depth) holding this frame's device-side state
-	SliceHdr *h_hdr = nullptr;   // pinned staging for the per-frame slice headers
-	uint32_t *h_prefix = nullptr;
+	SliceHdr *h_hdr = nullptr, *dv_hdr = nullptr;   // pinned + mapped per-frame slice headers, read by the kernels in place
+	uint32_t *h_prefix = nullptr, *dv_prefix = nullptr;
 	uint32_t *h_wf_err = nullptr; // pinned word the wavefront kernels write an error code to
 	uint32_t *d_wf_err = nullptr; // the same word as the device sees it
 	// completion flags in pinned host memory, written by 1-thread kernels at the end of the
@@ -204,8 +204,8 @@ struct cedar_enc {
 	int wf_split = 1, wf_split_intra = 1;
 	// pinned host memory
 	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
-	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = {};
-	uint32_t *h_sizes[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = {}, *dv_out[CEDAR_ENC_PIPELINE_DEPTH] = {};     // pinned + mapped, and its device view
+	uint32_t *h_sizes[CEDAR_ENC_PIPELINE_DEPTH] = {}, *dv_sizes[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	size_t out_cap = 0;
 	// streams / events
 	// s_main: input + analysis of all frames in order; s_db[frame % DB_STREAMS]: deblocking (the
@@ -584,12 +584,16 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S, hipHostMallocDefault));
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S, hipHostMallocDefault));
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
-		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap, hipHostMallocDefault));
-		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (S + 2) * sizeof(uint32_t), hipHostMallocDefault));
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, hipHostMallocMapped));
+		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (S + 2) * sizeof(uint32_t), hipHostMallocMapped));
+		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_sizes[i], e->h_sizes[i], 0));
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
-		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * ext.slice_num, hipHostMallocDefault));
-		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocDefault));
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * ext.slice_num, hipHostMallocMapped));
+		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_hdr, e->fl[i].h_hdr, 0));
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocMapped));
+		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_prefix, e->fl[i].h_prefix, 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_wf_err, sizeof(uint32_t), hipHostMallocMapped));
 		*e->fl[i].h_wf_err = 0;
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].d_wf_err, e->fl[i].h_wf_err, 0));
@@ -638,7 +642,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	if ((rc = dalloc(e, &e->d_nal_size, (size_t)n_units))) return rc;
 	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 3))) return rc;
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++)
-		if ((rc = dalloc(e, &e->d_out[i], e->out_cap))) return rc;
+		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_hdr, (size_t)ext.slice_num))) return rc;
 	if ((rc = dalloc(e, &e->d_prefix, (size_t)S))) return rc;
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
@@ -1096,21 +1100,16 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		f.h_prefix[s] = with_ps ? (uint32_t)e->sps_pps.size() : 0;
 	HIP_TRY(e, hipStreamWaitEvent(e->s_ent, e->ev_analysis[ds], 0));
 	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
-	HIP_TRY(e, hipMemcpyAsync(e->d_hdr, f.h_hdr, sizeof(SliceHdr) * e->ext.slice_num, hipMemcpyHostToDevice, e->s_ent));
-	HIP_TRY(e, hipMemcpyAsync(e->d_prefix, f.h_prefix, sizeof(uint32_t) * S, hipMemcpyHostToDevice, e->s_ent));
+	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
+	P.prefix_len = f.dv_prefix;
 	HIP_TRY(e, hipMemsetAsync(e->d_stream_size, 0, sizeof(uint32_t) * (S + 3), e->s_ent));
 	if (Launch::entropy(P, e->s_ent))
 		return fail(e, -EIO, "entropy launch failed");
 	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
 	f.host_out = slot; // every frame in flight owns one host buffer until it is collected
-	uint32_t spec = e->last_total ? e->last_total * 2 + 65536 : 262144;
-	if (idr && spec < 1u << 20)
-		spec = 1u << 20;
-	if (spec > e->out_cap)
-		spec = (uint32_t)e->out_cap;
-	f.spec_bytes = spec;
-	HIP_TRY(e, hipMemcpyAsync(e->h_sizes[slot], e->d_stream_size, sizeof(uint32_t) * (S + 2), hipMemcpyDeviceToHost, e->s_ent));
-	HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out], e->d_out[ds], spec, hipMemcpyDeviceToHost, e->s_ent));
+	f.spec_bytes = 0;
+	if (Launch::copy_out(P, e->s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
+		return fail(e, -EIO, "k_copy_out launch failed");
 	HIP_TRY(e, hipEventRecord(f.done_ent, e->s_ent));
 	if (Launch::flag(e->s_ent, f.d_done, f.done_tag))
 		return fail(e, -EIO, "k_flag launch failed");
@@ -1182,11 +1181,6 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 		return fail(e, -EIO, "wavefront hand-off timed out (flags %u)", *f.h_wf_err);
 	if (flags || total > e->out_cap)
 		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
-	if (total > f.spec_bytes) {
-		HIP_TRY(e, hipMemcpyAsync(e->h_out[f.host_out] + f.spec_bytes, e->d_out[f.ds] + f.spec_bytes,
-					  total - f.spec_bytes, hipMemcpyDeviceToHost, e->s_ent));
-		HIP_TRY(e, hipStreamSynchronize(e->s_ent));
-	}
 	uint32_t off = 0;
 	for (int s = 0; s < S; s++) {
 		e->res_off[s] = off;
