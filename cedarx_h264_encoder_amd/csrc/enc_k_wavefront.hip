@@ -518,12 +518,17 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					inter_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
 					break;
 				}
-				if (++spins > (1u << 22)) {
+				if (++spins > (1u << 20)) {
 					__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					inter_seen = 0x7fffffffu;
 					break;
 				}
-				__builtin_amdgcn_s_sleep(16);
+				// a kernel that waits for its frame's analysis is resident for a long time, and every
+				// poll is a trip to memory: after a few quick looks, look every ~3 us
+				if (spins < 8)
+					__builtin_amdgcn_s_sleep(16);
+				else
+					__builtin_amdgcn_s_sleep(127);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		};
