@@ -890,6 +890,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
 	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
 	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
+	const int my_mfc = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
+	const int my_dvc = pclass == 0 ? p.dvc[0] : pclass == 1 ? p.dvc[1] : p.dvc[2];
 
 	int iter = 0;
 	for (int band = b_lo + trip; band < b_hi; band += IR_TRIPLES, iter++) {
@@ -1119,89 +1121,90 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					}
 				}
 				WAVE_SYNC();
+				// lane = sample of a 4x4 block (as the Intra4x4 path): the group walks the 8 chroma
+				// blocks of its macroblock twice, transforms across lanes with DPP. Prediction only
+				// reads the row above and the column left of the macroblock, so nothing written here
+				// is read back within the step.
 				int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
-				int cnn = 0, cdcnz = 0;
-				const bool is_c = act && l < 8;
-				const int c = l >> 2, blk = l & 3;
-				const int bx = blk & 1, by = blk >> 1;
 				const uint8_t *T = L.c;
-				int cd[16];
-				int dcv = 128, pa = 0, pb = 0, pc = 0;
-#define CT(xx, yy) T[(1 + (yy)) * IC_STRIDE + 8 + 2 * (xx) + c]
-				auto predc = [&](int x, int y) {
-					return chroma_mode == 0 ? dcv
-					     : chroma_mode == 1 ? (int)CT(-1, y)
-					     : chroma_mode == 2 ? (int)CT(x, -1)
-					     : clip255((pa + pb * (x - 3) + pc * (y - 3) + 16) >> 5);
-				};
-				if (is_c) {
-					int stp = 0, slf = 0, H = 0, V = 0;
-					for (int k = 0; k < 4; k++) {
-						stp += CT(4 * bx + k, -1);
-						slf += CT(-1, 4 * by + k);
-						H += (k + 1) * ((int)CT(4 + k, -1) - (int)CT(2 - k, -1));
-						V += (k + 1) * ((int)CT(-1, 4 + k) - (int)CT(-1, 2 - k));
+				int plane_a[2] = { 0, 0 }, plane_b[2] = { 0, 0 }, plane_c[2] = { 0, 0 };
+				if (__any(act && chroma_mode == 3)) {
+#pragma unroll
+					for (int c = 0; c < 2; c++) {
+						int H = 0, V = 0;
+#pragma unroll
+						for (int k = 0; k < 4; k++) {
+							H += (k + 1) * ((int)T[8 + 2 * (4 + k) + c] - (int)T[8 + 2 * (2 - k) + c]);
+							V += (k + 1) * ((int)T[(1 + 4 + k) * IC_STRIDE + 6 + c] - (int)T[(1 + 2 - k) * IC_STRIDE + 6 + c]);
+						}
+						plane_a[c] = 16 * ((int)T[(1 + 7) * IC_STRIDE + 6 + c] + (int)T[8 + 2 * 7 + c]);
+						plane_b[c] = (34 * H + 32) >> 6;
+						plane_c[c] = (34 * V + 32) >> 6;
 					}
+				}
+				int pvs[8], cdq[8];
+				uint32_t ac_any = 0;
+#pragma unroll
+				for (int it = 0; it < 8; it++) {
+					const int c = it >> 2, blk = it & 3, bx = blk & 1, by = blk >> 1;
+					const int x = 4 * bx + pj, y = 4 * by + pi;
+					// DC of this block (clause 8.3.4.1-3): 4 samples above / left of the block
+					const uint32_t m = 0x00ff00ffu << (8 * c);
+					const uint32_t t0 = *(const uint32_t *)(T + 8 + 8 * bx), t1 = *(const uint32_t *)(T + 12 + 8 * bx);
+					const int stp = (int)__builtin_amdgcn_sad_u8(t0 & m, 0u, 0u) + (int)__builtin_amdgcn_sad_u8(t1 & m, 0u, 0u);
+					const int slf = (int)T[(1 + 4 * by) * IC_STRIDE + 6 + c] + (int)T[(2 + 4 * by) * IC_STRIDE + 6 + c] +
+							(int)T[(3 + 4 * by) * IC_STRIDE + 6 + c] + (int)T[(4 + 4 * by) * IC_STRIDE + 6 + c];
 					bool use_t = top_mb, use_l = left_mb;
 					if (bx == 1 && by == 0 && top_mb)
 						use_l = false;
 					if (bx == 0 && by == 1 && left_mb)
 						use_t = false;
-					dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
-					pa = 16 * ((int)CT(-1, 7) + (int)CT(7, -1));
-					pb = (34 * H + 32) >> 6;
-					pc = (34 * V + 32) >> 6;
-					int w[16];
-					{
-						int res[16];
-#pragma unroll
-						for (int i = 0; i < 16; i++) {
-							const int x = 4 * bx + (i & 3), y = 4 * by + (i >> 2);
-							res[i] = (int)SC[y * 16 + 2 * x + c] - predc(x, y);
-						}
-						fdct4x4(res, w);
-					}
-					L.cdc[l] = w[0];
-					cf[COEF_CAC + (4 * c + blk) * 16] = 0;
-#pragma unroll
-					for (int i = 1; i < 16; i++) {
-						const int r = kZigzag[i], cl = kPosClass[r];
-						const int lq = quant1(w[r], p.mfc[cl], f_intra_c, p.qbits_c);
-						cf[COEF_CAC + (4 * c + blk) * 16 + i] = (int16_t)lq;
-						cnn += lq != 0;
-						cd[r] = (lq * p.dvc[cl]) << p.qshift_c;
-					}
+					const int dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
+					const int ph = T[(1 + y) * IC_STRIDE + 6 + c], pvv = T[8 + 2 * x + c];
+					const int pp = clip255((plane_a[c] + plane_b[c] * (x - 3) + plane_c[c] * (y - 3) + 16) >> 5);
+					const int pv = chroma_mode == 0 ? dcv : chroma_mode == 1 ? ph : chroma_mode == 2 ? pvv : pp;
+					const int res = (int)SC[y * 16 + 2 * x + c] - pv;
+					const int w = fdct_lanes(res, ci, cj);
+					if (act && l == 0)
+						L.cdc[4 * c + blk] = w; // lane (0,0) holds the DC coefficient
+					const int level = l == 0 ? 0 : quant1(w, my_mfc, f_intra_c, p.qbits_c);
+					if (act)
+						cf[COEF_CAC + (4 * c + blk) * 16 + zz] = (int16_t)level;
+					cdq[it] = (level * my_dvc) << p.qshift_c;
+					pvs[it] = pv;
+					const uint64_t bal = __ballot(act && level != 0);
+					const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
+					if (act && l == 0)
+						p.nnz[mbaddr * NNZ_PER_MB + 16 + 4 * c + blk] = (uint8_t)nn;
+					ac_any |= (uint32_t)nn;
 				}
 				WAVE_SYNC();
-				if (is_c) {
+				int cdcnz = 0;
+				if (act && l < 8) { // 2x2 Hadamard of the chroma DCs: lane = (plane, output index)
+					const int c = l >> 2, blk = l & 3;
 					const int *dcs = L.cdc + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
 					const int lq = quant1(hd, p.mfc[0], 2 * f_intra_c, p.qbits_c + 1);
 					L.cdl[l] = lq;
-					cf[COEF_CDC + 4 * c + blk] = (int16_t)lq;
+					cf[COEF_CDC + l] = (int16_t)lq;
 					cdcnz = lq != 0;
 				}
 				WAVE_SYNC();
-				if (is_c) {
+#pragma unroll
+				for (int it = 0; it < 8; it++) {
+					const int c = it >> 2, blk = it & 3, bx = blk & 1, by = blk >> 1;
+					const int x = 4 * bx + pj, y = 4 * by + pi;
 					const int *ls = L.cdl + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
-					cd[0] = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
-					int pred[16], out[16];
-#pragma unroll
-					for (int i = 0; i < 16; i++)
-						pred[i] = predc(4 * bx + (i & 3), 4 * by + (i >> 2));
-					idct4x4_add(cd, pred, out);
-					__builtin_amdgcn_wave_barrier();
-#pragma unroll
-					for (int i = 0; i < 16; i++)
-						L.c[(1 + 4 * by + (i >> 2)) * IC_STRIDE + 8 + 2 * (4 * bx + (i & 3)) + c] = (uint8_t)out[i];
-					p.nnz[mbaddr * NNZ_PER_MB + 16 + l] = (uint8_t)cnn;
+					const int dcr = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
+					const int r = idct_lanes(l == 0 ? dcr : cdq[it], ci, cj);
+					if (act)
+						L.c[(1 + y) * IC_STRIDE + 8 + 2 * x + c] = (uint8_t)clip255(pvs[it] + r);
 				}
-#undef CT
-				const uint64_t acm = __ballot(cnn != 0), dcm = __ballot(cdcnz != 0);
-				const uint32_t ac = (uint32_t)(acm >> (16 * g)) & 0xffffu, dcb = (uint32_t)(dcm >> (16 * g)) & 0xffffu;
+				const uint64_t dcm = __ballot(cdcnz != 0);
+				const uint32_t ac = ac_any, dcb = (uint32_t)(dcm >> (16 * g)) & 0xffffu;
 				WAVE_SYNC();
 				if (act) {
 					if (l < 8)
