@@ -35,22 +35,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
 	} while (0)
 
-constexpr int MAX_ROWS = 512; // MB rows of one unit (8K pictures)
-
-DEVI void wait_progress(volatile int *prog, int idx, int need)
-{
-	// wave-uniform spin on an LDS word written by another wave of this workgroup
-	while (__hip_atomic_load((int *)&prog[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-		__builtin_amdgcn_s_sleep(1);
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-DEVI void publish_progress(volatile int *prog, int idx, int value)
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__hip_atomic_store((int *)&prog[idx], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // ---- hand-off between the workgroups (CUs) that share one unit's wavefront ----
 // Producer: payload as 8-byte write-through (agent-scope relaxed atomic = sc1)
 // stores, every storing wave drains with s_waitcnt vmcnt(0), then ONE lane stores
@@ -879,7 +863,10 @@ DEVI int i4_block(const uint32_t *ptab, const I4Ctx &c, const LaneK &ci, const L
 __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 {
 	__shared__ Ir2GroupLds s_g[IR_TRIPLES * 4];
-	__shared__ int s_prog[MAX_ROWS];
+	// last reconstructed row of every band's bottom macroblock row, for the triple that does the
+	// band below (dynamic LDS: 2 x IR_TRIPLES rows of mb_w * 16 + 32 bytes; the rest of the
+	// request is padding that keeps one workgroup per CU)
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];
 	__shared__ int s_staged[IR_TRIPLES], s_done_y[IR_TRIPLES], s_done_c[IR_TRIPLES];
 	// Intra4x4 stages finished in the current step by the luma wave (a) and the chroma wave (b),
 	// as (absolute step) * 16 + stages: the two share the 16 blocks of a macroblock, see i4 below
@@ -913,8 +900,6 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	uint32_t *sync = p.wf_sync; // region 0
 	if (threadIdx.x == 0)
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
-	for (int i = threadIdx.x; i < MAX_ROWS; i += blockDim.x)
-		s_prog[i] = 0;
 	if (threadIdx.x < IR_TRIPLES) {
 		s_staged[threadIdx.x] = 0;
 		s_done_y[threadIdx.x] = 0;
@@ -969,6 +954,13 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		const bool xwg_band = band == b_lo && b_lo > 0;
 		const bool xwg_top = g == 0 && xwg_band;
 		const bool is_xprod = g == 3 && band == b_hi - 1 && b_hi < nbands;
+		// bands of one workgroup hand their last row on through LDS, compute wave to compute wave
+		// (as groups of one wave do), without a detour through memory and the mover
+		const int rel = band - b_lo, row_bytes = p.mb_w * 16 + 32;
+		const bool in_top = rel > 0, in_bot = band + 1 < b_hi;
+		const int trip_up = (rel + IR_TRIPLES - 1) % IR_TRIPLES, base_up = ((rel - 1) / IR_TRIPLES) * (nsteps + 2);
+		uint8_t *const rowy_mine = s_rows + (size_t)(2 * trip) * row_bytes, *const rowc_mine = rowy_mine + row_bytes;
+		const uint8_t *const rowy_up = s_rows + (size_t)(2 * trip_up) * row_bytes, *const rowc_up = rowy_up + row_bytes;
 
 		if (role == 0) {
 			// ============================ luma wave ============================
@@ -983,11 +975,21 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				const uint64_t modes64 = (uint64_t)L.info[slot][2] | (uint64_t)L.info[slot][3] << 32;
 				const int mb_type = (int)(int8_t)(miw & 0xff), i16_mode = (int)((miw >> 8) & 0xff);
 				const uint8_t *SY = L.srcy[slot];
+				if (in_top && t < p.mb_w) // the macroblock above-right of group 0's is reconstructed
+					lds_wait_ge(&s_done_y[trip_up], base_up + (t + 8 < nsteps ? t + 8 : nsteps), xerr);
 				if (act) {
 					if (left_mb) // left neighbours = last column of the previous macroblock
 						L.t[(1 + l) * IT_STRIDE + 7] = L.t[(1 + l) * IT_STRIDE + 23];
 					if (top_mb) {
-						if (g == 0) { // staged by the mover
+						if (g == 0 && in_top) { // the triple above left its last row in LDS
+							const uint8_t *rp = rowy_up + 16 + mx * 16;
+							if (l == 0)
+								*(u32x4 *)(L.t + 8) = *(const u32x4 *)rp;
+							else if (l == 1 && tr_mb)
+								*(uint32_t *)(L.t + 24) = *(const uint32_t *)(rp + 16);
+							else if (l == 2 && left_mb)
+								L.t[7] = rp[-1];
+						} else if (g == 0) { // another workgroup's: staged by the mover
 							if (l == 0)
 								*(u32x4 *)(L.t + 8) = *(const u32x4 *)(L.topy[slot] + 8);
 							else if (l == 1 && tr_mb)
@@ -1131,8 +1133,12 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				WAVE_SYNC();
 				if (act) { // hand the macroblock to the mover and its last row to the group below
 					*(u32x4 *)(L.outy[slot] + l * 16) = *(const u32x4 *)(L.t + (1 + l) * IT_STRIDE + 8);
-					if (l == 15)
-						*(u32x4 *)L.boty[mx & 3] = *(const u32x4 *)(L.t + 16 * IT_STRIDE + 8);
+					if (l == 15) {
+						const u32x4 last = *(const u32x4 *)(L.t + 16 * IT_STRIDE + 8);
+						*(u32x4 *)L.boty[mx & 3] = last;
+						if (g == 3 && in_bot)
+							*(u32x4 *)(rowy_mine + 16 + mx * 16) = last;
+					}
 					if (l == 0)
 						L.cbp_y[slot] = cbp;
 				}
@@ -1152,16 +1158,19 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				lds_wait_ge(&s_staged[trip], base + t + 1, xerr);
 				const int chroma_mode = (int)((L.info[slot][0] >> 16) & 0xff);
 				const uint8_t *SC = L.srcc[slot];
+				if (in_top && t < p.mb_w) // only the macroblock above is needed here, but the luma wave's bound is as good
+					lds_wait_ge(&s_done_c[trip_up], base_up + (t + 7 < nsteps ? t + 7 : nsteps), xerr);
 				if (act) {
 					if (left_mb && l < 8)
 						*(uint16_t *)(L.c + (1 + l) * IC_STRIDE + 6) = *(const uint16_t *)(L.c + (1 + l) * IC_STRIDE + 22);
 					if (top_mb) {
-						const uint8_t *tp = g == 0 ? L.topc[slot] + 8 : LU.botc[mx & 3];
+						const uint8_t *rp = rowc_up + 16 + mx * 16;
+						const uint8_t *tp = g > 0 ? LU.botc[mx & 3] : in_top ? rp : L.topc[slot] + 8;
 						if (l == 8)
 							*(u32x4 *)(L.c + 8) = *(const u32x4 *)tp;
 						else if (l == 9 && left_mb)
-							*(uint16_t *)(L.c + 6) = g == 0 ? *(const uint16_t *)(L.topc[slot] + 6)
-											: *(const uint16_t *)(LU.botc[(mx - 1) & 3] + 14);
+							*(uint16_t *)(L.c + 6) = g > 0 ? *(const uint16_t *)(LU.botc[(mx - 1) & 3] + 14)
+									       : in_top ? *(const uint16_t *)(rp - 2) : *(const uint16_t *)(L.topc[slot] + 6);
 					}
 				}
 				WAVE_SYNC();
@@ -1283,8 +1292,12 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				if (act) {
 					if (l < 8)
 						*(u32x4 *)(L.outc[slot] + l * 16) = *(const u32x4 *)(L.c + (1 + l) * IC_STRIDE + 8);
-					else if (l == 8)
-						*(u32x4 *)L.botc[mx & 3] = *(const u32x4 *)(L.c + 8 * IC_STRIDE + 8);
+					else if (l == 8) {
+						const u32x4 last = *(const u32x4 *)(L.c + 8 * IC_STRIDE + 8);
+						*(u32x4 *)L.botc[mx & 3] = last;
+						if (g == 3 && in_bot)
+							*(u32x4 *)(rowc_mine + 16 + mx * 16) = last;
+					}
 					else if (l == 9)
 						L.cbp_c[slot] = ac ? 0x20 : (dcb ? 0x10 : 0);
 				}
@@ -1300,7 +1313,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			bool top_ok;
 		};
 		MoverRegs RA{}, RB{};
-		int pending_pub = -1, pending_x = -1;
+		int pending_x = -1;
 
 		auto load_step = [&](int t, bool block, MoverRegs &R) {
 			const int nmx = t - 2 * g, mx0 = t;
@@ -1311,16 +1324,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			const bool left_mb = nmx > 0, tr_mb = top_mb && nmx < p.mb_w - 1;
 			R.top_ok = true;
 			const int need = mx0 + 2 < p.mb_w ? mx0 + 2 : p.mb_w; // the macroblock above-right must be done
-			if (band > b_lo && mx0 < p.mb_w) {
-				bool ready = __hip_atomic_load(&s_prog[4 * band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
-				if (!ready && block) {
-					wait_progress(s_prog, 4 * band - 1, need);
-					ready = true;
-				}
-				if (ready)
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				R.top_ok = ready;
-			} else if (xwg_band && mx0 < p.mb_w) {
+			if (xwg_band && mx0 < p.mb_w) { // rows above live in another workgroup
+
 				if (xseen < (uint32_t)need)
 					xseen = xload32(&xprog[wj - 1]);
 				if (xseen < (uint32_t)need && block)
@@ -1332,7 +1337,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			R.mi = *(const uint64_t *)&p.mbi[a];
 			R.modes = *(const u32x4 *)(p.i4modes + a * 16);
 			R.ta = R.tb = 0;
-			if (g == 0 && top_mb && nact && R.top_ok) {
+			if (g == 0 && top_mb && nact && R.top_ok && !in_top) {
 				if (xwg_top) { // the other workgroup's write-through buffer
 					const uint64_t *hb = hb_in + (size_t)cmx * WF_HBUF_GRANULES;
 					if (l == 8 || l == 9)
@@ -1382,7 +1387,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					modes64 |= (uint64_t)((mw[k >> 2] >> (8 * (k & 3))) & 15u) << (4 * k);
 				*(u32x4 *)L.info[slot] = u32x4{ (uint32_t)R.mi, (uint32_t)(R.mi >> 32), (uint32_t)modes64, (uint32_t)(modes64 >> 32) };
 			}
-			if (g == 0 && top_mb) {
+			if (g == 0 && top_mb && !in_top) {
 				if (xwg_top) {
 					if (l == 8 || l == 9)
 						*(uint64_t *)(L.topy[slot] + 8 + (l - 8) * 8) = R.ta;
@@ -1428,7 +1433,6 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				const uint32_t w0 = (L.info[slot][0] & 0x00ffffffu) | cbp << 24;
 				*(uint64_t *)&p.mbi[mbaddr] = (uint64_t)w0 | (uint64_t)L.info[slot][1] << 32;
 			}
-			pending_pub = mx;
 			if (is_xprod) {
 				if (l < 4) {
 					const uint8_t *srcp = l < 2 ? L.outy[slot] + 15 * 16 + l * 8 : L.outc[slot] + 7 * 16 + (l - 2) * 8;
@@ -1439,10 +1443,6 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		};
 
 		auto publish = [&]() { // everything issued an iteration ago has completed by now
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (pending_pub >= 0 && l == 0)
-				__hip_atomic_store(&s_prog[my - r0], pending_pub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			pending_pub = -1;
 			if (b_hi < nbands && band == b_hi - 1) {
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				if (is_xprod && l == 0 && pending_x >= 0)
@@ -1523,7 +1523,9 @@ int Launch::intra_recon(const Params &p, void *stream)
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split_intra);
 	// wavefront workgroups are throughput-bound on their CU: enough (unused dynamic) LDS that
 	// two of them can never share one CU (160 KiB per CU)
-	hipLaunchKernelGGL(k_intra_recon2, grid, dim3(64 * 3 * IR_TRIPLES), 64 * 1024, (hipStream_t)stream, p);
+	// dynamic LDS: the band-to-band row buffers, padded so that two workgroups never share a CU
+	const size_t rows = (size_t)2 * IR_TRIPLES * (p.mb_w * 16 + 32);
+	hipLaunchKernelGGL(k_intra_recon2, grid, dim3(64 * 3 * IR_TRIPLES), rows > 64 * 1024 ? rows : 64 * 1024, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 
