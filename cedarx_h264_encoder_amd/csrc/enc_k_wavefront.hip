@@ -780,7 +780,7 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2_planes(Params p, int
 // The step is then the luma chain alone. Bottom rows travel between the groups of one
 // compute wave through LDS rings (boty / botc); band and workgroup boundaries as before.
 // ------------------------------------------------------------------------
-constexpr int IR_TRIPLES = 3;
+constexpr int IR_TRIPLES = 4; // 12 waves = 3 per SIMD: 168 VGPRs each, the same budget as 3 triples (9 waves) get
 
 struct __attribute__((aligned(16))) Ir2GroupLds {
 	uint8_t t[17 * IT_STRIDE];  // luma wave's tile (persists: column 15 is the next left neighbour)
@@ -894,7 +894,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		s_ptab[i] = w;
 	}
 	// waves land on SIMD wave%4: the three waves of a triple sit on three different SIMDs
-	const int role = wave / IR_TRIPLES, trip = wave % IR_TRIPLES; // 0 luma, 1 chroma, 2 mover
+	static_assert(IR_TRIPLES == 4, "wave -> (role, triple) below assumes 4 SIMDs = 4 triples");
+	const int role = wave / IR_TRIPLES, trip = (wave - role) & 3; // 0 luma, 1 chroma, 2 mover: triple k on SIMDs k, k+1, k+2
 	const int g = lane >> 4, l = lane & 15;
 	const int NWG = p.wf_split_intra;
 	uint32_t *sync = p.wf_sync; // region 0

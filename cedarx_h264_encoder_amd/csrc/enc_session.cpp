@@ -677,7 +677,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		// pipelined against 40 M with 8 parts back to back; x 8: 69 M (2 parts, pipelined) against
 		// 62-67 M; x 16: pipelining loses (80 M against 91 M), frames run back to back from there.
 		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
-		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 2) / 3);
+		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 3) / 4);
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)3 * WF_SYNC_WORDS))) return rc;
