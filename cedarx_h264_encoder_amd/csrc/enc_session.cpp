@@ -664,8 +664,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		// Measured on MI355X, 1080p (17 bands of 4 macroblock rows per unit), see DESIGN.md:
 		//   deblock (8 filter/mover pairs per workgroup): 1 unit 0.64 / 0.51 / 0.47 ms at 2 / 4 / 8
 		//   parts; 32 units 1.06 / 0.89 / 0.82 ms at 1 / 2 / 4 parts
-		//   intra recon (3 luma/chroma/mover triples per workgroup): a workgroup with more than 3
-		//   bands serialises them, 7.1 ms at 4 parts against 3.3 ms at 6 (1 unit)
+		//   intra recon (4 luma/chroma/mover triples per workgroup): a workgroup with more bands
+		//   than triples serialises them (3 triples: 7.1 ms at 4 parts against 3.3 ms at 6, 1 unit)
 		int nb_max = 0;
 		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
 			int a, b;
