@@ -116,7 +116,6 @@ DEVI int hsign(int i, int a)
 // ------------------------------------------------------------------------
 #define DT_STRIDE 32 // luma tile: (x,y) at [(4+y)*32 + 16 + x], x,y in [-4,15]
 #define DC_STRIDE 32 // chroma tile (nv12): (x,y,c) at [(2+y)*32 + 16 + 2x + c], x,y in [-2,7]
-// #define DB2_TIMING 1
 // Edge codes: the mover turns every boundary strength into one byte, 0x80 | tc0 (0 = edge
 // not filtered), so the filter wave spends two bit-field extracts on it. |a-b|+c on byte
 // values is one v_sad_u8; thresholds go in negated so the sign bit is the comparison.
@@ -297,22 +296,12 @@ DEVI void deblock2_body(const Params &p, const int wg)
 
 		if (!is_mover) {
 			// =========================== filter wave ===========================
-#ifdef DB2_TIMING
-			long long tw = 0, tv = 0, th = 0, tt0 = __builtin_readcyclecounter();
-#endif
 			for (int t = 0; t < nsteps; t++) {
 				const int mx = t - 2 * g;
 				const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 				const bool left_edge = mx > 0;
 				const int slot = t % 3, pslot = (t + 2) % 3;
-#ifdef DB2_TIMING
-				long long c0 = __builtin_readcyclecounter();
-#endif
 				lds_wait_ge(&s_staged[pair], base + t + 1, xerr);
-#ifdef DB2_TIMING
-				long long c1 = __builtin_readcyclecounter();
-				tw += c1 - c0;
-#endif
 				if (in_top && t < p.mb_w) // the macroblock above-right of group 0's has been filtered
 					lds_wait_ge(&s_filtered[pair_up], base_up + (t + 8 < nsteps ? t + 8 : nsteps), xerr);
 				if (act) {
@@ -384,10 +373,6 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					}
 				}
 				WAVE_SYNC();
-#ifdef DB2_TIMING
-				long long c2 = __builtin_readcyclecounter();
-				tv += c2 - c1;
-#endif
 				if (act && any_work) {
 					// ---- horizontal edges: lane = sample column l ----
 					if (DO_Y) {
@@ -456,15 +441,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					}
 				}
 				lds_signal(&s_filtered[pair], base + t + 1, lane);
-#ifdef DB2_TIMING
-				th += __builtin_readcyclecounter() - c2;
-#endif
 			}
-#ifdef DB2_TIMING
-			if (lane == 0 && s_ticket <= 1 && pair <= 2 && iter == 0 && !IDR && PL == 1)
-				printf("filter PL%d wg %d pair %d: total %lld wait %lld V %lld H %lld per step over %d steps\n", PL, s_ticket, pair,
-				       (__builtin_readcyclecounter() - tt0) / nsteps, tw / nsteps, tv / nsteps, th / nsteps, nsteps);
-#endif
 			continue;
 		}
 
@@ -692,31 +669,15 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			}
 		};
 
-#ifdef DB2_TIMING
-		long long mw = 0, mb = 0;
-#endif
 		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
-#ifdef DB2_TIMING
-			long long c0 = __builtin_readcyclecounter();
-#endif
 			if (t >= 1)
 				lds_wait_ge(&s_filtered[pair], base + t, xerr); // step t-1 filtered
-#ifdef DB2_TIMING
-			long long c1 = __builtin_readcyclecounter();
-			mw += c1 - c0;
-#endif
 			publish();
 			if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
 				publish_diag((uint32_t)(t - 1 + diag0));
 			if (t + 1 < nsteps) {
-#ifdef DB2_TIMING
-				long long c2 = __builtin_readcyclecounter();
-#endif
 				if (!R.top_ok)
 					load_step(t + 1, true, R);
-#ifdef DB2_TIMING
-				mb += __builtin_readcyclecounter() - c2;
-#endif
 				stage_step(t + 1, R);
 				lds_signal(&s_staged[pair], base + t + 2, lane);
 				load_step(t + 3, false, R); // may wait for this frame's analysis: after the filter wave has its tile
@@ -730,9 +691,6 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		stage_step(0, RA);
 		load_step(2, false, RA);
 		lds_signal(&s_staged[pair], base + 1, lane);
-#ifdef DB2_TIMING
-		long long mt0 = __builtin_readcyclecounter();
-#endif
 		for (int t = 0; t <= nsteps; t += 2) {
 			mover_iter(t, RB);
 			if (t + 1 <= nsteps)
@@ -740,10 +698,6 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		}
 		publish();
 		publish_diag((uint32_t)PROG_ALL);
-#ifdef DB2_TIMING
-		if (lane == 0 && s_ticket <= 1 && pair <= 2 && iter == 0 && !IDR && PL == 1)
-			printf("mover PL%d wg %d pair %d: total %lld wait-filter %lld blocked-on-top %lld\n", PL, s_ticket, pair, (__builtin_readcyclecounter() - mt0) / nsteps, mw / nsteps, mb / nsteps);
-#endif
 	}
 }
 

@@ -138,7 +138,6 @@ struct InFlight {
 	bool active = false;
 	bool idr = false;
 	int host_out = 0;      // which host output buffer receives this frame
-	uint32_t spec_bytes = 0; // bytes copied speculatively with the frame
 	bool with_ps = false;  // SPS+PPS precede this frame's slices
 	hipEvent_t done_main = nullptr, done_ent = nullptr; // done_main: reconstruction deblocked (stream s_db)
 	int ds = 0; // device slot (frame number % depth) holding this frame's device-side state
@@ -166,7 +165,6 @@ struct cedar_enc {
 	// GOP state (cedar.c:93-95)
 	int frame_count = 0, frame_p_count = 0;
 	int cur = 0; // reconstruction buffer being written (cedar.c:117-119)
-	int parity = 0;
 	int chroma_qp_offset = 4;
 	// device memory
 	uint8_t *d_in_y = nullptr, *d_in_uv = nullptr;
@@ -186,8 +184,6 @@ struct cedar_enc {
 	uint8_t *d_rbsp = nullptr;
 	uint32_t *d_esc = nullptr, *d_nal_off = nullptr, *d_nal_size = nullptr, *d_stream_size = nullptr;
 	uint8_t *d_out[CEDAR_ENC_PIPELINE_DEPTH] = {}; // compact bytestreams, one per frame in flight
-	SliceHdr *d_hdr = nullptr;
-	uint32_t *d_prefix = nullptr;
 	uint8_t *d_pred4 = nullptr;
 	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint64_t *d_wf_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {};
@@ -278,7 +274,7 @@ void free_all(cedar_enc *e)
 	}
 	F(e->d_slot); F(e->d_mb_bits); F(e->d_skip); F(e->d_bit_off); F(e->d_run); F(e->d_unit_bits);
 	F(e->d_rbsp); F(e->d_esc); F(e->d_nal_off); F(e->d_nal_size); F(e->d_stream_size);
-	F(e->d_hdr); F(e->d_prefix); F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab);
+	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab);
 	H(e->h_luma); H(e->h_chroma);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_wf_err); H((void *)e->fl[i].h_done);
@@ -643,8 +639,6 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 3))) return rc;
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++)
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
-	if ((rc = dalloc(e, &e->d_hdr, (size_t)ext.slice_num))) return rc;
-	if ((rc = dalloc(e, &e->d_prefix, (size_t)S))) return rc;
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
 	{
 		// workgroups per unit for the wavefront kernels: one CU is instruction-bound by a
@@ -839,8 +833,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.nal_size = e->d_nal_size;
 	P.stream_size = e->d_stream_size;
 	P.out = e->d_out[0];
-	P.hdr = e->d_hdr;
-	P.prefix_len = e->d_prefix;
+	P.hdr = nullptr; // per frame: the frame's own pinned header words
+	P.prefix_len = nullptr;
 	P.pred4_tab = e->d_pred4;
 	P.wf_sync = e->d_wf_sync[0];
 	P.wf_hbuf = e->d_wf_hbuf[0];
@@ -1107,7 +1101,6 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		return fail(e, -EIO, "entropy launch failed");
 	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
 	f.host_out = slot; // every frame in flight owns one host buffer until it is collected
-	f.spec_bytes = 0;
 	if (Launch::copy_out(P, e->s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
 		return fail(e, -EIO, "k_copy_out launch failed");
 	HIP_TRY(e, hipEventRecord(f.done_ent, e->s_ent));
@@ -1134,7 +1127,6 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		e->frame_p_count = 0;
 	e->frame_count++;
 	e->cur ^= 1;
-	e->parity ^= 1;
 	if (any_host) // the caller may refill the pinned input buffers once they are on the device
 		HIP_TRY(e, hipEventSynchronize(e->ev_host_in));
 	if (getenv("CEDAR_TRACE_SUBMIT"))
@@ -1214,7 +1206,7 @@ extern "C" int cedar_enc_encode(cedar_enc *e)
 		return fail(e, -EBUSY, "frames in flight: collect them before a synchronous encode");
 	// a failed encode leaves GOP counters and reference frames untouched
 	// (cedar.c:1182-1191 return before :1193-1201)
-	const int fc = e->frame_count, fpc = e->frame_p_count, cur = e->cur, par = e->parity;
+	const int fc = e->frame_count, fpc = e->frame_p_count, cur = e->cur, ps = e->prev_slot, ps2 = e->prev2_slot;
 	int r = cedar_enc_submit(e);
 	if (r >= 0)
 		r = cedar_enc_collect(e);
@@ -1227,7 +1219,8 @@ extern "C" int cedar_enc_encode(cedar_enc *e)
 		e->frame_count = fc;
 		e->frame_p_count = fpc;
 		e->cur = cur;
-		e->parity = par;
+		e->prev_slot = ps;
+		e->prev2_slot = ps2;
 	}
 	return r;
 }
