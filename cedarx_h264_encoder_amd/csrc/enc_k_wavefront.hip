@@ -222,7 +222,7 @@ struct Db2Shared {
 	// bottom rows of a band's last macroblock row, for the pair that filters the band below
 	uint8_t xbot[DB2_PAIRS][DB2_XRING][(PL & 1) ? 64 : 16];
 	uint8_t xbotc[DB2_PAIRS][DB2_XRING][(PL & 2) ? 32 : 16];
-	int staged[DB2_PAIRS], filtered[DB2_PAIRS];
+	int staged[DB2_PAIRS], filtered[DB2_PAIRS], vdone[DB2_PAIRS]; // steps staged / filtered / through their vertical edges
 	int ticket;
 };
 
@@ -236,7 +236,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	Db2GroupLds *s_g = S.g;
 	auto &s_xbot = S.xbot;
 	auto &s_xbotc = S.xbotc;
-	int *s_staged = S.staged, *s_filtered = S.filtered;
+	int *s_staged = S.staged, *s_filtered = S.filtered, *s_vdone = S.vdone;
 	int &s_ticket = S.ticket;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -252,6 +252,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	if (threadIdx.x < DB2_PAIRS) {
 		s_staged[threadIdx.x] = 0;
 		s_filtered[threadIdx.x] = 0;
+		s_vdone[threadIdx.x] = 0;
 	}
 
 	__syncthreads();
@@ -266,7 +267,11 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int nbands = (r1 - r0 + 3) >> 2;
 	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
-	const int nsteps = p.mb_w + 6;
+	// Rows of a band follow each other ONE macroblock apart: filtering (x, y) needs (x+1, y-1)
+	// only for the three columns its first vertical edge changes in (x, y-1), and only from the
+	// horizontal edges on. All groups do their vertical edges, then fetch the rows above (with
+	// that patch, fresh from the group above), then do their horizontal edges.
+	const int nsteps = p.mb_w + 3;
 	// edge code by boundary strength 0..3, one byte each (bS 4 = 0x80: the strong filter has no tc0)
 	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
 	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
@@ -297,30 +302,17 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		if (!is_mover) {
 			// =========================== filter wave ===========================
 			for (int t = 0; t < nsteps; t++) {
-				const int mx = t - 2 * g;
+				const int mx = t - g;
 				const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 				const bool left_edge = mx > 0;
 				const int slot = t % 3, pslot = (t + 2) % 3;
 				lds_wait_ge(&s_staged[pair], base + t + 1, xerr);
-				if (in_top && t < p.mb_w) // the macroblock above-right of group 0's has been filtered
-					lds_wait_ge(&s_filtered[pair_up], base_up + (t + 8 < nsteps ? t + 8 : nsteps), xerr);
 				if (act) {
 					if (left_edge) { // previous tile's last 4 columns (final) become the left neighbours
 						if (DO_Y)
 							*(uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12) = *(const uint32_t *)(L.y[pslot] + (4 + l) * DT_STRIDE + 28);
 						if (DO_C && l < 8)
 							*(uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12) = *(const uint32_t *)(L.c[pslot] + (2 + l) * DC_STRIDE + 28);
-					}
-					if (top_edge && g > 0) { // rows above: the group above saved them two steps ago
-						if (DO_Y && l < 4)
-							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 3] + l * 16);
-						else if (DO_C && l >= 4 && l < 6)
-							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(LU.botc[mx & 3] + (l - 4) * 16);
-					} else if (in_top && g == 0) { // ... or the pair above did
-						if (DO_Y && l < 4)
-							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(s_xbot[pair_up][mx & (DB2_XRING - 1)] + l * 16);
-						else if (DO_C && l >= 4 && l < 6)
-							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(s_xbotc[pair_up][mx & (DB2_XRING - 1)] + (l - 4) * 16);
 					}
 				}
 				WAVE_SYNC();
@@ -373,6 +365,47 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					}
 				}
 				WAVE_SYNC();
+				// columns 12..15 of the macroblock to the left are final now (this macroblock's first
+				// vertical edge was the last thing to touch them): the band below wants them before ITS
+				// horizontal edges of this step
+				if (act && left_edge && g == 3 && in_bot) {
+					if (DO_Y && l >= 12)
+						*(uint32_t *)(s_xbot[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+					else if (DO_C && l >= 6 && l < 8)
+						*(uint32_t *)(s_xbotc[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+				}
+				lds_signal(&s_vdone[pair], base + t + 1, lane);
+				// rows above: saved by the group above a step ago, their last columns patched by its
+				// vertical edges of this step; group 0 takes them from the pair above (or had them
+				// staged by the mover when they come from another workgroup)
+				if (in_top && t < p.mb_w) {
+					if (t + 1 < p.mb_w)
+						lds_wait_ge(&s_vdone[pair_up], base_up + t + 5, xerr);    // (t+1, above) through its vertical edges
+					else
+						lds_wait_ge(&s_filtered[pair_up], base_up + t + 4, xerr); // (t, above) done, nothing to its right
+				}
+				if (act && top_edge) {
+					if (g > 0) {
+						const bool patched = mx + 1 < p.mb_w;
+						if (DO_Y && l < 4) {
+							u32x4 v = *(const u32x4 *)(LU.bot[mx & 3] + l * 16);
+							if (patched)
+								v.w = *(const uint32_t *)(LU.y[slot] + (16 + l) * DT_STRIDE + 12);
+							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = v;
+						} else if (DO_C && l >= 4 && l < 6) {
+							u32x4 v = *(const u32x4 *)(LU.botc[mx & 3] + (l - 4) * 16);
+							if (patched)
+								v.w = *(const uint32_t *)(LU.c[slot] + (4 + l) * DC_STRIDE + 12);
+							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = v;
+						}
+					} else if (in_top) {
+						if (DO_Y && l < 4)
+							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(s_xbot[pair_up][mx & (DB2_XRING - 1)] + l * 16);
+						else if (DO_C && l >= 4 && l < 6)
+							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(s_xbotc[pair_up][mx & (DB2_XRING - 1)] + (l - 4) * 16);
+					}
+				}
+				WAVE_SYNC();
 				if (act && any_work) {
 					// ---- horizontal edges: lane = sample column l ----
 					if (DO_Y) {
@@ -413,8 +446,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					}
 				}
 				WAVE_SYNC();
-				if (in_bot && t - 6 >= DB2_XRING && t - 6 < p.mb_w) // ring slot of group 3: consumed by the pair below?
-					lds_wait_ge(&s_filtered[pair_dn], base_dn + (t - 6 - DB2_XRING) + 1, xerr);
+				if (in_bot && t - 3 >= DB2_XRING && t - 3 < p.mb_w) // ring slot of group 3: consumed by the pair below?
+					lds_wait_ge(&s_filtered[pair_dn], base_dn + (t - 3 - DB2_XRING) + 1, xerr);
 				if (act) { // bottom rows for the row below; columns 12..15 of the previous MB are final now
 					if (DO_Y && l >= 12) {
 						const u32x4 rowv = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
@@ -422,22 +455,16 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						*(u32x4 *)(L.bot[mx & 3] + (l - 12) * 16) = rowv;
 						if (left_edge)
 							*(uint32_t *)(L.bot[(mx - 1) & 3] + (l - 12) * 16 + 12) = patch;
-						if (g == 3 && in_bot) {
+						if (g == 3 && in_bot)
 							*(u32x4 *)(s_xbot[pair][mx & (DB2_XRING - 1)] + (l - 12) * 16) = rowv;
-							if (left_edge)
-								*(uint32_t *)(s_xbot[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 12) * 16 + 12) = patch;
-						}
 					} else if (DO_C && l >= 6 && l < 8) {
 						const u32x4 rowv = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
 						const uint32_t patch = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
 						*(u32x4 *)(L.botc[mx & 3] + (l - 6) * 16) = rowv;
 						if (left_edge)
 							*(uint32_t *)(L.botc[(mx - 1) & 3] + (l - 6) * 16 + 12) = patch;
-						if (g == 3 && in_bot) {
+						if (g == 3 && in_bot)
 							*(u32x4 *)(s_xbotc[pair][mx & (DB2_XRING - 1)] + (l - 6) * 16) = rowv;
-							if (left_edge)
-								*(uint32_t *)(s_xbotc[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 6) * 16 + 12) = patch;
-						}
 					}
 				}
 				lds_signal(&s_filtered[pair], base + t + 1, lane);
@@ -457,7 +484,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			// (x, y) changes all of it, row 15 and column 15 included, which intra (x+1, y),
 			// (x-1, y+1), (x, y+1) and (x+1, y+1) still need: in an intra picture the deblock
 			// wavefront stays behind the last of them, three more diagonals.
-			const uint32_t need = (uint32_t)(t + diag0 + (IDR ? 4 : 1));
+			const uint32_t need = (uint32_t)(t + 3 + diag0 + (IDR ? 4 : 1)); // group 3 is 3 diagonals ahead of group 0
 			if (inter_seen >= need)
 				return;
 			// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the
@@ -520,13 +547,13 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		int pending_x = -1;
 
 		auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t into the r_* registers
-			const int nmx = t - 2 * g, mx0 = t;
+			const int nmx = t - g, mx0 = t;
 			const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
 			const int cmx = nact ? nmx : 0;
 			const size_t a = row_mb + cmx;
 			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
 			if (t < nsteps)
-				wait_analysis(t < p.mb_w + 6 ? t : p.mb_w + 5);
+				wait_analysis(t);
 			// readiness of the rows above first: its acquire must not sit behind this step's own loads
 			R.top_ok = true;
 			if (xwg_band && mx0 < p.mb_w) { // rows above live in another workgroup
@@ -554,7 +581,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		};
 
 		auto stage_step = [&](int t, const MoverRegs &R) { // r_* registers -> tile slot t%3 + packed boundary strengths
-			const int mx = t - 2 * g;
+			const int mx = t - g;
 			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 			const bool left_edge = mx > 0;
 			const int slot = t % 3;
@@ -621,7 +648,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		};
 
 		auto writeback_step = [&](int t) { // filtered tile of step t -> memory, next workgroup
-			const int mx = t - 2 * g;
+			const int mx = t - g;
 			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 			const bool left_edge = mx > 0;
 			const int slot = t % 3;
