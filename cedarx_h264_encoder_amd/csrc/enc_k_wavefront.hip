@@ -301,6 +301,13 @@ DEVI void deblock2_body(const Params &p, const int wg)
 
 		if (!is_mover) {
 			// =========================== filter wave ===========================
+			// The hand-off ring of this pair may still hold the end of the pair's PREVIOUS band (8
+			// bands up), which the band below that one reads: wait until it is through before the
+			// ring is written again (only when a workgroup has more bands than pairs).
+			if (iter > 0 && in_bot) {
+				const int relc = rel - DB2_PAIRS + 1;
+				lds_wait_ge(&s_filtered[relc & (DB2_PAIRS - 1)], (relc / DB2_PAIRS) * (nsteps + 2) + nsteps, xerr);
+			}
 			for (int t = 0; t < nsteps; t++) {
 				const int mx = t - g;
 				const bool act = row_ok && mx >= 0 && mx < p.mb_w;

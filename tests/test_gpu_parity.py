@@ -401,3 +401,24 @@ def test_two_sessions_interleaved_pipelined(ce):
             q -= 1
     assert outs[id(a)] == want
     assert outs[id(b)] == want
+
+
+@pytest.mark.parametrize("env", [
+    {"CEDAR_WF_SPLIT": "1", "CEDAR_WF_SPLIT_INTRA": "1"},            # 17 bands on one workgroup: bands wrap around its wave teams
+    {"CEDAR_WF_SPLIT": "3", "CEDAR_WF_SPLIT_INTRA": "2", "CEDAR_DEBLOCK_PLANES": "0"},  # both planes in every wave pair
+    {"CEDAR_WF_SPLIT": "8", "CEDAR_WF_SPLIT_INTRA": "8", "CEDAR_ROW_PIPE": "0"},
+])
+def test_1080p_wavefront_shapes_match_oracle(ce, monkeypatch, env):
+    """The wavefront kernels' work split (workgroups per unit, bands per workgroup, planes per wave
+    pair) is a launch-shape choice: every shape must give the oracle's bytes."""
+    for k in ("CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DEBLOCK_PLANES", "CEDAR_ROW_PIPE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w, h = 1920, 1080
+    frames = [ol.gen_frame("B", w, h, f) for f in range(3)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=25))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=25) as enc:
+        got = _encode_pipelined(enc, frames)
+    assert got == want
