@@ -422,3 +422,18 @@ def test_1080p_wavefront_shapes_match_oracle(ce, monkeypatch, env):
     with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=25) as enc:
         got = _encode_pipelined(enc, frames)
     assert got == want
+
+
+def test_long_pipelined_run_many_gops(ce):
+    """120 frames, 8 GOPs, everything in flight that the session allows: every access unit equals
+    the oracle's (progress words are tagged per frame and never cleared; slots, streams and
+    rings are reused dozens of times)."""
+    w, h = 640, 368
+    n = 120
+    frames = [ol.gen_frame("BC"[f % 2], w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=29, keyint=15))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=29, keyframe_interval=15) as enc:
+        got = _encode_pipelined(enc, frames)
+    bad = [i for i in range(n) if got[i] != want[i]]
+    assert not bad, "first differing frames: %s" % bad[:8]
