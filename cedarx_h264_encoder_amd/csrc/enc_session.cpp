@@ -139,6 +139,7 @@ struct InFlight {
 	bool idr = false;
 	int host_out = 0;      // which host output buffer receives this frame
 	bool with_ps = false;  // SPS+PPS precede this frame's slices
+	int aud = 0;           // 0 none, 1 access unit delimiter of an IDR picture, 2 of a P picture
 	hipEvent_t done_main = nullptr, done_ent = nullptr; // done_main: reconstruction deblocked (stream s_db)
 	int ds = 0; // device slot (frame number % depth) holding this frame's device-side state
 	SliceHdr *h_hdr = nullptr, *dv_hdr = nullptr;   // pinned + mapped per-frame slice headers, read by the kernels in place
@@ -224,6 +225,7 @@ struct cedar_enc {
 	int res_host = 0;
 	int last_slot = 0, last_rec = 0;
 	std::vector<uint8_t> sps_pps;
+	std::vector<uint8_t> aud_nal[2]; // [0] in front of an IDR picture, [1] of a P picture
 	// stats
 	bool profiling = false;
 	unsigned profile_mask = ~0u;
@@ -326,7 +328,26 @@ void build_sps_pps(cedar_enc *e)
 	} else {
 		sps.put(0, 1);
 	}
-	sps.put(0, 1); // vui_parameters_present_flag
+	if (e->ext.fps_num > 0 && e->ext.fps_den > 0) {
+		// H.264 E.1.1: timing + bitstream restriction, nothing else
+		sps.put(1, 1); // vui_parameters_present_flag
+		sps.put(0, 4); // aspect ratio, overscan, video signal type, chroma location: absent
+		sps.put(1, 1); // timing_info_present_flag
+		sps.put((uint32_t)e->ext.fps_den, 32);      // num_units_in_tick
+		sps.put((uint32_t)e->ext.fps_num * 2u, 32); // time_scale: two ticks (fields) per frame
+		sps.put(1, 1); // fixed_frame_rate_flag
+		sps.put(0, 3); // nal_hrd, vcl_hrd, pic_struct: absent
+		sps.put(1, 1); // bitstream_restriction_flag
+		sps.put(1, 1); // motion_vectors_over_pic_boundaries_flag
+		sps.ue(0);     // max_bytes_per_pic_denom: no limit
+		sps.ue(0);     // max_bits_per_mb_denom: no limit
+		sps.ue(7);     // log2_max_mv_length_horizontal: |mv| <= 16 pel = 64 quarter-pel
+		sps.ue(7);     // log2_max_mv_length_vertical
+		sps.ue(0);     // max_num_reorder_frames
+		sps.ue(1);     // max_dec_frame_buffering
+	} else {
+		sps.put(0, 1); // vui_parameters_present_flag (cedar.c:933)
+	}
 	sps.trailing();
 	BitWriter pps;
 	pps.ue(0);
@@ -348,6 +369,14 @@ void build_sps_pps(cedar_enc *e)
 	e->sps_pps.clear();
 	append_nal(e->sps_pps, 3, 7, sps.buf);
 	append_nal(e->sps_pps, 3, 8, pps.buf);
+	// access_unit_delimiter_rbsp (H.264 7.3.2.4): primary_pic_type 0 = I slices only, 1 = I and P
+	for (int k = 0; k < 2; k++) {
+		BitWriter aud;
+		aud.put((uint32_t)k, 3);
+		aud.trailing();
+		e->aud_nal[k].clear();
+		append_nal(e->aud_nal[k], 0, 9, aud.buf);
+	}
 }
 
 // slice header bits (cedar.c:984-1030)
@@ -553,6 +582,10 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		return fail(e, -EINVAL, "bad stream/slice layout");
 	if (ext.search_range < 0 || ext.search_range > 16)
 		return fail(e, -EINVAL, "search range %d outside 0..16", ext.search_range);
+	if (ext.fps_num < 0 || ext.fps_den < 0 || (ext.fps_num > 0) != (ext.fps_den > 0) || ext.fps_num > 0x3fffffff)
+		return fail(e, -EINVAL, "frame rate %d/%d: both or neither, time_scale must fit 32 bits", ext.fps_num, ext.fps_den);
+	if (ext.aud != 0 && ext.aud != 1)
+		return fail(e, -EINVAL, "aud must be 0 or 1");
 	if (mb_h > 512 * ext.slice_count)
 		return fail(e, -EINVAL, "picture too tall for one slice");
 	int ndev = 0;
@@ -1090,8 +1123,9 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	}
 	const bool with_ps = (e->frame_count == 0 || (idr && e->ext.repeat_headers)) && e->ext.slice_first == 0; // cedar.c:1058-1061
 	f.with_ps = with_ps;
+	f.aud = e->ext.aud && e->ext.slice_first == 0 ? (idr ? 1 : 2) : 0; // the first slice's session opens the access unit
 	for (int s = 0; s < S; s++)
-		f.h_prefix[s] = with_ps ? (uint32_t)e->sps_pps.size() : 0;
+		f.h_prefix[s] = (with_ps ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
 	HIP_TRY(e, hipStreamWaitEvent(e->s_ent, e->ev_analysis[ds], 0));
 	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
 	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
@@ -1177,8 +1211,14 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	for (int s = 0; s < S; s++) {
 		e->res_off[s] = off;
 		e->res_size[s] = sz[s];
+		uint8_t *front = e->h_out[f.host_out] + off;
+		if (f.aud) {
+			const std::vector<uint8_t> &a = e->aud_nal[f.aud - 1];
+			memcpy(front, a.data(), a.size());
+			front += a.size();
+		}
 		if (f.with_ps)
-			memcpy(e->h_out[f.host_out] + off, e->sps_pps.data(), e->sps_pps.size());
+			memcpy(front, e->sps_pps.data(), e->sps_pps.size());
 		off += sz[s];
 	}
 	e->res_host = f.host_out;

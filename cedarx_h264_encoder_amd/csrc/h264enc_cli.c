@@ -54,6 +54,9 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.slice_count = env_int("H264ENC_SLICES", 1);
 	ext.search_range = env_int("H264ENC_SEARCH", 0);
 	ext.repeat_headers = env_int("H264ENC_REPEAT_HEADERS", 0);
+	ext.aud = env_int("H264ENC_AUD", 0);
+	ext.fps_num = env_int("H264ENC_FPS_NUM", 0);
+	ext.fps_den = env_int("H264ENC_FPS_DEN", ext.fps_num > 0 ? 1 : 0);
 
 	ret = cedar_enc_config_ext(cedar, &config, &ext);
 	if (ret) {

@@ -41,7 +41,7 @@ class _Config(ctypes.Structure):
 class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
-        "chroma_qp_offset_minus4", "repeat_headers")] + [("reserved", ctypes.c_int * 7)]
+        "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den")] + [("reserved", ctypes.c_int * 4)]
 
 
 class _Stats(ctypes.Structure):
@@ -154,6 +154,9 @@ class EncoderConfig:
     search_range: int = 0
     chroma_qp_offset_minus4: int = 0
     repeat_headers: int = 0
+    aud: int = 0              # 1: access unit delimiter in front of every access unit
+    fps_num: int = 0          # both > 0: VUI timing + bitstream restriction in the SPS
+    fps_den: int = 0
 
 
 class CedarEncoder:
@@ -181,7 +184,7 @@ class CedarEncoder:
         x = _ConfigExt()
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
-                  "chroma_qp_offset_minus4", "repeat_headers"):
+                  "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")

@@ -87,7 +87,13 @@ struct cedar_enc_config_ext {
 	int repeat_headers;  /* 1: SPS+PPS in front of every IDR, so closed GOPs encoded by
 				different sessions / GPUs can be concatenated; 0: only
 				before the very first frame (cedar.c:1058-1061)          */
-	int reserved[7];
+	int aud;             /* 1: an access unit delimiter NAL (type 9) opens every access
+				unit; 0: none, as the reference          */
+	int fps_num;         /* fps_num, fps_den both > 0: the SPS carries VUI timing (fixed  */
+	int fps_den;         /*   frame rate fps_num/fps_den) and a bitstream restriction
+				(no reordering, one reference frame); 0/0: no VUI, as the
+				reference (cedar.c:933)                                  */
+	int reserved[4];
 };
 
 typedef struct cedar_enc cedar_enc;

@@ -116,6 +116,15 @@ int main(int argc, char **argv)
 	printf("decoded %d pictures %dx%d", pictures, h264o_dec_crop_width(d), h264o_dec_crop_height(d));
 	if (n_y > 0)
 		printf(", PSNR Y %.2f dB C %.2f dB", psnr(sse_y, n_y), psnr(sse_c, n_c));
+	{
+		unsigned num, den;
+
+		h264o_dec_frame_rate(d, &num, &den);
+		if (den)
+			printf(", %.3f frames/s (VUI %u/%u)", (double)num / den, num, den);
+		if (h264o_dec_aud_count(d))
+			printf(", %d access unit delimiters", h264o_dec_aud_count(d));
+	}
 	printf("\n");
 	h264o_dec_close(d);
 	free(buf);

@@ -77,6 +77,9 @@ int main(int argc, char **argv)
 	cfg.slice_count = env_int("H264ENC_SLICES", cfg.slice_count);
 	cfg.search_range = env_int("H264ENC_SEARCH", cfg.search_range);
 	cfg.repeat_headers = env_int("H264ENC_REPEAT_HEADERS", 0);
+	cfg.aud = env_int("H264ENC_AUD", 0);
+	cfg.fps_num = env_int("H264ENC_FPS_NUM", 0);
+	cfg.fps_den = env_int("H264ENC_FPS_DEN", cfg.fps_num > 0 ? 1 : 0);
 	enc = h264o_open(&cfg, &err);
 	if (!enc) {
 		fprintf(stderr, "%s(): config failed: %s\n", __func__, strerror(-err));

@@ -42,6 +42,10 @@ typedef struct h264o_config {
 	int slice_count;      /* >= 1, bands of MB rows            */
 	int chroma_qp_offset; /* 4 (cedar.c:971, :1167)            */
 	int repeat_headers;   /* 1: SPS+PPS in front of every IDR (reference: frame 0 only, cedar.c:1058) */
+	int aud;              /* 1: access unit delimiter NAL (type 9) opens every access unit */
+	int fps_num, fps_den; /* both > 0: the SPS carries VUI timing (fixed frame rate fps_num/fps_den)
+	                       * and a bitstream restriction (no reordering, 1 reference frame);
+	                       * the reference writes vui_parameters_present_flag = 0 (cedar.c:933) */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */
@@ -87,6 +91,7 @@ int h264o_last_frame_type(const h264o_enc *e); /* 1 = IDR, 0 = P */
 /* stand-alone pieces exported for known-answer tests */
 int h264o_write_sps(const h264o_config *cfg, uint8_t *out, int cap);
 int h264o_write_pps(const h264o_config *cfg, uint8_t *out, int cap);
+int h264o_write_aud(int idr, uint8_t *out, int cap);
 /* slice header only (start code, NAL byte, header bits, zero-padded to a byte);
  * *nbits receives the number of RBSP bits after the NAL header byte */
 int h264o_write_slice_header(const h264o_config *cfg, int idr, int frame_num,
@@ -118,6 +123,9 @@ int h264o_dec_crop_height(const h264o_dec *d);
 const uint8_t *h264o_dec_luma(const h264o_dec *d);   /* coded size, stride = width */
 const uint8_t *h264o_dec_chroma(const h264o_dec *d); /* nv12 interleaved */
 const char *h264o_dec_error(const h264o_dec *d);
+void h264o_dec_frame_rate(const h264o_dec *d, unsigned *num, unsigned *den);
+int h264o_dec_reorder_frames(const h264o_dec *d); /* -1: no bitstream restriction in the SPS */
+int h264o_dec_aud_count(const h264o_dec *d);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ typedef struct dmb {
 struct h264o_dec {
 	int have_sps, have_pps;
 	int mb_w, mb_h, cw, ch, crop_r, crop_b;
+	uint32_t vui_ticks, vui_scale; /* 0: no timing in the SPS */
+	int vui_reorder, n_aud;
 	int log2_max_frame_num, poc_type;
 	int init_qp, chroma_qp_offset, deblock_ctrl;
 	uint8_t *cur_y, *cur_uv, *ref_y, *ref_uv;
@@ -167,8 +169,54 @@ int h264o_dec_crop_height(const h264o_dec *d) { return d->ch - 2 * d->crop_b; }
 const uint8_t *h264o_dec_luma(const h264o_dec *d) { return d->ref_y; }
 const uint8_t *h264o_dec_chroma(const h264o_dec *d) { return d->ref_uv; }
 const char *h264o_dec_error(const h264o_dec *d) { return d->err; }
+/* frame rate from the VUI as num/den (0/0 when the SPS has no timing) */
+void h264o_dec_frame_rate(const h264o_dec *d, unsigned *num, unsigned *den)
+{
+	*num = d->vui_ticks ? d->vui_scale : 0;
+	*den = d->vui_ticks * 2;
+}
+int h264o_dec_reorder_frames(const h264o_dec *d) { return d->vui_reorder; }
+int h264o_dec_aud_count(const h264o_dec *d) { return d->n_aud; }
 
 /* ---------------- parameter sets ---------------- */
+/* vui_parameters (H.264 E.1.1): timing and the bitstream restriction are kept, the rest skipped */
+static int parse_vui(h264o_dec *d, br *b)
+{
+	if (br_u(b, 1)) { /* aspect_ratio_info */
+		if (br_u(b, 8) == 255)
+			br_u(b, 32);
+	}
+	if (br_u(b, 1)) /* overscan_info */
+		br_u(b, 1);
+	if (br_u(b, 1)) { /* video_signal_type */
+		br_u(b, 4);
+		if (br_u(b, 1))
+			br_u(b, 24);
+	}
+	if (br_u(b, 1)) { /* chroma_loc_info */
+		br_ue(b);
+		br_ue(b);
+	}
+	if (br_u(b, 1)) { /* timing_info */
+		d->vui_ticks = br_u(b, 32);
+		d->vui_scale = br_u(b, 32);
+		br_u(b, 1);
+	}
+	if (br_u(b, 1) || br_u(b, 1))
+		return fail(d, "HRD parameters unsupported");
+	br_u(b, 1); /* pic_struct_present_flag */
+	if (br_u(b, 1)) { /* bitstream_restriction */
+		br_u(b, 1);
+		br_ue(b);
+		br_ue(b);
+		br_ue(b);
+		br_ue(b);
+		d->vui_reorder = (int)br_ue(b);
+		br_ue(b);
+	}
+	return 0;
+}
+
 static int parse_sps(h264o_dec *d, br *b)
 {
 	int profile = (int)br_u(b, 8), mbw, mbh;
@@ -201,7 +249,10 @@ static int parse_sps(h264o_dec *d, br *b)
 			return fail(d, "crop top unsupported");
 		d->crop_b = (int)br_ue(b);
 	}
-	br_u(b, 1); /* vui present: ignored (must be 0 for this test decoder) */
+	d->vui_ticks = d->vui_scale = 0;
+	d->vui_reorder = -1;
+	if (br_u(b, 1) && parse_vui(d, b) < 0)
+		return -1;
 	if (b->err)
 		return fail(d, "sps truncated");
 	if (!d->have_sps || mbw != d->mb_w || mbh != d->mb_h) {
@@ -1278,6 +1329,9 @@ int h264o_dec_decode(h264o_dec *d, const uint8_t *data, int size)
 			pictures += r;
 			break;
 		}
+		case 9: /* access unit delimiter: counted, content ignored */
+			d->n_aud++;
+			break;
 		default:
 			break; /* ignore other NAL types */
 		}

@@ -177,7 +177,26 @@ static void sps_rbsp(const h264o_config *c, bitw *b)
 	} else {
 		bw_put(b, 0, 1);
 	}
-	bw_put(b, 0, 1); /* vui_parameters_present_flag */
+	if (c->fps_num > 0 && c->fps_den > 0) {
+		/* H.264 E.1.1: timing + bitstream restriction, nothing else */
+		bw_put(b, 1, 1); /* vui_parameters_present_flag */
+		bw_put(b, 0, 4); /* aspect_ratio, overscan, video_signal_type, chroma_loc: absent */
+		bw_put(b, 1, 1); /* timing_info_present_flag */
+		bw_put(b, (uint32_t)c->fps_den, 32);     /* num_units_in_tick */
+		bw_put(b, (uint32_t)c->fps_num * 2u, 32); /* time_scale: two ticks (fields) per frame */
+		bw_put(b, 1, 1); /* fixed_frame_rate_flag */
+		bw_put(b, 0, 3); /* nal_hrd, vcl_hrd, pic_struct: absent */
+		bw_put(b, 1, 1); /* bitstream_restriction_flag */
+		bw_put(b, 1, 1); /* motion_vectors_over_pic_boundaries_flag */
+		bw_ue(b, 0);     /* max_bytes_per_pic_denom: no limit */
+		bw_ue(b, 0);     /* max_bits_per_mb_denom: no limit */
+		bw_ue(b, 7);     /* log2_max_mv_length_horizontal: |mv| <= 16 pel = 64 quarter-pel */
+		bw_ue(b, 7);     /* log2_max_mv_length_vertical */
+		bw_ue(b, 0);     /* max_num_reorder_frames: output order = decode order */
+		bw_ue(b, 1);     /* max_dec_frame_buffering */
+	} else {
+		bw_put(b, 0, 1); /* vui_parameters_present_flag (cedar.c:933) */
+	}
 	bw_trailing(b);
 }
 
@@ -209,6 +228,18 @@ int h264o_write_sps(const h264o_config *cfg, uint8_t *out, int cap)
 	bw_init(&b, tmp, sizeof(tmp));
 	sps_rbsp(cfg, &b);
 	return nal_write(out, cap, 3, 7, tmp, (int)(b.pos >> 3));
+}
+
+/* access_unit_delimiter_rbsp (H.264 7.3.2.4): primary_pic_type 0 = I slices only, 1 = I and P */
+int h264o_write_aud(int idr, uint8_t *out, int cap)
+{
+	uint8_t tmp[4];
+	bitw b;
+
+	bw_init(&b, tmp, sizeof(tmp));
+	bw_put(&b, idr ? 0 : 1, 3);
+	bw_trailing(&b);
+	return nal_write(out, cap, 0, 9, tmp, (int)(b.pos >> 3));
 }
 
 int h264o_write_pps(const h264o_config *cfg, uint8_t *out, int cap)
@@ -1637,6 +1668,9 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		return NULL;
 	if (cfg->slice_count < 1 || cfg->slice_count > ALIGN16(cfg->height) / 16)
 		return NULL;
+	if (cfg->fps_num < 0 || cfg->fps_den < 0 || (cfg->fps_num > 0) != (cfg->fps_den > 0) ||
+	    cfg->fps_num > 0x3fffffff)
+		return NULL;
 	*err = -ENOMEM;
 	e = calloc(1, sizeof(*e));
 	if (!e)
@@ -1728,6 +1762,12 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 
 	pad_source(e, luma, chroma);
 
+	if (e->cfg.aud) {
+		r = h264o_write_aud(idr, out + o, out_cap - o);
+		if (r < 0)
+			return r;
+		o += r;
+	}
 	if (e->frame_count == 0 || (idr && e->cfg.repeat_headers)) { /* cedar.c:1058-1061 */
 		r = h264o_write_sps(&e->cfg, out + o, out_cap - o);
 		if (r < 0)

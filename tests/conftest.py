@@ -10,6 +10,7 @@ import os
 # read when the runtime starts, so it has to be in the environment before the first HIP call
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+import faulthandler
 import subprocess
 import sys
 
@@ -28,3 +29,31 @@ def pytest_configure(config):
 def _build_oracle():
     """Build oracle/build/libh264o.so (gcc, seconds). Test infrastructure only."""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+# A GPU test that stops making progress must end the run with a Python traceback of every thread,
+# not sit on the box until an outer limit kills it: the kernels' hand-off waits are bounded (they
+# time out into an error code within seconds), so anything longer is a host-side hang worth a stack.
+HANG_SECONDS = 360
+
+
+def pytest_runtest_setup(item):
+    faulthandler.dump_traceback_later(HANG_SECONDS, exit=True)
+
+
+def pytest_runtest_teardown(item, nextitem):
+    faulthandler.cancel_dump_traceback_later()
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: bring PyTorch's HIP context up before the first session of the native library,
+    the order bench.py and __graft_entry__.smoke() use (the first `import torch` on a fresh box
+    pages in for a minute or two; better at the start than inside a parity test)."""
+    expr = config.option.markexpr or ""
+    if "not gpu" not in expr and any(i.get_closest_marker("gpu") for i in items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass

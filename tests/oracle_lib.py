@@ -18,7 +18,7 @@ MB_I4x4, MB_I16x16, MB_P16x16, MB_PSKIP = 0, 1, 2, 3
 class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
-        "search_range", "slice_count", "chroma_qp_offset", "repeat_headers")]
+        "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den")]
 
 
 class MB(ctypes.Structure):
@@ -62,6 +62,7 @@ def lib():
         L.h264o_last_frame_type.argtypes = [vp]
         L.h264o_write_sps.argtypes = [ctypes.POINTER(Config), vp, ci]
         L.h264o_write_pps.argtypes = [ctypes.POINTER(Config), vp, ci]
+        L.h264o_write_aud.argtypes = [ci, vp, ci]
         L.h264o_write_slice_header.argtypes = [ctypes.POINTER(Config), ci, ci, ci, ci, vp, ci,
                                                ctypes.POINTER(ci)]
         L.h264o_cavlc_block.argtypes = [vp, ci, ci, vp, ci]
@@ -74,6 +75,10 @@ def lib():
         L.h264o_dec_decode.argtypes = [vp, vp, ci]
         for n in ("width", "height", "crop_width", "crop_height"):
             getattr(L, "h264o_dec_" + n).argtypes = [vp]
+        L.h264o_dec_frame_rate.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+        L.h264o_dec_frame_rate.restype = None
+        L.h264o_dec_reorder_frames.argtypes = [vp]
+        L.h264o_dec_aud_count.argtypes = [vp]
         L.h264o_dec_luma.restype = vp
         L.h264o_dec_luma.argtypes = [vp]
         L.h264o_dec_chroma.restype = vp
@@ -181,6 +186,18 @@ class OracleDecoder:
 
     def crop_size(self):
         return lib().h264o_dec_crop_width(self.h), lib().h264o_dec_crop_height(self.h)
+
+    def frame_rate(self):
+        """(num, den) from the SPS VUI; (0, 0) without timing."""
+        n, d = ctypes.c_uint(), ctypes.c_uint()
+        lib().h264o_dec_frame_rate(self.h, ctypes.byref(n), ctypes.byref(d))
+        return n.value, d.value
+
+    def reorder_frames(self):
+        return lib().h264o_dec_reorder_frames(self.h)
+
+    def aud_count(self):
+        return lib().h264o_dec_aud_count(self.h)
 
     def close(self):
         if self.h:

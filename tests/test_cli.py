@@ -141,6 +141,13 @@ def test_hip_cli_equals_scalar_cli(tmp_path):
     assert a.read_bytes() == b.read_bytes()
     dec = _decode_all(a.read_bytes(), frames)
     assert dec.crop_size() == (w, h)
+    # the header extensions through the same environment knobs on both command lines
+    env = dict(env, H264ENC_AUD="1", H264ENC_FPS_NUM="25", H264ENC_REPEAT_HEADERS="1", H264ENC_KEYINT="2")
+    assert subprocess.run([HIPCLI, "-", str(w), str(h), str(a)], input=raw, capture_output=True, env=env, timeout=300).returncode == 0
+    assert subprocess.run([SCALAR, "-", str(w), str(h), str(b)], input=raw, capture_output=True, env=env, timeout=300).returncode == 0
+    assert a.read_bytes() == b.read_bytes() and a.read_bytes()[:6] == bytes([0, 0, 0, 1, 9, 0x10])
+    dec = _decode_all(a.read_bytes(), frames)
+    assert dec.frame_rate() == (50, 2) and dec.aud_count() == frames
 
 
 @pytest.mark.gpu

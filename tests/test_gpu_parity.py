@@ -333,6 +333,47 @@ def test_repeat_headers_and_gop_sharding(ce):
             assert kinds == ([7, 8, 5] if f % 3 == 0 else [1])
 
 
+def test_access_unit_delimiters_and_vui_timing(ce):
+    """SURVEY 8(f)-3, header extensions beside the path: an access unit delimiter opens every
+    access unit and the SPS carries VUI timing. Same bytes as the oracle (synchronous, pipelined,
+    two lock-step streams), the independent decoder reads the frame rate back, and with slices
+    sharded over sessions only the first slice's session writes the delimiter and parameter sets."""
+    w, h, n = 320, 240, 9
+    kw = dict(aud=1, fps_num=30000, fps_den=1001, repeat_headers=1)
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=4, **kw))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    assert want[0][:6] == bytes([0, 0, 0, 1, 9, 0x10]) and want[1][:6] == bytes([0, 0, 0, 1, 9, 0x30])
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4, **kw) as enc:
+        assert [enc.encode_frame(y, uv) for y, uv in frames] == want
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4, **kw) as enc:
+        assert _encode_pipelined(enc, frames) == want
+    dec = ol.OracleDecoder()
+    for au in want:
+        assert dec.decode(au) == 1
+    assert dec.frame_rate() == (60000, 2002) and dec.aud_count() == n and dec.reorder_frames() == 0
+    # two streams in one session: each gets its own delimiter + parameter sets
+    fr2 = [[ol.gen_frame("B", w, h, f, s << 8) for s in range(2)] for f in range(5)]
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=4, **kw)) for _ in range(2)]
+    want2 = [[oes[s].encode(*fr2[f][s]) for s in range(2)] for f in range(5)]
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4, n_streams=2, **kw) as enc:
+        assert _encode_pipelined(enc, fr2, streams=2) == want2
+    # slices on separate sessions: the concatenation is the whole, so only slice 0 carries the front matter
+    oe3 = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=4, slice_count=3, **kw))
+    parts = [ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4, slice_count=3, slice_first=k,
+                             slice_num=1, **kw) for k in range(3)]
+    try:
+        for f in range(5):
+            assert b"".join(p.encode_frame(*frames[f]) for p in parts) == oe3.encode(*frames[f]), f
+    finally:
+        for p in parts:
+            p.close()
+    for bad in (dict(fps_num=30), dict(fps_den=1), dict(aud=2), dict(fps_num=1 << 30, fps_den=1)):
+        with pytest.raises(ce.EncoderError) as ex:
+            ce.CedarEncoder(width=w, height=h, **bad)
+        assert ex.value.errno == errno.EINVAL, bad
+
+
 def test_session_contract_errors(ce):
     """Error behaviour of the reference's ioctls (cedar.c:738-789, :1039-1043)."""
     e = ce.CedarEncoder()

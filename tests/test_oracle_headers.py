@@ -135,3 +135,99 @@ def test_repeat_headers_puts_parameter_sets_before_every_idr():
         au = e.encode(y, uv)
         kinds.append([au[i + 4] & 0x1f for i in range(len(au) - 4) if au[i:i + 4] == b"\0\0\0\1"])
     assert kinds == [[7, 8, 5], [1], [7, 8, 5], [1]]
+
+
+# ---- header extensions next to the path: access unit delimiter, VUI timing ----
+class _Bits:
+    """Independent restatement of the SPS syntax (H.264 7.3.2.1.1 + E.1.1) for the known answers."""
+
+    def __init__(self):
+        self.b = []
+
+    def u(self, v, n):
+        self.b += [(v >> i) & 1 for i in range(n - 1, -1, -1)]
+
+    def ue(self, v):
+        v += 1
+        self.u(v, 2 * v.bit_length() - 1)
+
+    def nal(self, hdr):
+        bits = self.b + [1]
+        bits += [0] * (-len(bits) % 8)
+        rbsp = bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+        out, zeros = bytearray(b"\0\0\0\1" + bytes([hdr])), 0
+        for x in rbsp:
+            if zeros == 2 and x <= 3:
+                out.append(3)
+                zeros = 0
+            out.append(x)
+            zeros = zeros + 1 if x == 0 else 0
+        return bytes(out)
+
+
+def _sps_with_vui(w, h, profile, level, num, den):
+    cw, ch = (w + 15) & ~15, (h + 15) & ~15
+    b = _Bits()
+    b.u(profile, 8), b.u(0, 8), b.u(level, 8)
+    b.ue(0), b.ue(0), b.ue(2), b.ue(1), b.u(0, 1)
+    b.ue(cw // 16 - 1), b.ue(ch // 16 - 1), b.u(1, 1), b.u(0, 1)
+    if (cw, ch) != (w, h):
+        b.u(1, 1), b.ue(0), b.ue((cw - w) // 2), b.ue(0), b.ue((ch - h) // 2)
+    else:
+        b.u(0, 1)
+    b.u(1, 1)                                   # vui_parameters_present_flag
+    b.u(0, 4), b.u(1, 1), b.u(den, 32), b.u(2 * num, 32), b.u(1, 1)
+    b.u(0, 3), b.u(1, 1), b.u(1, 1), b.ue(0), b.ue(0), b.ue(7), b.ue(7), b.ue(0), b.ue(1)
+    return b.nal(0x67)
+
+
+@pytest.mark.parametrize("w,h,num,den", [(320, 240, 30, 1), (854, 480, 30000, 1001), (1920, 1080, 25, 1),
+                                         (3840, 2160, 60, 1), (64, 48, 1, 1)])
+def test_sps_vui_timing_matches_independent_writer(w, h, num, den):
+    c = ol.default_config(w, h, fps_num=num, fps_den=den)
+    got = _sps(c)
+    assert got == _sps_with_vui(w, h, c.profile_idc, c.level_idc, num, den)
+    # num_units_in_tick = 1 puts 00 00 00 01 into the RBSP: emulation prevention must break it up
+    assert b"\0\0\0\1" not in got[4:] and b"\0\0\1" not in got[4:]
+    # and without a frame rate the SPS is the reference's (vui_parameters_present_flag = 0)
+    assert _sps(ol.default_config(w, h)) != got
+
+
+def test_sps_vui_golden_bytes():
+    v = G["sps_vui"][0]
+    c = ol.default_config(v["width"], v["height"], fps_num=v["fps_num"], fps_den=v["fps_den"])
+    assert _sps(c) == _hex(v["hex"])
+
+
+def test_access_unit_delimiter_bytes():
+    buf = np.zeros(16, np.uint8)
+    for idr, want in ((1, "00 00 00 01 09 10"), (0, "00 00 00 01 09 30")):
+        n = ol.lib().h264o_write_aud(idr, buf.ctypes.data, 16)
+        assert buf[:n].tobytes() == _hex(want)  # nal_ref_idc 0, type 9; primary_pic_type 0 / 1 + stop bit
+
+
+def test_frame_rate_validation():
+    for bad in (dict(fps_num=30), dict(fps_den=1), dict(fps_num=-1, fps_den=1), dict(fps_num=1 << 30, fps_den=1)):
+        with pytest.raises(Exception):
+            ol.OracleEncoder(ol.default_config(64, 48, **bad))
+
+
+def test_stream_with_aud_and_vui_decodes_and_reports_timing():
+    w, h = 96, 64
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=28, keyint=3, aud=1, fps_num=30000, fps_den=1001,
+                                             repeat_headers=1, slice_count=2))
+    plain = ol.OracleEncoder(ol.default_config(w, h, qp=28, keyint=3, repeat_headers=1, slice_count=2))
+    dec = ol.OracleDecoder()
+    for f in range(7):
+        y, uv = ol.gen_frame("B", w, h, f)
+        au, ref = enc.encode(y, uv), plain.encode(y, uv)
+        kinds = [au[i + 4] & 0x1f for i in range(len(au) - 4) if au[i:i + 4] == b"\0\0\0\1"]
+        assert kinds == ([9, 7, 8, 5, 5] if f % 3 == 0 else [9, 1, 1])
+        # the delimiter and the VUI change nothing below the parameter sets
+        assert au[au.index(b"\0\0\0\1\x65" if f % 3 == 0 else b"\0\0\0\1\x41"):] == \
+            ref[ref.index(b"\0\0\0\1\x65" if f % 3 == 0 else b"\0\0\0\1\x41"):]
+        assert dec.decode(au) == 1
+        ry, ruv = enc.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
+    assert dec.frame_rate() == (60000, 2002) and dec.reorder_frames() == 0 and dec.aud_count() == 7
