@@ -123,6 +123,7 @@ struct Params {
 	const uint32_t *stripe_tab;      // [row_num + 1] macroblocks of the stripe in the rows before row r (per stream)
 	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
+	int32_t fault_inject;            // tests only (CEDAR_FAULT_INJECT): 1 a deblock mover, 2 an intra mover stops reporting
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
 	int32_t unit_mb_cap;             // max macroblocks of one unit

@@ -187,20 +187,34 @@ struct Db2GroupLds {
 	uint32_t bsc[3][16];  // chroma codes: bytes 0,1 vertical edges 0,2 (lane = plane, row); bytes 2,3 horizontal 0,2 (lane = column)
 };
 
-DEVI void lds_wait_ge(const int *word, int need, uint32_t *err)
+// Where a wave of a wavefront workgroup reports a wait that ran out, and where it looks for the
+// reports of others: once one hand-off is lost every later wait would run out too, one after the
+// other; the abort flags make the rest of the grid drain in milliseconds instead.
+struct WaitCtx {
+	uint32_t *err;     // pinned host word of the frame (collect turns it into -EIO)
+	int *abort_lds;    // this workgroup
+	uint32_t *abort_x; // all workgroups of the launch (device memory, zeroed per launch when wf_split > 1)
+};
+
+DEVI void lds_wait_ge(const int *word, int need, const WaitCtx &w)
 {
 	// bounded like every spin here: a lost partner ends in -EIO at collect, not in a hung grid
 	for (int spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spins++) {
-		if (spins > (1 << 22)) {
-			__hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			break;
-		}
 		// back off after ~50 us: the partner is usually a few hundred cycles away, but with frames
 		// pipelined a whole workgroup can wait for a millisecond for its frame's analysis
-		if (spins < 2048)
+		if (spins < 2048) {
 			__builtin_amdgcn_s_sleep(0);
-		else
-			__builtin_amdgcn_s_sleep(32);
+			continue;
+		}
+		if (spins > (1 << 22)) {
+			__hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(w.abort_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			xstore32(w.abort_x, 1u);
+			break;
+		}
+		if (__hip_atomic_load(w.abort_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+			break;
+		__builtin_amdgcn_s_sleep(32);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
@@ -224,6 +238,7 @@ struct Db2Shared {
 	uint8_t xbotc[DB2_PAIRS][DB2_XRING][(PL & 2) ? 32 : 16];
 	int staged[DB2_PAIRS], filtered[DB2_PAIRS], vdone[DB2_PAIRS]; // steps staged / filtered / through their vertical edges
 	int ticket;
+	int abort; // a wait of this workgroup ran out: stop waiting
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -247,8 +262,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	const int g = lane >> 4, l = lane & 15;
 	const int NWG = p.wf_split;
 	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0) {
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : wg;
+		S.abort = 0;
+	}
 	if (threadIdx.x < DB2_PAIRS) {
 		s_staged[threadIdx.x] = 0;
 		s_filtered[threadIdx.x] = 0;
@@ -277,6 +294,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
+	const WaitCtx xw{xerr, &S.abort, xabort};
 	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
 	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
 	uint32_t xseen = 0;
@@ -306,14 +324,14 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			// ring is written again (only when a workgroup has more bands than pairs).
 			if (iter > 0 && in_bot) {
 				const int relc = rel - DB2_PAIRS + 1;
-				lds_wait_ge(&s_filtered[relc & (DB2_PAIRS - 1)], (relc / DB2_PAIRS) * (nsteps + 2) + nsteps, xerr);
+				lds_wait_ge(&s_filtered[relc & (DB2_PAIRS - 1)], (relc / DB2_PAIRS) * (nsteps + 2) + nsteps, xw);
 			}
 			for (int t = 0; t < nsteps; t++) {
 				const int mx = t - g;
 				const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 				const bool left_edge = mx > 0;
 				const int slot = t % 3, pslot = (t + 2) % 3;
-				lds_wait_ge(&s_staged[pair], base + t + 1, xerr);
+				lds_wait_ge(&s_staged[pair], base + t + 1, xw);
 				if (act) {
 					if (left_edge) { // previous tile's last 4 columns (final) become the left neighbours
 						if (DO_Y)
@@ -387,9 +405,9 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				// staged by the mover when they come from another workgroup)
 				if (in_top && t < p.mb_w) {
 					if (t + 1 < p.mb_w)
-						lds_wait_ge(&s_vdone[pair_up], base_up + t + 5, xerr);    // (t+1, above) through its vertical edges
+						lds_wait_ge(&s_vdone[pair_up], base_up + t + 5, xw);    // (t+1, above) through its vertical edges
 					else
-						lds_wait_ge(&s_filtered[pair_up], base_up + t + 4, xerr); // (t, above) done, nothing to its right
+						lds_wait_ge(&s_filtered[pair_up], base_up + t + 4, xw); // (t, above) done, nothing to its right
 				}
 				if (act && top_edge) {
 					if (g > 0) {
@@ -454,7 +472,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				}
 				WAVE_SYNC();
 				if (in_bot && t - 3 >= DB2_XRING && t - 3 < p.mb_w) // ring slot of group 3: consumed by the pair below?
-					lds_wait_ge(&s_filtered[pair_dn], base_dn + (t - 3 - DB2_XRING) + 1, xerr);
+					lds_wait_ge(&s_filtered[pair_dn], base_dn + (t - 3 - DB2_XRING) + 1, xw);
 				if (act) { // bottom rows for the row below; columns 12..15 of the previous MB are final now
 					if (DO_Y && l >= 12) {
 						const u32x4 rowv = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
@@ -705,7 +723,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 
 		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
 			if (t >= 1)
-				lds_wait_ge(&s_filtered[pair], base + t, xerr); // step t-1 filtered
+				lds_wait_ge(&s_filtered[pair], base + t, xw); // step t-1 filtered
 			publish();
 			if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
 				publish_diag((uint32_t)(t - 1 + diag0));
@@ -713,7 +731,9 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				if (!R.top_ok)
 					load_step(t + 1, true, R);
 				stage_step(t + 1, R);
-				lds_signal(&s_staged[pair], base + t + 2, lane);
+				// fault injection (tests): from step 8 of the first band on, this mover stops reporting
+				const bool lost = p.fault_inject == 1 && unit == 0 && band == 0 && t >= 8;
+				lds_signal(&s_staged[pair], lost ? base + 1 : base + t + 2, lane);
 				load_step(t + 3, false, R); // may wait for this frame's analysis: after the filter wave has its tile
 			}
 			if (t >= 1)
@@ -859,7 +879,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	// Intra4x4 stages finished in the current step by the luma wave (a) and the chroma wave (b),
 	// as (absolute step) * 16 + stages: the two share the 16 blocks of a macroblock, see i4 below
 	__shared__ int s_i4a[IR_TRIPLES], s_i4b[IR_TRIPLES];
-	__shared__ int s_ticket;
+	__shared__ int s_ticket, s_abort;
 	// Intra4x4 predictors as tile offsets: entry [tr][mode][lane] = kind << 24 | the offsets (int8,
 	// relative to the block's first sample in the tile) of edge samples E[k-1], E[k], E[k+1];
 	// tr = 1 when the block's top-right neighbours exist, else E[t4..t7] fold onto t3
@@ -887,8 +907,10 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	const int g = lane >> 4, l = lane & 15;
 	const int NWG = p.wf_split_intra;
 	uint32_t *sync = p.wf_sync; // region 0
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0) {
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : (int)blockIdx.x;
+		s_abort = 0;
+	}
 	if (threadIdx.x < IR_TRIPLES) {
 		s_staged[threadIdx.x] = 0;
 		s_done_y[threadIdx.x] = 0;
@@ -903,6 +925,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
+	const WaitCtx xw{xerr, &s_abort, xabort};
 	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
 	uint64_t *hb_out = p.wf_hbuf_intra + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
 	const uint64_t *hb_in = p.wf_hbuf_intra + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
@@ -959,13 +982,13 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				const bool left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
 				const int slot = t % 3;
 				const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
-				lds_wait_ge(&s_staged[trip], base + t + 1, xerr);
+				lds_wait_ge(&s_staged[trip], base + t + 1, xw);
 				const uint32_t miw = L.info[slot][0];
 				const uint64_t modes64 = (uint64_t)L.info[slot][2] | (uint64_t)L.info[slot][3] << 32;
 				const int mb_type = (int)(int8_t)(miw & 0xff), i16_mode = (int)((miw >> 8) & 0xff);
 				const uint8_t *SY = L.srcy[slot];
 				if (in_top && t < p.mb_w) // the macroblock above-right of group 0's is reconstructed
-					lds_wait_ge(&s_done_y[trip_up], base_up + (t + 8 < nsteps ? t + 8 : nsteps), xerr);
+					lds_wait_ge(&s_done_y[trip_up], base_up + (t + 8 < nsteps ? t + 8 : nsteps), xw);
 				if (act) {
 					if (left_mb) // left neighbours = last column of the previous macroblock
 						L.t[(1 + l) * IT_STRIDE + 7] = L.t[(1 + l) * IT_STRIDE + 23];
@@ -1023,15 +1046,15 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					lds_signal(&s_i4a[trip], key + 3, lane);
 					cbp |= i4_block(s_ptab, cx, ci, cj, 3, 6, tab);
 					lds_signal(&s_i4a[trip], key + 4, lane);
-					lds_wait_ge(&s_i4b[trip], key + 4, xerr); // blocks 4, 5
+					lds_wait_ge(&s_i4b[trip], key + 4, xw); // blocks 4, 5
 					cbp |= i4_block(s_ptab, cx, ci, cj, 6, 7, tab);
 					lds_signal(&s_i4a[trip], key + 5, lane);
 					cbp |= i4_block(s_ptab, cx, ci, cj, 7, 10, tab);
 					lds_signal(&s_i4a[trip], key + 6, lane);
-					lds_wait_ge(&s_i4b[trip], key + 6, xerr); // blocks 8, 9
+					lds_wait_ge(&s_i4b[trip], key + 6, xw); // blocks 8, 9
 					cbp |= i4_block(s_ptab, cx, ci, cj, 10, 11, tab);
 					cbp |= i4_block(s_ptab, cx, ci, cj, 11, 14, tab);
-					lds_wait_ge(&s_i4b[trip], key + 8, xerr); // blocks 12, 13
+					lds_wait_ge(&s_i4b[trip], key + 8, xw); // blocks 12, 13
 					cbp |= i4_block(s_ptab, cx, ci, cj, 14, 15, tab);
 					cbp |= i4_block(s_ptab, cx, ci, cj, 15, 0, tab);
 				}
@@ -1144,11 +1167,11 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				const bool left_mb = mx > 0;
 				const int slot = t % 3;
 				const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
-				lds_wait_ge(&s_staged[trip], base + t + 1, xerr);
+				lds_wait_ge(&s_staged[trip], base + t + 1, xw);
 				const int chroma_mode = (int)((L.info[slot][0] >> 16) & 0xff);
 				const uint8_t *SC = L.srcc[slot];
 				if (in_top && t < p.mb_w) // only the macroblock above is needed here, but the luma wave's bound is as good
-					lds_wait_ge(&s_done_c[trip_up], base_up + (t + 7 < nsteps ? t + 7 : nsteps), xerr);
+					lds_wait_ge(&s_done_c[trip_up], base_up + (t + 7 < nsteps ? t + 7 : nsteps), xw);
 				if (act) {
 					if (left_mb && l < 8)
 						*(uint16_t *)(L.c + (1 + l) * IC_STRIDE + 6) = *(const uint16_t *)(L.c + (1 + l) * IC_STRIDE + 22);
@@ -1176,16 +1199,16 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 								modes64, top_mb, left_mb, tr_mb, is4, g, l, pi, pj, zz,
 								my_mf, my_dv, f_intra, p.qbits, p.qshift };
 						uint32_t tab = i4_tab(s_ptab, cx, 4);
-						lds_wait_ge(&s_i4a[trip], key + 2, xerr); // tile neighbours set up, blocks 0, 1
+						lds_wait_ge(&s_i4a[trip], key + 2, xw); // tile neighbours set up, blocks 0, 1
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 4, 5, tab);
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 5, 8, tab);
 						lds_signal(&s_i4b[trip], key + 4, lane);
-						lds_wait_ge(&s_i4a[trip], key + 4, xerr); // blocks 2, 3
+						lds_wait_ge(&s_i4a[trip], key + 4, xw); // blocks 2, 3
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 8, 9, tab);
-						lds_wait_ge(&s_i4a[trip], key + 5, xerr); // block 6
+						lds_wait_ge(&s_i4a[trip], key + 5, xw); // block 6
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 9, 12, tab);
 						lds_signal(&s_i4b[trip], key + 6, lane);
-						lds_wait_ge(&s_i4a[trip], key + 6, xerr); // block 7
+						lds_wait_ge(&s_i4a[trip], key + 6, xw); // block 7
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 12, 13, tab);
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 13, 4, tab);
 						lds_signal(&s_i4b[trip], key + 8, lane);
@@ -1454,8 +1477,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		};
 		auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
 			if (t >= 1) {
-				lds_wait_ge(&s_done_y[trip], base + t, xerr);
-				lds_wait_ge(&s_done_c[trip], base + t, xerr);
+				lds_wait_ge(&s_done_y[trip], base + t, xw);
+				lds_wait_ge(&s_done_c[trip], base + t, xw);
 			}
 			publish();
 			if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
@@ -1465,7 +1488,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					load_step(t + 1, true, R);
 				stage_step(t + 1, R);
 				load_step(t + 3, false, R);
-				lds_signal(&s_staged[trip], base + t + 2, lane);
+				const bool lost = p.fault_inject == 2 && unit == 0 && band == 0 && t >= 8; // fault injection (tests)
+				lds_signal(&s_staged[trip], lost ? base + 1 : base + t + 2, lane);
 			}
 			if (t >= 1)
 				writeback_step(t - 1);

@@ -881,6 +881,10 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.prog_tag = P.prev_tag = 0;
 	P.wf_split = e->wf_split;
 	P.wf_split_intra = e->wf_split_intra;
+	{
+		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO
+		P.fault_inject = env ? atoi(env) : 0;
+	}
 
 	build_sps_pps(e);
 	e->frame_count = 0; // cedar.c:815-816

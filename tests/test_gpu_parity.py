@@ -478,3 +478,28 @@ def test_long_pipelined_run_many_gops(ce):
         got = _encode_pipelined(enc, frames)
     bad = [i for i in range(n) if got[i] != want[i]]
     assert not bad, "first differing frames: %s" % bad[:8]
+
+
+@pytest.mark.parametrize("which,keyint", [(1, 25), (2, 1)], ids=["deblock-mover", "intra-mover"])
+def test_lost_handoff_drains_and_reports_eio(ce, monkeypatch, which, keyint):
+    """Failure detection: every hand-off wait in the wavefront kernels is bounded, and the first
+    one that runs out raises abort flags so that the rest of the grid (and the frames queued behind
+    it) drains at once instead of timing out wait by wait. CEDAR_FAULT_INJECT makes one mover wave
+    stop reporting: the encode call must come back with -EIO within seconds, GOP state must not
+    advance (cedar.c:1182-1191), and the next session must work as if nothing had happened."""
+    import time
+    w, h = 640, 368
+    frames = [ol.gen_frame("B", w, h, f) for f in range(3)]
+    monkeypatch.setenv("CEDAR_FAULT_INJECT", str(which))
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=keyint) as bad:
+        t0 = time.time()
+        with pytest.raises(ce.EncoderError) as ex:
+            for y, uv in frames:
+                bad.encode_frame(y, uv)
+        assert ex.value.errno == errno.EIO
+        assert time.time() - t0 < 60
+    monkeypatch.delenv("CEDAR_FAULT_INJECT")
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=keyint))
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=keyint) as good:
+        for y, uv in frames:
+            assert good.encode_frame(y, uv) == oe.encode(y, uv)
