@@ -253,6 +253,35 @@ def run_rank(args, rank, world, local_rank):
                "seconds": round(cdt, 2),
                "fnv_sha": hashlib.sha1(b"".join(cpu_aus)).hexdigest()[:16],
                "gpu_sha": hashlib.sha1(b"".join(first_aus[:n_cmp])).hexdigest()[:16]}
+        # (ii) of SURVEY 8(d): the host cores of a one-GPU box, one independent stream per core: N
+        # processes of the scalar command line (oracle/build/h264enc_scalar) on the same sample
+        # (threads in this process would share one address space and contend on page faults)
+        import subprocess
+        import tempfile
+        ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        nfr = args.cpu_frames  # the same sample, so the same IDR / P mix
+        scalar = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "build", "h264enc_scalar")
+        if not os.path.exists(scalar):
+            subprocess.run(["make", "-s", "-C", os.path.dirname(os.path.dirname(scalar))], check=True)
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "sample.nv12")
+            with open(src, "wb") as fh:
+                for y, uv in frames[:nfr]:
+                    fh.write(y.tobytes())
+                    fh.write(uv.tobytes())
+            env = dict(os.environ, H264ENC_QP=str(args.qp), H264ENC_KEYINT=str(args.keyint))
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([scalar, src, str(W), str(H), os.path.join(td, "o%d.264" % i)],
+                                      stdout=subprocess.DEVNULL, env=env) for i in range(ncores)]
+            rcs = [pr.wait() for pr in procs]
+            mdt = time.perf_counter() - t0
+            with open(os.path.join(td, "o0.264"), "rb") as fh:
+                same = fh.read() == b"".join(cpu_aus[:nfr])
+        if any(rcs) or not same:
+            raise SystemExit("cpu_baseline all-cores leg failed (rc %s, same bytes %s)" % (rcs, same))
+        cpu["all_cores"] = {"value": ncores * nfr * mbs_per_frame / mdt, "cores": ncores,
+                            "sample": "%d processes x %d frames of the same sample, one per core" % (ncores, nfr),
+                            "seconds": round(mdt, 2)}
 
     out = {
         "metric": "macroblocks/s @ fixed QP, 1080p nv12",

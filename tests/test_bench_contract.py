@@ -45,6 +45,7 @@ def test_bench_single_gpu_line():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 * rf["frac"] and rf["achieved"] > 0  # achieved is printed rounded
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0  # 1 thread and all cores
     assert j["bitexact_vs_cpu"] is True  # the GPU bytes of the sample equal the oracle's
 
 
