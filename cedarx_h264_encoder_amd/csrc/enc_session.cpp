@@ -584,6 +584,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		return fail(e, -EINVAL, "search range %d outside 0..16", ext.search_range);
 	if (ext.fps_num < 0 || ext.fps_den < 0 || (ext.fps_num > 0) != (ext.fps_den > 0) || ext.fps_num > 0x3fffffff)
 		return fail(e, -EINVAL, "frame rate %d/%d: both or neither, time_scale must fit 32 bits", ext.fps_num, ext.fps_den);
+	if (e->chroma_qp_offset < -12 || e->chroma_qp_offset > 12) // H.264 7.4.2.2
+		return fail(e, -EINVAL, "chroma_qp_index_offset %d outside -12..12", e->chroma_qp_offset);
 	if (ext.aud != 0 && ext.aud != 1)
 		return fail(e, -EINVAL, "aud must be 0 or 1");
 	if (mb_h > 512 * ext.slice_count)

@@ -1668,6 +1668,8 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		return NULL;
 	if (cfg->slice_count < 1 || cfg->slice_count > ALIGN16(cfg->height) / 16)
 		return NULL;
+	if (cfg->chroma_qp_offset < -12 || cfg->chroma_qp_offset > 12) /* H.264 7.4.2.2 */
+		return NULL;
 	if (cfg->fps_num < 0 || cfg->fps_den < 0 || (cfg->fps_num > 0) != (cfg->fps_den > 0) ||
 	    cfg->fps_num > 0x3fffffff)
 		return NULL;

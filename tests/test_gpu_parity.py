@@ -374,6 +374,28 @@ def test_access_unit_delimiters_and_vui_timing(ce):
         assert ex.value.errno == errno.EINVAL, bad
 
 
+@pytest.mark.parametrize("off", [-12, -3, 0, 12])
+def test_chroma_qp_offset_variants(ce, off):
+    """chroma_qp_index_offset other than the reference's +4 (cedar.c:971-972, :1165-1168): chroma
+    quantiser, the chroma deblock thresholds and the PPS follow it; decoder round trip included."""
+    w, h = 208, 112
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=29, keyint=3, chroma_qp_offset=off))
+    dec = ol.OracleDecoder()
+    with ce.CedarEncoder(width=w, height=h, qp=29, keyframe_interval=3, chroma_qp_offset_minus4=off - 4) as ge:
+        for f in range(5):
+            y, uv = ol.gen_frame("B", w, h, f)
+            ref = oe.encode(y, uv)
+            assert ge.encode_frame(y, uv) == ref, f
+            _compare_state(oe, ge)
+            assert dec.decode(ref) == 1
+            dy, duv = dec.picture()
+            assert np.array_equal(dy, ge.debug_read("recon_y")) and np.array_equal(duv, ge.debug_read("recon_uv"))
+    for bad in (-17, 9):
+        with pytest.raises(ce.EncoderError) as ex:
+            ce.CedarEncoder(width=w, height=h, chroma_qp_offset_minus4=bad)
+        assert ex.value.errno == errno.EINVAL
+
+
 def test_session_contract_errors(ce):
     """Error behaviour of the reference's ioctls (cedar.c:738-789, :1039-1043)."""
     e = ce.CedarEncoder()

@@ -83,3 +83,22 @@ def test_no_start_code_emulation_in_payload():
         payload = au[s + 4:e]
         for i in range(len(payload) - 2):
             assert not (payload[i] == 0 and payload[i + 1] == 0 and payload[i + 2] < 3)
+
+
+@pytest.mark.parametrize("off", [-12, -5, 0, 4, 12])
+def test_chroma_qp_offset_round_trip(off):
+    """chroma_qp_index_offset over its whole range (the reference fixes +4, cedar.c:971-972)."""
+    w, h = 96, 64
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=3, chroma_qp_offset=off))
+    dec = ol.OracleDecoder()
+    sizes = []
+    for f in range(5):
+        au = enc.encode(*ol.gen_frame("B", w, h, f))
+        sizes.append(len(au))
+        assert dec.decode(au) == 1
+        ry, ruv = enc.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
+    for bad in (-13, 13):
+        with pytest.raises(Exception):
+            ol.OracleEncoder(ol.default_config(w, h, chroma_qp_offset=bad))
