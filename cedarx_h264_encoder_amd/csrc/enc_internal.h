@@ -123,6 +123,13 @@ struct Params {
 	const uint32_t *stripe_tab;      // [row_num + 1] macroblocks of the stripe in the rows before row r (per stream)
 	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
+	// Frame pipelining keeps the deblock stream to ONE packet per frame (every packet queued behind a
+	// resident kernel costs its hardware pipe ~20 us): the last workgroup of the deblock launch
+	// zeroes the sync words of regions 1-2 for the slot's next use (db_self_reset) and stores
+	// done_tag to done_flag (pinned host memory) instead of a memset before and a k_flag after
+	uint32_t *done_flag;
+	uint32_t done_tag;
+	int32_t db_self_reset;
 	int32_t fault_inject;            // tests only (CEDAR_FAULT_INJECT): 1 a deblock mover, 2 an intra mover stops reporting
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
@@ -175,6 +182,9 @@ struct Launch {
 	// concurrency probe: does a kernel on `waiter` see a flag set by a later launch on `setter`?
 	// (HIP maps streams onto few hardware queues; two streams on one queue run back to back)
 	static int probe_overlap(void *waiter, void *setter, uint32_t *d_words, bool *overlaps);
+	// us per launch of a chain of n tiny kernels on `chain` while `blocked` (may be null) holds a
+	// running kernel with a packet behind it: queues that share a command-processor pipe show ~8x
+	static int probe_pipe(void *blocked, void *chain, uint32_t *d_words, int n_chain, double *us_per_kernel);
 	static int deblock(const Params &p, void *stream, int planes); // 1 luma, 2 chroma, 3 both
 	static int entropy(const Params &p, void *stream); // cavlc, scan, pack, escape
 };

@@ -11,6 +11,7 @@
 // only triggers (kernel/cedar.c:1068-1080, :1142-1149, :1170-1176).
 #include <hip/hip_runtime.h>
 
+#include <time.h>
 #include "enc_device.h"
 
 namespace cedar {
@@ -444,6 +445,8 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 // to the caller's pinned buffers by plain coalesced stores; host_out / host_sizes are device
 // views of mapped host memory. hipMemcpyAsync did this before: its staging stalled a submit
 // for ~7 ms three times while a pipeline of frames warmed up, and the size had to be guessed.
+static __device__ __forceinline__ void xstore_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256) void k_copy_out(Params p, uint8_t *host_out, uint32_t *host_sizes)
 {
 	const uint32_t total = p.stream_size[p.n_streams];
@@ -452,6 +455,22 @@ __global__ __launch_bounds__(256) void k_copy_out(Params p, uint8_t *host_out, u
 		((u32x4 *)host_out)[i] = ((const u32x4 *)p.out)[i];
 	if (blockIdx.x == 0 && (int)threadIdx.x < p.n_streams + 2)
 		host_sizes[threadIdx.x] = p.stream_size[threadIdx.x];
+	if (!p.done_flag)
+		return;
+	// Pipelined frames: the last workgroup raises the frame's "bitstream delivered" flag (after
+	// every workgroup's stores to host memory have been performed) and leaves the size words
+	// zeroed for the lane's next frame: no k_flag, no memset on the entropy stream.
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t *cnt = p.stream_size + p.n_streams + 3;
+		if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			for (int i = 0; i < p.n_streams + 4; i++)
+				xstore_u32(&p.stream_size[i], 0u);
+			__hip_atomic_store(p.done_flag, p.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
 }
 
 int Launch::copy_out(const Params &p, void *stream, uint8_t *host_out, uint32_t *host_sizes)
@@ -501,6 +520,42 @@ int Launch::probe_overlap(void *waiter, void *setter, uint32_t *d_words, bool *o
 	if (hipMemcpy(h, d_words, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
 		return -1;
 	*overlaps = h[1] != 0;
+	return 0;
+}
+
+__global__ void k_probe_nop(uint32_t *w)
+{
+	if (threadIdx.x == 1)
+		w[2] = 1;
+}
+
+// Hardware queues come in groups that share a command-processor pipe (two of eight per pipe on
+// MI355X with GPU_MAX_HW_QUEUES=8). A pipe whose one queue holds a running kernel WITH a packet
+// queued behind it serves its other queue slowly: ~25 us per kernel launch instead of ~3 us
+// (measured, tools/dev/pipe_probe.hip). This times a chain of tiny kernels on `chain` while
+// `blocked` is in that state; the caller compares with the unblocked time.
+int Launch::probe_pipe(void *blocked, void *chain, uint32_t *d_words, int n_chain, double *us_per_kernel)
+{
+	uint32_t h[4] = { 0, 0, 0, 0 };
+	if (hipMemcpy(d_words, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess)
+		return -1;
+	if (blocked) {
+		hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, (hipStream_t)blocked, d_words);
+		hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(64), 0, (hipStream_t)blocked, d_words);
+	}
+	timespec a, b;
+	clock_gettime(CLOCK_MONOTONIC, &a);
+	for (int i = 0; i < n_chain; i++)
+		hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(64), 0, (hipStream_t)chain, d_words);
+	if (hipStreamSynchronize((hipStream_t)chain) != hipSuccess)
+		return -1;
+	clock_gettime(CLOCK_MONOTONIC, &b);
+	*us_per_kernel = ((b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3) / n_chain;
+	if (blocked) {
+		hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, (hipStream_t)chain, d_words);
+		if (hipStreamSynchronize((hipStream_t)chain) != hipSuccess || hipStreamSynchronize((hipStream_t)blocked) != hipSuccess)
+			return -1;
+	}
 	return 0;
 }
 

@@ -773,6 +773,26 @@ __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2_planes(Params p, int
 	} else {
 		deblock2_body<IDR, 3>(p, (int)blockIdx.x);
 	}
+	if (!p.db_self_reset)
+		return;
+	// Epilogue of a pipelined frame: the last workgroup to get here leaves the sync words of both
+	// deblock regions zeroed for the next frame that uses this slot (nobody reads them any more:
+	// every workgroup has counted itself out) and tells the host that the frame is deblocked.
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t *r1 = p.wf_sync + WF_SYNC_WORDS, *r2 = p.wf_sync + 2 * WF_SYNC_WORDS;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (__hip_atomic_fetch_add(&r1[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
+			for (int i = 0; i < used; i++) {
+				xstore32(&r1[i], 0u);
+				xstore32(&r2[i], 0u);
+			}
+			if (p.done_flag)
+				__hip_atomic_store(p.done_flag, p.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
 }
 
 // ------------------------------------------------------------------------

@@ -36,6 +36,7 @@ std::atomic<int> g_pipelined_sessions[64];
 
 constexpr int DB_STREAMS = 3;
 constexpr int AN_STREAMS = 3;
+constexpr int ENT_LANES = 2;
 
 // ---- ITU-T H.264 constants needed on the host (clauses 8.5.9, 8.7.2) ----
 const uint16_t kQuantMF[6][3] = { // class 0 even/even, 1 odd/odd, 2 mixed
@@ -139,6 +140,9 @@ struct InFlight {
 	bool idr = false;
 	int host_out = 0;      // which host output buffer receives this frame
 	bool with_ps = false;  // SPS+PPS precede this frame's slices
+	int lane = 0;          // entropy lane
+	hipStream_t s_db = nullptr, s_ent = nullptr; // the streams that carry this frame's deblocking / entropy coding
+	bool events = true;    // done_main / done_ent were recorded (frames not pipelined)
 	int aud = 0;           // 0 none, 1 access unit delimiter of an IDR picture, 2 of a P picture
 	hipEvent_t done_main = nullptr, done_ent = nullptr; // done_main: reconstruction deblocked (stream s_db)
 	int ds = 0; // device slot (frame number % depth) holding this frame's device-side state
@@ -166,24 +170,32 @@ struct cedar_enc {
 	// GOP state (cedar.c:93-95)
 	int frame_count = 0, frame_p_count = 0;
 	int cur = 0; // reconstruction buffer being written (cedar.c:117-119)
+	int depth = 4;  // frames in flight this session allows (<= CEDAR_ENC_PIPELINE_DEPTH) = device slots
+	int nrec = 5;   // reconstruction buffers (depth + 1)
 	int chroma_qp_offset = 4;
 	// device memory
-	uint8_t *d_in_y = nullptr, *d_in_uv = nullptr;
-	uint8_t **d_in_ptrs = nullptr; // [2*n_streams]
+	uint8_t *d_in_y = nullptr, *d_in_uv = nullptr; // device copies of the pinned input buffers: [depth][n_streams]
+	uint8_t **d_in_ptrs = nullptr; // [depth][2*n_streams]
 	std::vector<const uint8_t *> h_in_ptrs;
-	bool in_ptrs_dirty = true;
+	std::vector<const uint8_t *> in_tab[CEDAR_ENC_PIPELINE_DEPTH]; // per slot: what d_in_ptrs holds
+	bool in_tab_valid[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	// per frame in flight (slot): source planes, records, levels, wavefront sync + progress words
 	uint8_t *d_src_y[CEDAR_ENC_PIPELINE_DEPTH] = {}, *d_src_uv[CEDAR_ENC_PIPELINE_DEPTH] = {};
-	uint8_t *d_rec_y[2] = { nullptr, nullptr }, *d_rec_uv[2] = { nullptr, nullptr };
+	// reconstructions rotate through depth + 1 buffers: the one a frame writes was last touched by
+	// frames that have been collected (written by frame n - nrec, searched by frame n - nrec + 1)
+	uint8_t *d_rec_y[CEDAR_ENC_PIPELINE_DEPTH + 1] = {}, *d_rec_uv[CEDAR_ENC_PIPELINE_DEPTH + 1] = {};
 	MbInfo *d_mbi[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int8_t *d_i4[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint8_t *d_nnz[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int16_t *d_coef[CEDAR_ENC_PIPELINE_DEPTH] = {};
-	uint32_t *d_slot = nullptr, *d_mb_bits = nullptr;
-	uint8_t *d_skip = nullptr;
-	uint32_t *d_bit_off = nullptr, *d_run = nullptr, *d_unit_bits = nullptr;
-	uint8_t *d_rbsp = nullptr;
-	uint32_t *d_esc = nullptr, *d_nal_off = nullptr, *d_nal_size = nullptr, *d_stream_size = nullptr;
+	// entropy coding scratch, one set per entropy lane (frames alternate between the lanes' streams)
+	uint32_t *d_slot[ENT_LANES] = {}, *d_mb_bits[ENT_LANES] = {};
+	uint8_t *d_skip[ENT_LANES] = {};
+	uint32_t *d_bit_off[ENT_LANES] = {}, *d_run[ENT_LANES] = {}, *d_unit_bits[ENT_LANES] = {};
+	uint8_t *d_rbsp[ENT_LANES] = {};
+	uint32_t *d_esc[ENT_LANES] = {}, *d_nal_off[ENT_LANES] = {}, *d_nal_size[ENT_LANES] = {}, *d_stream_size[ENT_LANES] = {};
+	int ent_lanes = 1;
+	hipStream_t s_ent2 = nullptr; // lane 1 (an alias of the spare stream s_db[2]); lane 0 is s_ent
 	uint8_t *d_out[CEDAR_ENC_PIPELINE_DEPTH] = {}; // compact bytestreams, one per frame in flight
 	uint8_t *d_pred4 = nullptr;
 	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
@@ -213,8 +225,15 @@ struct cedar_enc {
 	hipStream_t s_main = nullptr, s_ent = nullptr, s_db[DB_STREAMS] = {};
 	hipStream_t s_ana[AN_STREAMS] = {}; // analysis streams; s_ana[0] == s_main
 	int an_streams = 1;
+	// IDR pictures depend on no other frame: with look-ahead they get streams of their own (input
+	// of every frame on s_in, an IDR picture's analysis on s_idr, its deblocking on s_db_idr) and run
+	// beside the P pictures submitted before them
+	bool lookahead = false;
+	bool idr_deblock_inline = true;
+	hipStream_t s_in = nullptr, s_idr = nullptr, s_db_idr = nullptr;
 	bool split_planes = true;
 	hipEvent_t ev_host_in = nullptr; // pinned input buffers consumed
+	hipEvent_t ev_base = nullptr;    // time zero of CEDAR_TRACE_TIMELINE
 	// per device slot: source planes + sync words ready (s_main), records complete (s_main),
 	// reconstruction deblocked (s_db)
 	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH] = {}, ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH] = {};
@@ -223,7 +242,7 @@ struct cedar_enc {
 	// results of the last collected frame
 	std::vector<uint32_t> res_off, res_size;
 	int res_host = 0;
-	int last_slot = 0, last_rec = 0;
+	int last_slot = 0, last_rec = 0, last_lane = 0;
 	std::vector<uint8_t> sps_pps;
 	std::vector<uint8_t> aud_nal[2]; // [0] in front of an IDR picture, [1] of a P picture
 	// stats
@@ -267,15 +286,17 @@ void free_all(cedar_enc *e)
 	auto F = [](void *p) { if (p) hipFree(p); };
 	auto H = [](void *p) { if (p) hipHostFree(p); };
 	F(e->d_in_y); F(e->d_in_uv); F((void *)e->d_in_ptrs);
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH + 1; i++) {
 		F(e->d_rec_y[i]); F(e->d_rec_uv[i]);
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
 		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
-	F(e->d_slot); F(e->d_mb_bits); F(e->d_skip); F(e->d_bit_off); F(e->d_run); F(e->d_unit_bits);
-	F(e->d_rbsp); F(e->d_esc); F(e->d_nal_off); F(e->d_nal_size); F(e->d_stream_size);
+	for (int l = 0; l < ENT_LANES; l++) {
+		F(e->d_slot[l]); F(e->d_mb_bits[l]); F(e->d_skip[l]); F(e->d_bit_off[l]); F(e->d_run[l]); F(e->d_unit_bits[l]);
+		F(e->d_rbsp[l]); F(e->d_esc[l]); F(e->d_nal_off[l]); F(e->d_nal_size[l]); F(e->d_stream_size[l]);
+	}
 	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab);
 	H(e->h_luma); H(e->h_chroma);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
@@ -293,12 +314,104 @@ void free_all(cedar_enc *e)
 					hipEventDestroy(e->fl[i].tm.ev[s][k]);
 	}
 	if (e->ev_host_in) hipEventDestroy(e->ev_host_in);
+	if (e->ev_base) hipEventDestroy(e->ev_base);
 	if (e->s_main) hipStreamDestroy(e->s_main);
 	for (int i = 1; i < AN_STREAMS; i++)
 		if (e->s_ana[i]) hipStreamDestroy(e->s_ana[i]);
 	if (e->s_ent) hipStreamDestroy(e->s_ent);
 	for (int i = 0; i < DB_STREAMS; i++)
 		if (e->s_db[i]) hipStreamDestroy(e->s_db[i]);
+}
+
+// Which stream does what. Hardware queues share command-processor pipes in pairs, and a queue
+// that holds a running kernel with more packets behind it ("blocked") makes its pipe serve the
+// other queue slowly: ~21 us per launch instead of ~3 us when the blocked queue is the later of
+// the pair, ~6 us when it is the earlier (measured; Launch::probe_pipe, tools/dev/pipe_probe.hip).
+// Roles differ in how often they are blocked and in how many dependent launches per frame they
+// have on the critical path:
+//   MAIN  gates + analysis: a dozen launches per frame, the gates spin
+//   ENT   ten short kernels per frame behind an event wait
+//   DB0/1 deblock kernels, resident for a frame time; memset + kernel + flag every other frame
+//   IDR   an IDR picture's milliseconds of intra reconstruction (look-ahead), once per GOP
+//   IN    k_input: never waits, nothing waits for it in steady state
+// All ordered pairs of the seven streams are measured and the roles dealt to minimise the
+// expected launch delay per frame; the spare stream keeps a pipe-mate company.
+int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
+{
+	enum { MAIN, ENT, DB0, DB1, IDR, IN, DB2, NROLE };
+	const bool three = db_streams_wanted >= 3; // a third deblock stream, or a spare
+	// (the seventh role is a third deblock stream, or else the second entropy lane)
+	const double blocked_frac[NROLE] = { 0.5, 0.3, 0.9, 0.9, 0.45, 0.0, three ? 0.9 : 0.3 };
+	const double launches[NROLE] = { 12, three ? 10.0 : 5.0, three ? 1.0 : 1.5, three ? 1.0 : 1.5, 0.3, 0.1, three ? 1.0 : 5.0 };
+	hipStream_t pool[7] = { e->s_main, e->s_ent, e->s_db[0], e->s_db[1], e->s_db[2], e->s_ana[1], e->s_ana[2] };
+	const int NP = 7;
+	double slow[NP][NP] = {}; // [blocked][chain]: extra us per launch
+	double base = 0, t = 0;
+	for (int k = 0; k < 2; k++)
+		if (Launch::probe_pipe(nullptr, pool[0], e->d_prog[0], 24, &base))
+			return fail(e, -EIO, "pipe probe failed");
+	const bool trace = getenv("CEDAR_TRACE_SUBMIT") != nullptr;
+	for (int i = 0; i < NP; i++)
+		for (int j = 0; j < NP; j++) {
+			if (i == j)
+				continue;
+			double worst = 0; // the effect comes and goes from one try to the next: keep the worst of three
+			for (int k = 0; k < 3; k++) {
+				if (Launch::probe_pipe(pool[i], pool[j], e->d_prog[0], 24, &t))
+					return fail(e, -EIO, "pipe probe failed");
+				worst = t > worst ? t : worst;
+			}
+			slow[i][j] = worst > base + 1.5 ? worst - base : 0.0;
+		}
+	HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+	int best[NROLE] = { 0, 1, 2, 3, 5, 6, 4 }, cur[NROLE];
+	double best_cost = 1e30;
+	bool taken[NP] = {};
+	struct Rec { // depth-first over the 7! assignments
+		const double *blocked_frac, *launches;
+		void go(int r, int *cur, bool *taken, double cost, const double (*slow)[7], int *best, double &best_cost) const
+		{
+			if (cost >= best_cost)
+				return;
+			if (r == NROLE) {
+				best_cost = cost;
+				for (int k = 0; k < NROLE; k++)
+					best[k] = cur[k];
+				return;
+			}
+			for (int sidx = 0; sidx < 7; sidx++) {
+				if (taken[sidx])
+					continue;
+				double add = 0;
+				for (int q = 0; q < r; q++)
+					add += blocked_frac[q] * launches[r] * slow[cur[q]][sidx] + blocked_frac[r] * launches[q] * slow[sidx][cur[q]];
+				taken[sidx] = true;
+				cur[r] = sidx;
+				go(r + 1, cur, taken, cost + add, slow, best, best_cost);
+				taken[sidx] = false;
+			}
+		}
+	};
+	Rec{ blocked_frac, launches }.go(0, cur, taken, 0.0, slow, best, best_cost);
+	const int spare = best[DB2];
+	e->s_main = pool[best[MAIN]];
+	e->s_ana[0] = e->s_main;
+	e->s_ent = pool[best[ENT]];
+	e->s_db[0] = pool[best[DB0]];
+	e->s_db[1] = pool[best[DB1]];
+	e->s_db[2] = pool[spare];
+	e->s_ana[1] = pool[best[IDR]];
+	e->s_ana[2] = pool[best[IN]];
+	if (trace) {
+		fprintf(stderr, "config: launch chain %.1f us per kernel; extra us per launch (blocked -> chain):", base);
+		for (int i = 0; i < NP; i++)
+			for (int j = 0; j < NP; j++)
+				if (slow[i][j] > 0)
+					fprintf(stderr, " %d->%d %.1f", i, j, slow[i][j]);
+		fprintf(stderr, "; roles main %d ent %d db %d %d idr %d in %d spare %d, expected delay %.1f us per frame\n", best[MAIN],
+			best[ENT], best[DB0], best[DB1], best[IDR], best[IN], spare, best_cost);
+	}
+	return 0;
 }
 
 // SPS (cedar.c:892-937) + PPS (cedar.c:939-982)
@@ -602,6 +715,18 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	const int S = ext.n_streams;
 	const int n_units = S * ext.slice_num;
 
+	// Frames in flight. Sessions that pipeline their frames on the device (few units, below) take
+	// IDR pictures out of the frame order -- they depend on nothing -- so an IDR picture submitted
+	// early enough costs no time; "early enough" is its ~2.5 ms against ~0.23 ms per P picture
+	// (1080p), hence the deep ring. Everything else keeps 4.
+	{
+		const char *envp = getenv("CEDAR_ROW_PIPE"), *envd = getenv("CEDAR_PIPE_DEPTH");
+		const bool deep = envp ? atoi(envp) != 0 : n_units <= 8;
+		e->depth = envd ? atoi(envd) : deep ? CEDAR_ENC_PIPELINE_DEPTH : 4;
+		if (e->depth < 2) e->depth = 2;
+		if (e->depth > CEDAR_ENC_PIPELINE_DEPTH) e->depth = CEDAR_ENC_PIPELINE_DEPTH;
+		e->nrec = e->depth + 1;
+	}
 	// ---- buffer manager (cedar.c:605-704) ----
 	const int luma_sz = align_up(cfg->src_width * cfg->src_height, 4096);      // cedar.c:612
 	const int chroma_sz = align_up(cfg->src_width * cfg->src_height / 2, 4096); // cedar.c:621
@@ -614,13 +739,13 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	int rc = 0;
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S, hipHostMallocDefault));
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S, hipHostMallocDefault));
-	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (S + 2) * sizeof(uint32_t), hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_sizes[i], e->h_sizes[i], 0));
 	}
-	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * ext.slice_num, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_hdr, e->fl[i].h_hdr, 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocMapped));
@@ -635,14 +760,14 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
 	P.plane_y_stride = (int64_t)plane_y;
 	P.plane_uv_stride = (int64_t)plane_uv;
-	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S))) return rc;
-	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S))) return rc;
-	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S))) return rc;
-	for (int i = 0; i < 2; i++) {
+	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S * e->depth))) return rc;
+	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S * e->depth))) return rc;
+	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S * e->depth))) return rc;
+	for (int i = 0; i < e->nrec; i++) {
 		if ((rc = dalloc(e, &e->d_rec_y[i], plane_y * S))) return rc;
 		if ((rc = dalloc(e, &e->d_rec_uv[i], plane_uv * S))) return rc;
 	}
-	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_src_y[i], plane_y * S))) return rc;
 		if ((rc = dalloc(e, &e->d_src_uv[i], plane_uv * S))) return rc;
 		// + 1 macroblock: the dummy slot idle k_inter waves write to
@@ -651,9 +776,17 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		if ((rc = dalloc(e, &e->d_nnz[i], ((size_t)P.n_mb * S + 1) * NNZ_PER_MB))) return rc;
 		if ((rc = dalloc(e, &e->d_coef[i], ((size_t)P.n_mb * S + 1) * COEF_PER_MB))) return rc;
 	}
-	if ((rc = dalloc(e, &e->d_slot, (size_t)P.n_mb * S * SLOT_WORDS))) return rc;
-	if ((rc = dalloc(e, &e->d_mb_bits, (size_t)P.n_mb * S))) return rc;
-	if ((rc = dalloc(e, &e->d_skip, (size_t)P.n_mb * S))) return rc;
+	{
+		// A second entropy lane (frames alternating between two streams with scratch of their own)
+		// is there for the asking; measured, one lane keeps up (1080p: 32.5 M MB/s either way)
+		const char *envl2 = getenv("CEDAR_ENTROPY_LANES");
+		e->ent_lanes = envl2 && atoi(envl2) > 1 && e->depth > 4 ? ENT_LANES : 1;
+	}
+	for (int l = 0; l < e->ent_lanes; l++) {
+		if ((rc = dalloc(e, &e->d_slot[l], (size_t)P.n_mb * S * SLOT_WORDS))) return rc;
+		if ((rc = dalloc(e, &e->d_mb_bits[l], (size_t)P.n_mb * S))) return rc;
+		if ((rc = dalloc(e, &e->d_skip[l], (size_t)P.n_mb * S))) return rc;
+	}
 	int max_rows = 0;
 	for (int s = ext.slice_first; s < ext.slice_first + ext.slice_num; s++) {
 		int a, b;
@@ -664,15 +797,17 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.rbsp_cap = align_up(P.unit_mb_cap * 1024 + 4096, 256);
 	P.esc_chunks_cap = P.rbsp_cap / ESC_CHUNK;
 	P.out_cap = (int32_t)e->out_cap;
-	if ((rc = dalloc(e, &e->d_bit_off, (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
-	if ((rc = dalloc(e, &e->d_run, (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
-	if ((rc = dalloc(e, &e->d_unit_bits, (size_t)n_units))) return rc;
-	if ((rc = dalloc(e, &e->d_rbsp, (size_t)n_units * P.rbsp_cap + 64))) return rc; // + one escape chunk of read slack
-	if ((rc = dalloc(e, &e->d_esc, (size_t)n_units * P.esc_chunks_cap))) return rc;
-	if ((rc = dalloc(e, &e->d_nal_off, (size_t)n_units))) return rc;
-	if ((rc = dalloc(e, &e->d_nal_size, (size_t)n_units))) return rc;
-	if ((rc = dalloc(e, &e->d_stream_size, (size_t)S + 3))) return rc;
-	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++)
+	for (int l = 0; l < e->ent_lanes; l++) {
+		if ((rc = dalloc(e, &e->d_bit_off[l], (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
+		if ((rc = dalloc(e, &e->d_run[l], (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
+		if ((rc = dalloc(e, &e->d_unit_bits[l], (size_t)n_units))) return rc;
+		if ((rc = dalloc(e, &e->d_rbsp[l], (size_t)n_units * P.rbsp_cap + 64))) return rc; // + one escape chunk of read slack
+		if ((rc = dalloc(e, &e->d_esc[l], (size_t)n_units * P.esc_chunks_cap))) return rc;
+		if ((rc = dalloc(e, &e->d_nal_off[l], (size_t)n_units))) return rc;
+		if ((rc = dalloc(e, &e->d_nal_size[l], (size_t)n_units))) return rc;
+		if ((rc = dalloc(e, &e->d_stream_size[l], (size_t)S + 4))) return rc; // + k_copy_out's workgroup counter
+	}
+	for (int i = 0; i < e->depth; i++)
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
 	{
@@ -708,7 +843,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
 		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 3) / 4);
 	}
-	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)3 * WF_SYNC_WORDS))) return rc;
 		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
 		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 3 * n_units * PROG_BANDS))) return rc;
@@ -725,7 +860,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		e->h_in_ptrs[s] = e->d_in_y + (size_t)s * luma_sz;
 		e->h_in_ptrs[S + s] = e->d_in_uv + (size_t)s * chroma_sz;
 	}
-	e->in_ptrs_dirty = true;
+	for (bool &v : e->in_tab_valid)
+		v = false;
 
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
 	e->s_ana[0] = e->s_main;
@@ -734,11 +870,22 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_db[i], hipStreamNonBlocking));
 	for (int i = 1; i < AN_STREAMS; i++)
 		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ana[i], hipStreamNonBlocking));
+	if (e->depth > 4) {
+		const char *envd3 = getenv("CEDAR_DEBLOCK_STREAMS");
+		const int rc_roles = assign_stream_roles(e, envd3 ? atoi(envd3) : 2);
+		if (rc_roles)
+			return rc_roles;
+	}
 	{
 		const char *env = getenv("CEDAR_DEBLOCK_PLANES");
 		e->split_planes = env ? atoi(env) != 0 : n_units <= 32; // two concurrent wavefronts while CUs are spare
 	}
 	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_host_in, hipEventDisableTiming));
+	if (getenv("CEDAR_TRACE_TIMELINE")) {
+		HIP_TRY(e, hipEventCreate(&e->ev_base));
+		HIP_TRY(e, hipEventRecord(e->ev_base, e->s_main));
+		HIP_TRY(e, hipEventSynchronize(e->ev_base));
+	}
 	{
 		// Frame pipelining needs kernels of s_main and of the deblock streams to be on the GPU at
 		// the same time (they poll each other's progress words). Probe it: a stream that shares
@@ -810,6 +957,51 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		int nb = envb ? atoi(envb) : 5;
 		if (nb > 64) nb = 64;
 		e->inter_bands = e->row_pipe ? (nb < 1 ? 1 : nb) : 1;
+		// Look-ahead for IDR pictures: two more streams -- the IDR picture's analysis (busy for
+		// milliseconds) and the input of all frames (which must never queue behind that, nor behind
+		// a gate on s_main) -- dealt by assign_stream_roles; each must run beside every stream in use.
+		// CEDAR_IDR_DEBLOCK_INLINE=0 also puts the IDR picture's deblocking on a stream of its own,
+		// resident beside the intra wavefront (measured slower: one more queue that blocks a pipe).
+		const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
+		e->lookahead = false;
+		e->idr_deblock_inline = !envi || atoi(envi) != 0;
+		if (e->row_pipe && e->depth > 4 && (!envl || atoi(envl) != 0)) {
+			// streams not taken by the deblock / analysis roles, in the order assign_stream_roles meant
+			// them for: IDR analysis, input, then the spare one (second entropy lane)
+			std::vector<hipStream_t> used = { e->s_main, e->s_ent }, spare, got;
+			for (int i = 0; i < e->db_streams; i++)
+				used.push_back(e->s_db[i]);
+			for (int i = 1; i < e->an_streams; i++)
+				used.push_back(e->s_ana[i]);
+			for (int i = e->an_streams; i < AN_STREAMS; i++)
+				spare.push_back(e->s_ana[i]);
+			for (int i = e->db_streams; i < DB_STREAMS; i++)
+				spare.push_back(e->s_db[i]);
+			const size_t want = e->idr_deblock_inline ? 3 : 4;
+			for (size_t c = 0; c < spare.size() && got.size() < want; c++) {
+				bool ok = true, o = false;
+				for (size_t j = 0; ok && j < used.size(); j++)
+					if (Launch::probe_overlap(spare[c], used[j], e->d_prog[0], &o) || !o)
+						ok = false;
+				if (ok) {
+					got.push_back(spare[c]);
+					used.push_back(spare[c]);
+				}
+			}
+			HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+			if (got.size() >= (e->idr_deblock_inline ? 2u : 3u)) {
+				e->s_idr = got[0];
+				e->s_in = got[1];
+				size_t k = 2;
+				e->s_db_idr = e->idr_deblock_inline ? nullptr : got[k++];
+				const char *envl2 = getenv("CEDAR_ENTROPY_LANES");
+				e->s_ent2 = k < got.size() && e->ent_lanes > 1 && (!envl2 || atoi(envl2) > 1) ? got[k] : nullptr;
+				e->lookahead = true;
+			}
+		}
+		if (getenv("CEDAR_TRACE_SUBMIT"))
+			fprintf(stderr, "config: row_pipe %d, deblock streams %d, analysis streams %d, stripes %d, look-ahead %d, depth %d\n",
+				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth);
 	}
 	{
 		// diagonal stripes s = x + 2*y of a P picture and, per stripe, how many of its macroblocks
@@ -838,7 +1030,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		e->P.dummy_rec = e->d_dummy_rec;
 		e->P.stripe_tab = nullptr;
 	}
-	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
+	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
 		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input[i], hipEventDisableTiming));
 		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis[i], hipEventDisableTiming));
@@ -855,18 +1047,18 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	P.in_chroma = (const uint8_t *const *)(e->d_in_ptrs + S);
 	P.src_y = e->d_src_y[0];
 	P.src_uv = e->d_src_uv[0];
-	P.slot = e->d_slot;
-	P.mb_bits = e->d_mb_bits;
-	P.skip = e->d_skip;
+	P.slot = e->d_slot[0];
+	P.mb_bits = e->d_mb_bits[0];
+	P.skip = e->d_skip[0];
 	P.mvd = nullptr;
-	P.bit_off = e->d_bit_off;
-	P.run_before = e->d_run;
-	P.unit_bits = e->d_unit_bits;
-	P.rbsp = e->d_rbsp;
-	P.esc_cnt = e->d_esc;
-	P.nal_off = e->d_nal_off;
-	P.nal_size = e->d_nal_size;
-	P.stream_size = e->d_stream_size;
+	P.bit_off = e->d_bit_off[0];
+	P.run_before = e->d_run[0];
+	P.unit_bits = e->d_unit_bits[0];
+	P.rbsp = e->d_rbsp[0];
+	P.esc_cnt = e->d_esc[0];
+	P.nal_off = e->d_nal_off[0];
+	P.nal_size = e->d_nal_size[0];
+	P.stream_size = e->d_stream_size[0];
 	P.out = e->d_out[0];
 	P.hdr = nullptr; // per frame: the frame's own pinned header words
 	P.prefix_len = nullptr;
@@ -923,7 +1115,8 @@ extern "C" int cedar_enc_set_device_input(cedar_enc *e, int stream, const void *
 		e->h_in_ptrs[stream] = e->d_in_y + (size_t)stream * e->cfg.input_luma_size;
 		e->h_in_ptrs[S + stream] = e->d_in_uv + (size_t)stream * e->cfg.input_chroma_size;
 	}
-	e->in_ptrs_dirty = true;
+	for (bool &v : e->in_tab_valid)
+		v = false;
 	return 0;
 }
 
@@ -945,35 +1138,41 @@ extern "C" int cedar_enc_pipeline_depth(void)
 	return CEDAR_ENC_PIPELINE_DEPTH;
 }
 
+extern "C" int cedar_enc_session_depth(const cedar_enc *e)
+{
+	return e && e->configured ? e->depth : -EINVAL;
+}
+
 extern "C" int cedar_enc_submit(cedar_enc *e)
 {
 	if (!e)
 		return -EINVAL;
 	if (!e->configured) // cedar.c:1039-1043
 		return fail(e, -EINVAL, "CONFIG not run yet");
-	if (e->fl_count >= CEDAR_ENC_PIPELINE_DEPTH)
+	if (e->fl_count >= e->depth)
 		return fail(e, -EBUSY, "pipeline full: collect first");
 	const double t0 = now_ms();
 	HIP_TRY(e, hipSetDevice(e->device));
 	const int S = e->ext.n_streams;
 	if (e->fl_count == 0)
 		e->fl_head = 0; // an empty pipeline always lands in host buffer 0 (the one CONFIG returned)
-	const int slot = (e->fl_head + e->fl_count) % CEDAR_ENC_PIPELINE_DEPTH;
+	const int slot = (e->fl_head + e->fl_count) % e->depth;
 	InFlight &f = e->fl[slot];
 	memset(f.tm.used, 0, sizeof(f.tm.used));
 	// frames in flight were submitted in order, so counters advance at submit
 	const bool idr = e->frame_p_count == 0; // cedar.c:1047-1050
 	// Device-side per-frame state rotates with the frame number (never the slot of the frame
 	// before, even when the ring of frames in flight restarts at 0)
-	const int ds = e->frame_count % CEDAR_ENC_PIPELINE_DEPTH;
+	const int ds = e->frame_count % e->depth;
 	f.ds = ds;
 	f.done_tag = (uint32_t)e->frame_count + 1u;
 	Params P = e->P;
 	P.is_idr = idr;
 	P.rec_y = e->d_rec_y[e->cur];
 	P.rec_uv = e->d_rec_uv[e->cur];
-	P.ref_y = e->d_rec_y[e->cur ^ 1];
-	P.ref_uv = e->d_rec_uv[e->cur ^ 1];
+	const int ref = (e->cur + e->nrec - 1) % e->nrec;
+	P.ref_y = e->d_rec_y[ref];
+	P.ref_uv = e->d_rec_uv[ref];
 	P.src_y = e->d_src_y[ds];
 	P.src_uv = e->d_src_uv[ds];
 	P.mbi = e->d_mbi[ds];
@@ -984,7 +1183,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	P.wf_hbuf = e->d_wf_hbuf[ds];
 	P.wf_hbuf_intra = e->d_wf_hbuf[ds] + (size_t)S * e->ext.slice_num * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
 	P.out = e->d_out[ds];
-	const int prev = e->prev_slot, prev2 = e->prev2_slot;
+	const int prev = e->prev_slot;
 	const bool pipe = e->row_pipe;
 	if (pipe) {
 		P.prog_inter = e->d_prog[ds];
@@ -994,49 +1193,76 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		P.prog_tag = (uint32_t)(e->frame_count + 1) << 16;
 		P.prev_tag = (uint32_t)e->frame_count << 16;
 	}
-	hipStream_t s_db = e->s_db[e->frame_count % e->db_streams];
-	hipStream_t s_ana = e->s_ana[e->frame_count % e->an_streams]; // frames take turns: each stream's gates wait for one frame only
+	// Which streams carry this frame. With look-ahead an IDR picture has streams of its own and
+	// waits for nothing but its input: it runs beside the P pictures submitted before it.
+	const bool ahead = e->lookahead && idr;
+	// (idr_deblock_inline: the IDR picture's deblocking follows its analysis on the same stream
+	// instead of running beside it on a stream of its own, resident and polling)
+	const bool db_late = ahead && e->idr_deblock_inline;
+	hipStream_t s_db = db_late ? e->s_idr : ahead ? e->s_db_idr : e->s_db[e->frame_count % e->db_streams];
+	hipStream_t s_ana = ahead ? e->s_idr : e->s_ana[e->frame_count % e->an_streams]; // frames take turns: each stream's gates wait for one frame only
+	hipStream_t s_in = e->lookahead ? e->s_in : s_ana; // input of all frames, in order, behind no gate
 	P.nal_ref_idc = idr ? 3 : 2; // cedar.c:987-990
 	P.nal_type = idr ? 5 : 1;
 
 	// ---- input: H2D of the pinned buffers unless the caller supplied device frames ----
-	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, s_ana);
+	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
 	bool any_host = false;
-	for (int s = 0; s < S; s++)
-		any_host = any_host || e->h_in_ptrs[s] == e->d_in_y + (size_t)s * e->cfg.input_luma_size;
-	if (any_host && prev >= 0 && e->an_streams > 1) // the device staging copy of the host input is shared by all frames
-		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[prev], 0));
+	const size_t in_y_slot = (size_t)ds * e->cfg.input_luma_size * S, in_uv_slot = (size_t)ds * e->cfg.input_chroma_size * S;
 	for (int s = 0; s < S; s++) {
+		// a stream without a device frame of its own points at the session's device copy (slot 0 is the mark)
 		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
 		if (e->h_in_ptrs[s] == own) {
 			any_host = true;
-			HIP_TRY(e, hipMemcpyAsync((void *)own, e->h_luma + (size_t)s * e->cfg.input_luma_size,
-						  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_ana));
-			HIP_TRY(e, hipMemcpyAsync(e->d_in_uv + (size_t)s * e->cfg.input_chroma_size,
+			HIP_TRY(e, hipMemcpyAsync(e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size,
+						  e->h_luma + (size_t)s * e->cfg.input_luma_size,
+						  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_in));
+			HIP_TRY(e, hipMemcpyAsync(e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size,
 						  e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
-						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_ana));
+						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_in));
 		}
 	}
+	auto in_ptr = [&](int s, bool chroma) -> const uint8_t * { // where k_input finds stream s of this frame
+		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
+		if (e->h_in_ptrs[s] != own)
+			return e->h_in_ptrs[(chroma ? S : 0) + s];
+		return chroma ? e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size
+			      : e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
+	};
 	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
 		P.in_luma = P.in_chroma = nullptr;
 		for (int s = 0; s < S; s++) {
-			P.in_k[s] = e->h_in_ptrs[s];
-			P.in_k[IN_K_STREAMS + s] = e->h_in_ptrs[S + s];
+			P.in_k[s] = in_ptr(s, false);
+			P.in_k[IN_K_STREAMS + s] = in_ptr(s, true);
 		}
-	} else if (e->in_ptrs_dirty) {
-		HIP_TRY(e, hipMemcpyAsync((void *)e->d_in_ptrs, e->h_in_ptrs.data(), sizeof(void *) * 2 * S,
-					  hipMemcpyHostToDevice, s_ana));
-		e->in_ptrs_dirty = false;
+	} else if (!e->in_tab_valid[ds]) {
+		// many streams: a pointer table in device memory per slot (the device copies of host frames
+		// rotate with the slot), uploaded when the caller changed a pointer
+		std::vector<const uint8_t *> &t = e->in_tab[ds];
+		t.resize((size_t)2 * S);
+		for (int s = 0; s < S; s++) {
+			t[s] = in_ptr(s, false);
+			t[S + s] = in_ptr(s, true);
+		}
+		HIP_TRY(e, hipMemcpyAsync((void *)(e->d_in_ptrs + (size_t)ds * 2 * S), t.data(), sizeof(void *) * 2 * S,
+					  hipMemcpyHostToDevice, s_in));
+		e->in_tab_valid[ds] = true;
+	}
+	if (S > IN_K_STREAMS) {
+		P.in_luma = (const uint8_t *const *)(e->d_in_ptrs + (size_t)ds * 2 * S);
+		P.in_chroma = P.in_luma + S;
 	}
 	if (any_host)
-		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_ana));
+		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_in));
 	// (k_input also zeroes the ticket / abort / progress words of the wavefront kernels)
 	*f.h_wf_err = 0;
 	P.wf_err = f.d_wf_err;
-	if (Launch::input(P, s_ana))
+	if (Launch::input(P, s_in))
 		return fail(e, -EIO, "k_input launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, s_ana);
-	HIP_TRY(e, hipEventRecord(e->ev_input[ds], s_ana));
+	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
+	HIP_TRY(e, hipEventRecord(e->ev_input[ds], s_in));
+	if (s_in != s_ana)
+		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[ds], 0));
 
 	auto launch_deblock = [&]() -> int {
 	// ---- in-loop deblocking: produces the next frame's reference ----
@@ -1047,7 +1273,15 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		// on its own stream, the progress words need no zeroing (frame tags).
 		if (!pipe)
 			HIP_TRY(e, hipStreamWaitEvent(s_db, e->ev_analysis[ds], 0));
-		if (e->wf_split > 1)
+		if (db_late) // same stream: everything is there when the kernel starts, nothing to poll
+			P.prog_intra = nullptr;
+		// Pipelined: ONE packet on the deblock stream per frame -- every packet queued behind a
+		// resident kernel costs the hardware pipe ~20 us. The kernel's last workgroup zeroes the
+		// sync words for the slot's next frame and raises the frame's done flag itself.
+		P.db_self_reset = pipe ? 1 : 0;
+		P.done_flag = f.d_done + 1;
+		P.done_tag = f.done_tag;
+		if (!pipe && e->wf_split > 1)
 			HIP_TRY(e, hipMemsetAsync(e->d_wf_sync[ds] + WF_SYNC_WORDS, 0,
 						  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)S * e->ext.slice_num * WF_MAX_SPLIT), s_db));
 		tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
@@ -1056,31 +1290,30 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		if (Launch::deblock(P, s_db, e->split_planes ? 4 : 3))
 			return fail(e, -EIO, "k_deblock launch failed");
 		tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
-		// the frame is complete when deblocking and entropy coding are (collect waits for both events)
-		HIP_TRY(e, hipEventRecord(f.done_main, s_db));
-		HIP_TRY(e, hipEventRecord(e->ev_deblocked[ds], s_db));
-		if (Launch::flag(s_db, f.d_done + 1, f.done_tag))
-			return fail(e, -EIO, "k_flag launch failed");
+		P.db_self_reset = 0;
+		f.s_db = s_db;
+		if (!pipe) {
+			// the frame is complete when deblocking and entropy coding are (collect waits for both)
+			HIP_TRY(e, hipEventRecord(f.done_main, s_db));
+			HIP_TRY(e, hipEventRecord(e->ev_deblocked[ds], s_db));
+			if (Launch::flag(s_db, f.d_done + 1, f.done_tag))
+				return fail(e, -EIO, "k_flag launch failed");
+		}
 		return 0;
 	};
 	// Row-pipelined, the deblock kernel only polls progress words: it is queued BEFORE this
 	// frame's analysis so that it is resident and waiting when the first stripe arrives.
-	if (pipe) {
+	if (pipe && !db_late) {
 		const int rc_db = launch_deblock();
 		if (rc_db)
 			return rc_db;
 	}
 
 	// ---- analysis + reconstruction ----
-	// What this frame overwrites or reads of its predecessors:
-	//   rec[cur] was deblocked in place by frame n-2 (same s_db stream as this frame's deblock);
-	//   a P picture reads rec[cur^1], which frame n-1 is deblocking.
-	// Row-pipelined, a P picture follows frame n-1's deblocking band by band (k_gate), which
-	// also implies frame n-2 is through; everything else waits for whole frames.
-	if (prev2 >= 0 && (idr || !pipe))
-		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_deblocked[prev2], 0));
-	if (prev >= 0 && idr && e->an_streams > 1) // an IDR overwrites the picture the frame before is still searching
-		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_analysis[prev], 0));
+	// What this frame overwrites or reads of its predecessors: rec[cur] was last touched by frames
+	// that have been collected (the buffers rotate through depth + 1); a P picture reads the
+	// reconstruction frame n-1 is deblocking. Row-pipelined, a P picture follows that deblocking
+	// band by band (k_gate); otherwise it waits for the whole frame. An IDR picture waits for nothing.
 	if (prev >= 0 && !idr && !pipe)
 		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_deblocked[prev], 0));
 	if (idr) {
@@ -1132,23 +1365,47 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	f.aud = e->ext.aud && e->ext.slice_first == 0 ? (idr ? 1 : 2) : 0; // the first slice's session opens the access unit
 	for (int s = 0; s < S; s++)
 		f.h_prefix[s] = (with_ps ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
-	HIP_TRY(e, hipStreamWaitEvent(e->s_ent, e->ev_analysis[ds], 0));
-	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
+	// entropy lanes: frames alternate between two streams with scratch buffers of their own
+	const int lane = e->ent_lanes > 1 && e->s_ent2 ? e->frame_count % e->ent_lanes : 0;
+	hipStream_t s_ent = lane ? e->s_ent2 : e->s_ent;
+	P.slot = e->d_slot[lane];
+	P.mb_bits = e->d_mb_bits[lane];
+	P.skip = e->d_skip[lane];
+	P.bit_off = e->d_bit_off[lane];
+	P.run_before = e->d_run[lane];
+	P.unit_bits = e->d_unit_bits[lane];
+	P.rbsp = e->d_rbsp[lane];
+	P.esc_cnt = e->d_esc[lane];
+	P.nal_off = e->d_nal_off[lane];
+	P.nal_size = e->d_nal_size[lane];
+	P.stream_size = e->d_stream_size[lane];
+	f.lane = lane;
+	HIP_TRY(e, hipStreamWaitEvent(s_ent, e->ev_analysis[ds], 0));
+	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
 	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
 	P.prefix_len = f.dv_prefix;
-	HIP_TRY(e, hipMemsetAsync(e->d_stream_size, 0, sizeof(uint32_t) * (S + 3), e->s_ent));
-	if (Launch::entropy(P, e->s_ent))
+	// Pipelined: as few packets on the entropy stream as possible (see launch_deblock): the size
+	// words are left zeroed and the done flag raised by k_copy_out's last workgroup
+	if (!pipe)
+		HIP_TRY(e, hipMemsetAsync(e->d_stream_size[lane], 0, sizeof(uint32_t) * (S + 4), s_ent));
+	if (Launch::entropy(P, s_ent))
 		return fail(e, -EIO, "entropy launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, e->s_ent);
+	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
 	f.host_out = slot; // every frame in flight owns one host buffer until it is collected
-	if (Launch::copy_out(P, e->s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
+	f.s_ent = s_ent;
+	f.events = !pipe;
+	P.done_flag = pipe ? f.d_done : nullptr;
+	P.done_tag = f.done_tag;
+	if (Launch::copy_out(P, s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
 		return fail(e, -EIO, "k_copy_out launch failed");
-	HIP_TRY(e, hipEventRecord(f.done_ent, e->s_ent));
-	if (Launch::flag(e->s_ent, f.d_done, f.done_tag))
-		return fail(e, -EIO, "k_flag launch failed");
+	if (!pipe) {
+		HIP_TRY(e, hipEventRecord(f.done_ent, s_ent));
+		if (Launch::flag(s_ent, f.d_done, f.done_tag))
+			return fail(e, -EIO, "k_flag launch failed");
+	}
 	const double t_ent = now_ms();
 
-	if (!pipe) {
+	if (!pipe || db_late) {
 		const int rc_db = launch_deblock();
 		if (rc_db)
 			return rc_db;
@@ -1159,6 +1416,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	e->fl_count++;
 	e->last_slot = ds;
 	e->last_rec = e->cur;
+	e->last_lane = lane;
 	e->prev2_slot = e->prev_slot;
 	e->prev_slot = ds;
 	// cedar.c:1193-1201: advance the GOP counter, swap reference frames
@@ -1166,7 +1424,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	if (e->frame_p_count == e->cfg.keyframe_interval)
 		e->frame_p_count = 0;
 	e->frame_count++;
-	e->cur ^= 1;
+	e->cur = (e->cur + 1) % e->nrec;
 	if (any_host) // the caller may refill the pinned input buffers once they are on the device
 		HIP_TRY(e, hipEventSynchronize(e->ev_host_in));
 	if (getenv("CEDAR_TRACE_SUBMIT"))
@@ -1199,12 +1457,13 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 			}
 		}
 		if (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
-			HIP_TRY(e, hipEventSynchronize(f.done_ent));
-			HIP_TRY(e, hipEventSynchronize(f.done_main));
+			// (pipelined frames record no events: their streams are kept to the fewest packets)
+			HIP_TRY(e, f.events ? hipEventSynchronize(f.done_ent) : hipStreamSynchronize(f.s_ent));
+			HIP_TRY(e, f.events ? hipEventSynchronize(f.done_main) : hipStreamSynchronize(f.s_db));
 		}
 		std::atomic_thread_fence(std::memory_order_acquire);
 	}
-	e->fl_head = (e->fl_head + 1) % CEDAR_ENC_PIPELINE_DEPTH;
+	e->fl_head = (e->fl_head + 1) % e->depth;
 	e->fl_count--;
 	f.active = false;
 	const uint32_t *sz = e->h_sizes[slot];
@@ -1230,6 +1489,8 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	e->res_host = f.host_out;
 	e->last_total = total;
 	if (e->profiling) {
+		static const char *const stage_name[CEDAR_ENC_STAGE_COUNT] = { "input", "intra_decide", "intra_recon", "inter", "deblock", "entropy" };
+		const bool timeline = e->ev_base && getenv("CEDAR_TRACE_TIMELINE");
 		for (int st = 0; st < CEDAR_ENC_STAGE_COUNT; st++)
 			if (f.tm.used[st]) {
 				float ms = 0;
@@ -1237,6 +1498,10 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 					e->stats.ms[st] += ms;
 					e->stats.launches[st]++;
 				}
+				float a = 0, b = 0; // when the stage ran on the device, relative to the session's base event
+				if (timeline && hipEventElapsedTime(&a, e->ev_base, f.tm.ev[st][0]) == hipSuccess &&
+				    hipEventElapsedTime(&b, e->ev_base, f.tm.ev[st][1]) == hipSuccess)
+					fprintf(stderr, "timeline frame %llu %s %.3f %.3f\n", (unsigned long long)e->stats.frames, stage_name[st], a, b);
 			}
 	}
 	e->stats.frames++;
@@ -1344,7 +1609,7 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 	case CEDAR_ENC_DBG_RECON_UV: src = e->d_rec_uv[rec] + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
 	case CEDAR_ENC_DBG_SRC_Y: src = e->d_src_y[par] + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
 	case CEDAR_ENC_DBG_SRC_UV: src = e->d_src_uv[par] + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
-	case CEDAR_ENC_DBG_MB_BITS: src = e->d_mb_bits + (size_t)stream * P.n_mb; n = sizeof(uint32_t) * P.n_mb; break;
+	case CEDAR_ENC_DBG_MB_BITS: src = e->d_mb_bits[e->last_lane] + (size_t)stream * P.n_mb; n = sizeof(uint32_t) * P.n_mb; break;
 	default: return -EINVAL;
 	}
 	if ((size_t)dst_size < n)

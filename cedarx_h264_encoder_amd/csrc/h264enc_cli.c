@@ -127,6 +127,7 @@ int main(int argc, char **argv)
 	 * H264ENC_PIPELINE=0 restores the serial loop. */
 	if (env_int("H264ENC_PIPELINE", 1)) {
 		int in_flight = 0;
+		const int depth = cedar_enc_session_depth(cedar);
 
 		while (1) {
 			int got = read_frame(fd_in, config.input_luma, luma_size) == luma_size &&
@@ -140,7 +141,7 @@ int main(int argc, char **argv)
 				else
 					in_flight++;
 			}
-			while (in_flight > (got ? CEDAR_ENC_PIPELINE_DEPTH - 1 : 0)) {
+			while (in_flight > (got ? depth - 1 : 0)) {
 				const uint8_t *data;
 				int size;
 

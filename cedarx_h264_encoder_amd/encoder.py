@@ -102,6 +102,7 @@ def load_library():
     L.cedar_enc_encode.argtypes = [vp]
     L.cedar_enc_pipeline_depth.argtypes = []
     L.cedar_enc_pipeline_depth.restype = ctypes.c_int
+    L.cedar_enc_session_depth.argtypes = [vp]
     L.cedar_enc_submit.argtypes = [vp]
     L.cedar_enc_collect.argtypes = [vp]
     L.cedar_enc_close.argtypes = [vp]
@@ -224,8 +225,8 @@ class CedarEncoder:
 
     @property
     def pipeline_depth(self):
-        """Frames that may be in flight between submit() and collect()."""
-        return int(self._L.cedar_enc_pipeline_depth())
+        """Frames this session allows in flight between submit() and collect()."""
+        return self._check(self._L.cedar_enc_session_depth(self._h), "session_depth")
 
     def submit(self):
         return self._check(self._L.cedar_enc_submit(self._h), "submit")

@@ -133,15 +133,18 @@ int cedar_enc_set_device_input(cedar_enc *enc, int stream, const void *d_luma, c
 
 /* Pipelined form of encode for throughput: submit queues one frame for every
  * stream without waiting; collect waits for the oldest submitted frame and
- * returns its byte count (same meaning as cedar_enc_encode). At most
- * CEDAR_ENC_PIPELINE_DEPTH frames may be in flight. cedar_enc_encode ==
- * submit + collect. With few streams, frames in flight overlap on the device
- * along macroblock rows (frame n+1 is analysed behind frame n's deblocking
- * wavefront); the bytes are the same at any depth. Device input frames
- * (cedar_enc_set_device_input) must stay untouched until their frame is
- * collected. */
-#define CEDAR_ENC_PIPELINE_DEPTH 4
-int cedar_enc_pipeline_depth(void);
+ * returns its byte count (same meaning as cedar_enc_encode). cedar_enc_encode ==
+ * submit + collect. A session allows cedar_enc_session_depth() frames in flight
+ * (submit returns -EBUSY beyond that): 4, or CEDAR_ENC_PIPELINE_DEPTH (the
+ * maximum) for sessions of few streams, whose frames overlap on the device --
+ * frame n+1 is analysed behind frame n's deblocking wavefront, and an IDR
+ * picture, which depends on no other frame, runs beside the P pictures submitted
+ * before it, so it costs no time when the caller keeps the ring full. The bytes
+ * are the same at any depth. Device input frames (cedar_enc_set_device_input)
+ * must stay untouched until their frame is collected. */
+#define CEDAR_ENC_PIPELINE_DEPTH 16
+int cedar_enc_pipeline_depth(void);                  /* the compile-time maximum */
+int cedar_enc_session_depth(const cedar_enc *enc);   /* this session's; -EINVAL before CONFIG */
 int cedar_enc_submit(cedar_enc *enc);
 int cedar_enc_collect(cedar_enc *enc);
 
