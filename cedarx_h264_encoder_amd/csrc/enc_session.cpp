@@ -723,6 +723,12 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		const char *envp = getenv("CEDAR_ROW_PIPE"), *envd = getenv("CEDAR_PIPE_DEPTH");
 		const bool deep = envp ? atoi(envp) != 0 : n_units <= 8;
 		e->depth = envd ? atoi(envd) : deep ? CEDAR_ENC_PIPELINE_DEPTH : 4;
+		// every slot owns a pinned bytestream buffer sized for the worst case: keep the ring's
+		// share of host memory bounded (4K: 33 MB a slot, eight 1080p streams: 67 MB)
+		const size_t per_slot = ((size_t)P.n_mb * 1024 + 4096 < ((size_t)1 << 20) ? (size_t)1 << 20 : (size_t)P.n_mb * 1024 + 4096) * S;
+		if (!envd && deep && (size_t)e->depth * per_slot > ((size_t)512 << 20))
+			e->depth = (int)(((size_t)512 << 20) / per_slot);
+		if (e->depth < 4) e->depth = envd ? e->depth : 4;
 		if (e->depth < 2) e->depth = 2;
 		if (e->depth > CEDAR_ENC_PIPELINE_DEPTH) e->depth = CEDAR_ENC_PIPELINE_DEPTH;
 		e->nrec = e->depth + 1;
