@@ -340,9 +340,10 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 {
 	enum { MAIN, ENT, DB0, DB1, IDR, IN, DB2, NROLE };
 	const bool three = db_streams_wanted >= 3; // a third deblock stream, or a spare
-	// (the seventh role is a third deblock stream, or else the second entropy lane)
-	const double blocked_frac[NROLE] = { 0.5, 0.3, 0.9, 0.9, 0.45, 0.0, three ? 0.9 : 0.3 };
-	const double launches[NROLE] = { 12, three ? 10.0 : 5.0, three ? 1.0 : 1.5, three ? 1.0 : 1.5, 0.3, 0.1, three ? 1.0 : 5.0 };
+	// (the seventh role is a third deblock stream, a second entropy lane, or -- the default -- a spare)
+	const bool ent1 = !three && e->ent_lanes > 1;
+	const double blocked_frac[NROLE] = { 0.5, 0.3, 0.9, 0.9, 0.45, 0.0, three ? 0.9 : ent1 ? 0.3 : 0.0 };
+	const double launches[NROLE] = { 12, ent1 ? 5.0 : 10.0, three ? 1.0 : 1.5, three ? 1.0 : 1.5, 0.3, 0.1, three ? 1.0 : ent1 ? 5.0 : 0.0 };
 	hipStream_t pool[7] = { e->s_main, e->s_ent, e->s_db[0], e->s_db[1], e->s_db[2], e->s_ana[1], e->s_ana[2] };
 	const int NP = 7;
 	double slow[NP][NP] = {}; // [blocked][chain]: extra us per launch
@@ -1500,6 +1501,9 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 		for (int st = 0; st < CEDAR_ENC_STAGE_COUNT; st++)
 			if (f.tm.used[st]) {
 				float ms = 0;
+				// (a pipelined frame's done flags are raised from inside its last kernels: the
+				// marker behind such a kernel may be a few microseconds away still)
+				hipEventSynchronize(f.tm.ev[st][1]);
 				if (hipEventElapsedTime(&ms, f.tm.ev[st][0], f.tm.ev[st][1]) == hipSuccess) {
 					e->stats.ms[st] += ms;
 					e->stats.launches[st]++;
