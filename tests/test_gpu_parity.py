@@ -264,22 +264,38 @@ def test_full_depth_pipeline_matches_oracle(ce, w, h, qp, keyint, n):
 
 
 def test_frame_pipelining_on_off_and_stripe_counts_agree(ce, monkeypatch):
+    """Every schedule the session can be configured into writes the same bytes: frames back to
+    back, pipelined with different stripe counts, with and without the IDR look-ahead, shallow and
+    deep rings, the IDR picture's deblocking beside or behind its intra wavefront, a third deblock
+    stream, a second analysis stream, a second entropy lane."""
     w, h = 640, 368
-    frames = [ol.gen_frame("C", w, h, f) for f in range(9)]
-    outs = {}
+    frames = [ol.gen_frame("C", w, h, f) for f in range(13)]
+    knobs = ("CEDAR_ROW_PIPE", "CEDAR_INTER_BANDS", "CEDAR_ANALYSIS_STREAMS", "CEDAR_LOOKAHEAD", "CEDAR_PIPE_DEPTH",
+             "CEDAR_IDR_DEBLOCK_INLINE", "CEDAR_DEBLOCK_STREAMS", "CEDAR_ENTROPY_LANES")
+    outs, depths = {}, {}
     for key, env in (("off", {"CEDAR_ROW_PIPE": "0"}), ("on", {"CEDAR_ROW_PIPE": "1"}),
                      ("2 stripes", {"CEDAR_ROW_PIPE": "1", "CEDAR_INTER_BANDS": "2"}),
                      ("11 stripes, 1 analysis stream", {"CEDAR_ROW_PIPE": "1", "CEDAR_INTER_BANDS": "11",
-                                                        "CEDAR_ANALYSIS_STREAMS": "1"})):
-        for k in ("CEDAR_ROW_PIPE", "CEDAR_INTER_BANDS", "CEDAR_ANALYSIS_STREAMS"):
+                                                        "CEDAR_ANALYSIS_STREAMS": "1"}),
+                     ("no look-ahead, depth 4", {"CEDAR_LOOKAHEAD": "0", "CEDAR_PIPE_DEPTH": "4"}),
+                     ("no look-ahead, depth 16", {"CEDAR_LOOKAHEAD": "0"}),
+                     ("depth 5", {"CEDAR_PIPE_DEPTH": "5"}),
+                     ("idr deblock beside intra", {"CEDAR_IDR_DEBLOCK_INLINE": "0"}),
+                     ("3 deblock streams", {"CEDAR_DEBLOCK_STREAMS": "3"}),
+                     ("2 analysis streams", {"CEDAR_ANALYSIS_STREAMS": "2"}),
+                     ("2 entropy lanes", {"CEDAR_ENTROPY_LANES": "2"})):
+        for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)   # read by cedar_enc_config
         with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=4) as enc:
+            depths[key] = enc.pipeline_depth
             outs[key] = _encode_pipelined(enc, frames)
-    assert outs["on"] == outs["off"]
-    assert outs["2 stripes"] == outs["off"]
-    assert outs["11 stripes, 1 analysis stream"] == outs["off"]
+    for key in outs:
+        assert outs[key] == outs["off"], key
+    assert depths["on"] == 16 and depths["off"] == 4 and depths["depth 5"] == 5 and depths["no look-ahead, depth 4"] == 4
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=4))
+    assert outs["off"] == [oe.encode(y, uv) for y, uv in frames]
 
 
 def test_pipelined_multi_slice_and_multi_stream_sessions(ce):
