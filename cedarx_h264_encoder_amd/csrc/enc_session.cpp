@@ -972,7 +972,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
 		e->lookahead = false;
 		e->idr_deblock_inline = !envi || atoi(envi) != 0;
-		if (e->row_pipe && e->depth > 4 && (!envl || atoi(envl) != 0)) {
+		// (sessions whose frames run back to back take the IDR picture out of line too: nothing polls
+		// there, the P picture after it waits for its events, and with 4 frames in flight it gets a
+		// three-frame head start)
+		const char *envlb = getenv("CEDAR_LOOKAHEAD_BATCH");
+		if ((e->row_pipe ? e->depth > 4 : ((!envlb || atoi(envlb) != 0) && e->depth >= 3)) && (!envl || atoi(envl) != 0)) {
 			// streams not taken by the deblock / analysis roles, in the order assign_stream_roles meant
 			// them for: IDR analysis, input, then the spare one (second entropy lane)
 			std::vector<hipStream_t> used = { e->s_main, e->s_ent }, spare, got;
