@@ -19,6 +19,7 @@ for s in range(NSRC):
     frames.append(fr)
 torch.cuda.synchronize()
 for S in [int(x) for x in sys.argv[1:]] or [1]:
+    enc = None  # (one pipelined session per process and device: let the previous one go first)
     enc = ce.CedarEncoder(width=W, height=H, qp=QP, keyframe_interval=int(os.environ.get("KEYINT", "25")), n_streams=S, slice_count=SLICES)
     depth = enc.pipeline_depth
     def feed(i):
