@@ -189,6 +189,22 @@ def test_batched_streams_equal_independent_streams(ce):
                 assert ge.output(s) == refs[s], "frame %d stream %d" % (f, s)
 
 
+@pytest.mark.parametrize("batch_lookahead", ["1", "0"])
+def test_many_streams_back_to_back_with_idr_lookahead(ce, monkeypatch, batch_lookahead):
+    """More than 8 units: frames run back to back, 4 in flight; IDR pictures still leave the
+    frame order (streams of their own, events instead of progress words). 11 streams, two slices
+    each, keyint 3, the ring kept full: every stream equals its own oracle."""
+    monkeypatch.setenv("CEDAR_LOOKAHEAD_BATCH", batch_lookahead)
+    w, h, S, n = 176, 144, 11, 10
+    frames = [[ol.gen_frame("B", w, h, f, s << 8) for s in range(S)] for f in range(n)]
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=3, slice_count=2)) for _ in range(S)]
+    want = [[oes[s].encode(*frames[f][s]) for s in range(S)] for f in range(n)]
+    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=3, slice_count=2, n_streams=S) as enc:
+        assert enc.pipeline_depth == 4
+        got = _encode_pipelined(enc, frames, streams=S)
+    assert got == want
+
+
 def test_config4_shape_eight_1080p_streams_in_one_session(ce):
     """BASELINE configs[4] shape on one device: 8 lock-step 1920x1080 streams (seed offset
     s<<8); every stream must equal the oracle's encode of that stream alone."""
