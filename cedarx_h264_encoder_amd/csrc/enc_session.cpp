@@ -248,6 +248,7 @@ struct cedar_enc {
 	// stats
 	bool profiling = false;
 	unsigned profile_mask = ~0u;
+	int profile_every = 1;
 	cedar_enc_stats stats{};
 	uint32_t last_total = 0;
 	char err[256] = { 0 };
@@ -1133,14 +1134,14 @@ extern "C" int cedar_enc_set_device_input(cedar_enc *e, int stream, const void *
 
 static void tm_begin(cedar_enc *e, InFlight &f, int stage, hipStream_t s)
 {
-	if (e->profiling && ((e->profile_mask >> stage) & 1u)) {
+	if (e->profiling && ((e->profile_mask >> stage) & 1u) && e->frame_count % e->profile_every == 0) {
 		hipEventRecord(f.tm.ev[stage][0], s);
 		f.tm.used[stage] = true;
 	}
 }
 static void tm_end(cedar_enc *e, InFlight &f, int stage, hipStream_t s)
 {
-	if (e->profiling && ((e->profile_mask >> stage) & 1u))
+	if (f.tm.used[stage])
 		hipEventRecord(f.tm.ev[stage][1], s);
 }
 
@@ -1581,6 +1582,9 @@ extern "C" int cedar_enc_set_profiling(cedar_enc *e, int on)
 		return -EINVAL;
 	// 0 off, 1 every stage, otherwise bit (1 + stage) selects a stage: events are stream markers,
 	// a dozen of them per frame cost ~10 % of a pipelined 1080p stream
+	// bits 8..15: time every n-th frame only (a marker behind a resident kernel costs its pipe ~20 us)
+	e->profile_every = ((on >> 8) & 0xff) > 1 ? (on >> 8) & 0xff : 1;
+	on &= 0xff;
 	e->profiling = on != 0;
 	e->profile_mask = on == 1 ? ~0u : (unsigned)on >> 1;
 	return 0;

@@ -247,15 +247,17 @@ class CedarEncoder:
         return self.output(stream)
 
     # -- instrumentation --
-    def set_profiling(self, on=True, stages=None):
-        """HIP-event timing of the stages: all of them, or only the named ones (cheaper)."""
+    def set_profiling(self, on=True, stages=None, every=1):
+        """HIP-event timing of the stages: all of them, or only the named ones (cheaper), on every
+        frame or on every `every`-th one (cheaper still)."""
+        sample = (min(max(int(every), 1), 255) << 8) if on else 0
         if on and stages:
             mask = 0
             for name in stages:
                 mask |= 1 << (1 + STAGES.index(name))
-            self._L.cedar_enc_set_profiling(self._h, mask)
+            self._L.cedar_enc_set_profiling(self._h, mask | sample)
         else:
-            self._L.cedar_enc_set_profiling(self._h, 1 if on else 0)
+            self._L.cedar_enc_set_profiling(self._h, (1 if on else 0) | sample)
 
     def stats(self):
         s = _Stats()

@@ -167,7 +167,8 @@ struct cedar_enc_stats {
 	int      wf_split;                       /* workgroups (CUs) per unit in the wavefront kernels */
 	int      deblock_planes_split;           /* 1: luma and chroma deblock run as two kernels      */
 };
-/* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time */
+/* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
+ * bits 8..15 = n: time every n-th frame only (0/1: every frame) */
 int cedar_enc_set_profiling(cedar_enc *enc, int on);
 int cedar_enc_get_stats(cedar_enc *enc, struct cedar_enc_stats *out);
 int cedar_enc_reset_stats(cedar_enc *enc);
