@@ -18,14 +18,20 @@ for s in range(NSRC):
         fr.append((torch.from_numpy(y).to(dev), torch.from_numpy(uv).to(dev)))
     frames.append(fr)
 torch.cuda.synchronize()
+host_frames = [[(y.cpu().numpy(), uv.cpu().numpy()) for y, uv in fr] for fr in frames] if os.environ.get("TPUT_HOST") == "1" else None
 for S in [int(x) for x in sys.argv[1:]] or [1]:
     enc = None  # (one pipelined session per process and device: let the previous one go first)
     enc = ce.CedarEncoder(width=W, height=H, qp=QP, keyframe_interval=int(os.environ.get("KEYINT", "25")), n_streams=S, slice_count=SLICES)
     depth = enc.pipeline_depth
+    HOST = os.environ.get("TPUT_HOST") == "1"   # frames handed over in the pinned host buffers (the reference contract)
     def feed(i):
         for s in range(S):
             y, uv = frames[s % NSRC][i % 26 if i % 25 else 0]
-            enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
+            if HOST:
+                hy, huv = host_frames[s % NSRC][i % 26 if i % 25 else 0]
+                enc.set_input(hy, huv, s)   # memcpy into the session's pinned buffers; submit does the H2D
+            else:
+                enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
         enc.submit()
     q = 0
     for i in range(50):   # pipelined warm-up: the runtime's one-time pool growth stalls land here
