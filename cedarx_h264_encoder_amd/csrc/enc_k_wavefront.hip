@@ -273,6 +273,13 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	}
 
 	__syncthreads();
+	// a ticket beyond the launch means the sync words were not zero when the kernel started: refuse
+	// to index memory with it (code 32 in the frame's error word) rather than fault
+	if (s_ticket < 0 || s_ticket >= p.n_streams * p.slice_num * NWG) {
+		if (threadIdx.x == 0)
+			__hip_atomic_store(p.wf_err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		return;
+	}
 	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
 	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
 	int r0, r1;
@@ -939,6 +946,13 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		s_i4b[threadIdx.x] = 0;
 	}
 	__syncthreads();
+	// a ticket beyond the launch means the sync words were not zero when the kernel started: refuse
+	// to index memory with it (code 32 in the frame's error word) rather than fault
+	if (s_ticket < 0 || s_ticket >= p.n_streams * p.slice_num * NWG) {
+		if (threadIdx.x == 0)
+			__hip_atomic_store(p.wf_err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		return;
+	}
 	const int unit = s_ticket / NWG, wj = s_ticket % NWG;
 	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
 	int r0, r1;

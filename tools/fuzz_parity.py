@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One-off wide parity sweep against the oracle: random geometries, QPs, GOP lengths, slice and
+stream counts, header options, frames kept in flight (development tool; tests/ holds the fixed cases)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import cedarx_h264_encoder_amd as ce
+from tests import oracle_lib as ol
+seed, n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 100
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+rng = np.random.RandomState(seed)
+t0 = time.time()
+for case in range(n_cases):
+    w = max(16, int(rng.randint(1, 40)) * 16 - int(rng.choice([0, 0, 2, 6, 10, 14])))
+    h = max(16, int(rng.randint(1, 24)) * 16 - int(rng.choice([0, 0, 2, 4, 8, 12])))
+    mb_h = (h + 15) // 16
+    qp = int(rng.choice([1, 8, 17, 24, 30, 36, 41, 47]))
+    keyint = int(rng.choice([1, 2, 3, 5, 25]))
+    slices = int(rng.randint(1, min(4, mb_h) + 1))
+    S = int(rng.choice([1, 1, 1, 2, 3, 9]))
+    pat = str(rng.choice(["A", "B", "B", "C"]))
+    kw = dict(aud=int(rng.randint(0, 2)), repeat_headers=int(rng.randint(0, 2)))
+    if rng.randint(0, 2):
+        kw.update(fps_num=int(rng.choice([24, 25, 30000])), fps_den=int(rng.choice([1, 1001])))
+    n = int(rng.randint(3, 14))
+    depth_draw = int(rng.randint(1, 17))
+    if case < first_case:
+        continue
+    print("case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s n %d depth<=%d" % (case, w, h, qp, keyint, slices, S, pat, kw, n, depth_draw), flush=True)
+    frames = [[ol.gen_frame(pat, w, h, f, s << 8) for s in range(S)] for f in range(n)]
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **kw)) for _ in range(S)]
+    want = [[oes[s].encode(*frames[f][s]) for s in range(S)] for f in range(n)]
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, n_streams=S, **kw) as enc:
+        depth, got, q = min(enc.pipeline_depth, depth_draw), [], 0
+        for fr in frames:
+            if q == depth:
+                enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
+            for s in range(S):
+                enc.set_input(fr[s][0], fr[s][1], stream=s)
+            enc.submit(); q += 1
+        while q:
+            enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
+    if got != want:
+        sys.exit("MISMATCH seed %d case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s depth %d" % (
+            seed, case, w, h, qp, keyint, slices, S, pat, kw, depth))
+print("seed %d: %d cases bit-exact in %.0f s" % (seed, n_cases, time.time() - t0))
