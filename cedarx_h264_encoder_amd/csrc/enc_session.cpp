@@ -230,7 +230,8 @@ struct cedar_enc {
 	// beside the P pictures submitted before them
 	bool lookahead = false;
 	bool idr_deblock_inline = true;
-	hipStream_t s_in = nullptr, s_idr = nullptr, s_db_idr = nullptr;
+	hipStream_t s_in = nullptr, s_idr = nullptr, s_db_idr = nullptr, s_idr2 = nullptr;
+	unsigned idr_count = 0;
 	bool split_planes = true;
 	hipEvent_t ev_host_in = nullptr; // pinned input buffers consumed
 	hipEvent_t ev_base = nullptr;    // time zero of CEDAR_TRACE_TIMELINE
@@ -341,10 +342,12 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 {
 	enum { MAIN, ENT, DB0, DB1, IDR, IN, DB2, NROLE };
 	const bool three = db_streams_wanted >= 3; // a third deblock stream, or a spare
-	// (the seventh role is a third deblock stream, a second entropy lane, or -- the default -- a spare)
-	const bool ent1 = !three && e->ent_lanes > 1;
-	const double blocked_frac[NROLE] = { 0.5, 0.3, 0.9, 0.9, 0.45, 0.0, three ? 0.9 : ent1 ? 0.3 : 0.0 };
-	const double launches[NROLE] = { 12, ent1 ? 5.0 : 10.0, three ? 1.0 : 1.5, three ? 1.0 : 1.5, 0.3, 0.1, three ? 1.0 : ent1 ? 5.0 : 0.0 };
+	// (the seventh role is a third deblock stream, a second entropy lane, or -- the default -- the
+	// stream that carries every other IDR picture)
+	const bool ent1 = !three && e->ent_lanes > 1, idr2 = !three && !ent1;
+	const double blocked_frac[NROLE] = { 0.5, 0.3, 0.9, 0.9, idr2 ? 0.25 : 0.45, 0.0, three ? 0.9 : ent1 ? 0.3 : 0.25 };
+	const double launches[NROLE] = { 12, ent1 ? 5.0 : 10.0, three ? 1.0 : 1.5, three ? 1.0 : 1.5, idr2 ? 0.15 : 0.3, 0.1,
+					 three ? 1.0 : ent1 ? 5.0 : 0.15 };
 	hipStream_t pool[7] = { e->s_main, e->s_ent, e->s_db[0], e->s_db[1], e->s_db[2], e->s_ana[1], e->s_ana[2] };
 	const int NP = 7;
 	double slow[NP][NP] = {}; // [blocked][chain]: extra us per launch
@@ -1008,6 +1011,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 				e->s_db_idr = e->idr_deblock_inline ? nullptr : got[k++];
 				const char *envl2 = getenv("CEDAR_ENTROPY_LANES");
 				e->s_ent2 = k < got.size() && e->ent_lanes > 1 && (!envl2 || atoi(envl2) > 1) ? got[k] : nullptr;
+				// the spare stream otherwise carries every other IDR picture: consecutive IDR pictures
+				// depend on nothing either, which doubles the rate of short GOPs (keyint 1: all of them)
+				e->s_idr2 = !e->s_ent2 && e->idr_deblock_inline && k < got.size() ? got[k] : nullptr;
 				e->lookahead = true;
 			}
 		}
@@ -1211,8 +1217,9 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	// (idr_deblock_inline: the IDR picture's deblocking follows its analysis on the same stream
 	// instead of running beside it on a stream of its own, resident and polling)
 	const bool db_late = ahead && e->idr_deblock_inline;
-	hipStream_t s_db = db_late ? e->s_idr : ahead ? e->s_db_idr : e->s_db[e->frame_count % e->db_streams];
-	hipStream_t s_ana = ahead ? e->s_idr : e->s_ana[e->frame_count % e->an_streams]; // frames take turns: each stream's gates wait for one frame only
+	hipStream_t s_idr = ahead && e->s_idr2 && (e->idr_count & 1u) ? e->s_idr2 : e->s_idr; // IDR pictures take turns
+	hipStream_t s_db = db_late ? s_idr : ahead ? e->s_db_idr : e->s_db[e->frame_count % e->db_streams];
+	hipStream_t s_ana = ahead ? s_idr : e->s_ana[e->frame_count % e->an_streams]; // frames take turns: each stream's gates wait for one frame only
 	hipStream_t s_in = e->lookahead ? e->s_in : s_ana; // input of all frames, in order, behind no gate
 	P.nal_ref_idc = idr ? 3 : 2; // cedar.c:987-990
 	P.nal_type = idr ? 5 : 1;
@@ -1436,6 +1443,8 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	if (e->frame_p_count == e->cfg.keyframe_interval)
 		e->frame_p_count = 0;
 	e->frame_count++;
+	if (idr)
+		e->idr_count++;
 	e->cur = (e->cur + 1) % e->nrec;
 	if (any_host) // the caller may refill the pinned input buffers once they are on the device
 		HIP_TRY(e, hipEventSynchronize(e->ev_host_in));
