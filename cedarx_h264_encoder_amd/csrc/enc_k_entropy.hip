@@ -512,7 +512,9 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
 	const bool has_left = mx > 0, has_top = my > r0;
 	const bool has_c = has_top && (mx < p.mb_w - 1 || mx > 0);
-	const size_t addr_c = has_top ? (mx < p.mb_w - 1 ? mbaddr - p.mb_w + 1 : mbaddr - p.mb_w - 1) : mbaddr;
+	// (has_c, not has_top: a picture one macroblock wide has no neighbour C at all, and mbaddr - 2 of
+	// its second row is element -1 of the record array)
+	const size_t addr_c = has_c ? (mx < p.mb_w - 1 ? mbaddr - p.mb_w + 1 : mbaddr - p.mb_w - 1) : mbaddr;
 
 	// ---- stage everything the half needs (coalesced) ----
 	{

@@ -32,6 +32,8 @@ CASES = [
     (64, 48, 5, 3, 4, "C", 1),       # very low QP: escape-coded levels
     (64, 48, 47, 3, 4, "B", 1),      # highest QP the reference accepts
     (16, 16, 24, 2, 4, "C", 1),      # single macroblock
+    (16, 350, 30, 1, 4, "A", 3),     # one macroblock wide, tall: no neighbour C anywhere (k_cavlc2 read record -1 of the second row)
+    (16, 96, 24, 3, 6, "B", 2),
     (432, 32, 24, 3, 4, "B", 1),
     (64, 80, 24, 3, 4, "B", 1),      # 5 macroblock rows: idle row groups in the last band
     (96, 112, 30, 25, 4, "C", 1),    # 7 rows
