@@ -3,6 +3,7 @@ oracle on the same seeded inputs. Integer pipeline => the bar is BIT-EXACT:
 identical Annex-B bytes, identical per-macroblock decisions/levels and
 identical deblocked reconstruction. All tests here need an MI355X."""
 import errno
+import os
 
 import numpy as np
 import pytest
@@ -559,3 +560,23 @@ def test_lost_handoff_drains_and_reports_eio(ce, monkeypatch, which, keyint):
     with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=keyint) as good:
         for y, uv in frames:
             assert good.encode_frame(y, uv) == oe.encode(y, uv)
+
+
+@pytest.mark.parametrize("mode", ["plain", "narrow", "wide"])
+def test_fuzz_sweep_against_oracle(mode):
+    """tools/fuzz_parity.py with a fixed seed: random geometry (every other picture 1-3 macroblocks
+    wide or high in "narrow"), QP, GOP length, slices, streams (up to 33 in "wide"), search range,
+    chroma QP offset, header options and frames in flight; every access unit against the oracle.
+    The sweep is what found k_cavlc2 reading record -1 on pictures one macroblock wide."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if mode == "narrow":
+        env["FUZZ_NARROW"] = "1"
+    if mode == "wide":
+        env["FUZZ_WIDE"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "40"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "40 cases bit-exact" in r.stdout

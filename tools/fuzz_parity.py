@@ -28,13 +28,25 @@ for case in range(n_cases):
     kw = dict(aud=int(rng.randint(0, 2)), repeat_headers=int(rng.randint(0, 2)))
     if rng.randint(0, 2):
         kw.update(fps_num=int(rng.choice([24, 25, 30000])), fps_den=int(rng.choice([1, 1001])))
+    if os.environ.get("FUZZ_WIDE"):   # more of the configuration space: many streams, search ranges, chroma QP offsets
+        S = int(rng.choice([1, 2, 8, 9, 17, 33]))
+        if S > 9:
+            w, h = min(w, 160), min(h, 96)
+        sr = int(rng.choice([0, 0, -1, 1, 4, 9]))
+        coff = int(rng.choice([4, 4, -12, 0, 12]))
+        kw.update(search_range=sr, chroma_qp_offset_minus4=coff - 4)
     n = int(rng.randint(3, 14))
     depth_draw = int(rng.randint(1, 17))
     if case < first_case:
         continue
     print("case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s n %d depth<=%d" % (case, w, h, qp, keyint, slices, S, pat, kw, n, depth_draw), flush=True)
     frames = [[ol.gen_frame(pat, w, h, f, s << 8) for s in range(S)] for f in range(n)]
-    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **kw)) for _ in range(S)]
+    okw = dict(kw)
+    if "search_range" in okw:
+        sr_ = okw.pop("search_range")
+        okw["search_range"] = 16 if sr_ == 0 else max(sr_, 0)
+        okw["chroma_qp_offset"] = okw.pop("chroma_qp_offset_minus4") + 4
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **okw)) for _ in range(S)]
     want = [[oes[s].encode(*frames[f][s]) for s in range(S)] for f in range(n)]
     with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, n_streams=S, **kw) as enc:
         depth, got, q = min(enc.pipeline_depth, depth_draw), [], 0
