@@ -19,6 +19,9 @@ for case in range(n_cases):
             w = int(rng.choice([16, 18, 32, 34, 48]))
         else:
             h = int(rng.choice([16, 18, 32, 34, 48]))
+    if os.environ.get("FUZZ_BIG"):   # 640x360 .. 1920x1088: many bands per workgroup, the real split factors
+        w = int(rng.randint(40, 121)) * 16 - int(rng.choice([0, 0, 2, 6, 10, 14]))
+        h = int(rng.randint(22, 69)) * 16 - int(rng.choice([0, 0, 2, 4, 8, 12]))
     mb_h = (h + 15) // 16
     qp = int(rng.choice([1, 8, 17, 24, 30, 36, 41, 47]))
     keyint = int(rng.choice([1, 2, 3, 5, 25]))
@@ -36,6 +39,8 @@ for case in range(n_cases):
         coff = int(rng.choice([4, 4, -12, 0, 12]))
         kw.update(search_range=sr, chroma_qp_offset_minus4=coff - 4)
     n = int(rng.randint(3, 14))
+    if os.environ.get("FUZZ_BIG"):
+        n, S = min(n, 5), min(S, 2)
     depth_draw = int(rng.randint(1, 17))
     if case < first_case:
         continue
