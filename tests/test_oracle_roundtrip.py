@@ -102,3 +102,16 @@ def test_chroma_qp_offset_round_trip(off):
     for bad in (-13, 13):
         with pytest.raises(Exception):
             ol.OracleEncoder(ol.default_config(w, h, chroma_qp_offset=bad))
+
+
+def test_fuzzed_round_trips():
+    """tools/fuzz_oracle_roundtrip.py, fixed seed: 120 random configurations (geometry, QP, GOP,
+    slices, search range, chroma QP offset, header options), decode(stream) == reconstruction."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_roundtrip.py"), "20261003", "120"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    assert "120 cases, decode == recon" in r.stdout
