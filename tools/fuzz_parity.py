@@ -53,6 +53,27 @@ for case in range(n_cases):
         okw["chroma_qp_offset"] = okw.pop("chroma_qp_offset_minus4") + 4
     oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **okw)) for _ in range(S)]
     want = [[oes[s].encode(*frames[f][s]) for s in range(S)] for f in range(n)]
+    if os.environ.get("FUZZ_WIDE") and slices >= 2 and S == 1 and case % 3 == 0:
+        # the slices of one picture on two sessions ("two GPUs"): the concatenation is the whole
+        a = int(rng.randint(1, slices))
+        parts = [ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices,
+                                 slice_first=f0, slice_num=fn, **kw) for f0, fn in ((0, a), (a, slices - a))]
+        got = []
+        for fr in frames:
+            for pe in parts:
+                pe.set_input(fr[0][0], fr[0][1])
+                pe.submit()
+            au = b""
+            for pe in parts:
+                pe.collect()
+                au += pe.output(0)
+            got.append([au])
+        for pe in parts:
+            pe.close()
+        if got != want:
+            sys.exit("MISMATCH (sharded slices %d+%d) seed %d case %d: %dx%d qp %d keyint %d slices %d pattern %s %s" % (
+                a, slices - a, seed, case, w, h, qp, keyint, slices, pat, kw))
+        continue
     with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, n_streams=S, **kw) as enc:
         depth, got, q = min(enc.pipeline_depth, depth_draw), [], 0
         for fr in frames:
