@@ -225,6 +225,7 @@ def run_rank(args, rank, world, local_rank):
     roofline = {
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "wf_split": st.get("wf_split"),
+        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams")},
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "avg_launch_ms": round(avg_ms, 4), "launches": launches,
         "algorithmic_bytes_per_launch": int(alg_bytes),

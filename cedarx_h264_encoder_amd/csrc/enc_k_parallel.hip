@@ -510,16 +510,22 @@ __global__ void k_probe_set(uint32_t *w)
 
 int Launch::probe_overlap(void *waiter, void *setter, uint32_t *d_words, bool *overlaps)
 {
-	uint32_t h[2] = { 0, 0 };
-	if (hipMemcpy(d_words, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess)
-		return -1;
-	hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, (hipStream_t)waiter, d_words);
-	hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, (hipStream_t)setter, d_words);
-	if (hipStreamSynchronize((hipStream_t)waiter) != hipSuccess || hipStreamSynchronize((hipStream_t)setter) != hipSuccess)
-		return -1;
-	if (hipMemcpy(h, d_words, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
-		return -1;
-	*overlaps = h[1] != 0;
+	// A "no" is tried again: on a box that is still paging things in, the setter's launch can take
+	// longer than the waiter's patience once, and a false "no" costs the whole frame pipelining
+	// (two streams that do share a hardware queue say "no" every time).
+	*overlaps = false;
+	for (int attempt = 0; attempt < 3 && !*overlaps; attempt++) {
+		uint32_t h[2] = { 0, 0 };
+		if (hipMemcpy(d_words, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess)
+			return -1;
+		hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, (hipStream_t)waiter, d_words);
+		hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, (hipStream_t)setter, d_words);
+		if (hipStreamSynchronize((hipStream_t)waiter) != hipSuccess || hipStreamSynchronize((hipStream_t)setter) != hipSuccess)
+			return -1;
+		if (hipMemcpy(h, d_words, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+			return -1;
+		*overlaps = h[1] != 0;
+	}
 	return 0;
 }
 

@@ -1606,6 +1606,10 @@ extern "C" int cedar_enc_get_stats(cedar_enc *e, struct cedar_enc_stats *out)
 	*out = e->stats;
 	out->wf_split = e->wf_split;
 	out->deblock_planes_split = e->split_planes ? 1 : 0;
+	out->frames_pipelined = e->row_pipe ? 1 : 0;
+	out->idr_lookahead = e->lookahead ? 1 : 0;
+	out->depth = e->depth;
+	out->deblock_streams = e->db_streams;
 	return 0;
 }
 

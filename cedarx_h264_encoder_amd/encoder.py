@@ -47,7 +47,9 @@ class _ConfigExt(ctypes.Structure):
 class _Stats(ctypes.Structure):
     _fields_ = [("frames", ctypes.c_uint64), ("launches", ctypes.c_uint64 * 6),
                 ("ms", ctypes.c_double * 6), ("encode_wall_ms", ctypes.c_double),
-                ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int)]
+                ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int),
+                ("frames_pipelined", ctypes.c_int), ("idr_lookahead", ctypes.c_int), ("depth", ctypes.c_int),
+                ("deblock_streams", ctypes.c_int)]
 
 
 _lib = None
@@ -264,6 +266,8 @@ class CedarEncoder:
         self._L.cedar_enc_get_stats(self._h, ctypes.byref(s))
         return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms, "wf_split": s.wf_split,
                 "deblock_planes_split": bool(s.deblock_planes_split),
+                "frames_pipelined": bool(s.frames_pipelined), "idr_lookahead": bool(s.idr_lookahead),
+                "depth": s.depth, "deblock_streams": s.deblock_streams,
                 "ms": {n: s.ms[i] for i, n in enumerate(STAGES)},
                 "launches": {n: s.launches[i] for i, n in enumerate(STAGES)}}
 

@@ -166,6 +166,10 @@ struct cedar_enc_stats {
 	double   encode_wall_ms;                 /* host wall time inside encode  */
 	int      wf_split;                       /* workgroups (CUs) per unit in the wavefront kernels */
 	int      deblock_planes_split;           /* 1: luma and chroma deblock run as two kernels      */
+	int      frames_pipelined;               /* 1: frames in flight overlap on the device          */
+	int      idr_lookahead;                  /* 1: IDR pictures run on streams of their own        */
+	int      depth;                          /* frames in flight this session allows               */
+	int      deblock_streams;                /* deblock streams in use                             */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */
