@@ -1542,6 +1542,7 @@ extern "C" int cedar_enc_encode(cedar_enc *e)
 	// a failed encode leaves GOP counters and reference frames untouched
 	// (cedar.c:1182-1191 return before :1193-1201)
 	const int fc = e->frame_count, fpc = e->frame_p_count, cur = e->cur, ps = e->prev_slot, ps2 = e->prev2_slot;
+	const unsigned ic = e->idr_count;
 	int r = cedar_enc_submit(e);
 	if (r >= 0)
 		r = cedar_enc_collect(e);
@@ -1556,6 +1557,7 @@ extern "C" int cedar_enc_encode(cedar_enc *e)
 		e->cur = cur;
 		e->prev_slot = ps;
 		e->prev2_slot = ps2;
+		e->idr_count = ic;
 	}
 	return r;
 }
