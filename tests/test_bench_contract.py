@@ -33,7 +33,7 @@ def _free_port():
 @pytest.mark.gpu
 def test_bench_single_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "25", "--warmup", "25",
-                        "--cpu-frames", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-frames", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
     assert KEYS <= set(j)
@@ -55,7 +55,7 @@ def test_bench_two_ranks_shard_streams():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "25", "--warmup", "25"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)                       # rank 0 prints, once
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0

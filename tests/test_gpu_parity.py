@@ -577,6 +577,6 @@ def test_fuzz_sweep_against_oracle(mode):
         env["FUZZ_WIDE"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "40"],
-                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+                       capture_output=True, text=True, env=env, timeout=300, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "40 cases bit-exact" in r.stdout

@@ -112,6 +112,6 @@ def test_fuzzed_round_trips():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_roundtrip.py"), "20261003", "120"],
-                       capture_output=True, text=True, timeout=600, cwd=root)
+                       capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
     assert "120 cases, decode == recon" in r.stdout
