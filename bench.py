@@ -10,18 +10,33 @@ the host). Workload = BASELINE.json configs[2] per GPU (1920x1080 nv12, I+P,
 keyint 25, QP 24, synthetic pattern-B); with N GPUs every rank encodes its own
 streams (configs[4]: independent streams shard with no collective), so scaling is
 weak and `value` is total macroblocks of all ranks / max-over-ranks time.
+`--slices-across-gpus` is configs[3] instead: rank k encodes slice k of ONE picture
+(3840x2160 by default), the host concatenates the slice NALs; strong scaling.
 
 Inputs are resident in HBM before the timed region (device-input entry point of
 the C-ABI); the Annex-B bytes land in pinned host memory inside it.
 
+The timed region carries the GOP's I:P mix whatever K and W are: in front of the W
+warm-up frames the measured session encodes (-W mod keyint) alignment frames, so
+that the K timed frames start with an IDR picture and hold ceil(K / keyint) of them
+(`config.timed_region`).
+
 Extra objects on the JSON line:
-  roofline     dominant kernel: algorithmic bytes per launch / its average
-               launch duration measured with HIP events on the kernel's stream
+  roofline     dominant kernel: algorithmic bytes per launch / its average launch
+               duration (HIP events on the kernel's stream). `avg_launch_ms` is measured
+               in the timed region, where a pipelined deblock kernel is RESIDENT and
+               polls for its frame's analysis; `work_ms` is the same kernel in a session
+               whose frames run back to back (duration = work) and is what `achieved`
+               divides by. `true_bound` names what really limits the kernel (the SAD
+               issue rate for k_inter, the dependency chain for the wavefront kernels)
+               and the fraction of THAT ceiling; `kernels` lists every stage the same way.
   cpu_baseline the scalar C oracle (oracle/, kind "port") timed on this box's
                host cores on a bounded sample of the same workload (rank 0, N=1)
+  gop_parallel the same ONE stream with G closed GOPs encoded side by side
+               (cedar_enc_config_ext.gop_parallel; same bytes, G*keyint frames of latency)
+  batched      S lock-step streams per GPU
 """
 import argparse
-import ctypes
 import hashlib
 import json
 import os
@@ -47,7 +62,15 @@ KERNEL_BYTES_PER_MB = {
     "deblock": 384 + 384,        # read + write reconstruction in place
     "entropy": 816 + 24 + 8,     # levels + counts + record read once (bitstream added separately)
 }
+KERNEL_NAME = {"input": "k_input", "intra_decide": "k_intra_decide", "intra_recon": "k_intra_recon2", "inter": "k_inter",
+               "deblock": "k_deblock2_planes", "entropy": "k_cavlc2..k_copy_out"}
 PIPELINE_BYTES_PER_MB = {"I": 768.0, "P": 1152.0}
+# What really bounds each kernel. k_inter: the exhaustive +-16 search is 33*33
+# candidates x 256 absolute differences per macroblock; every byte-SAD instruction of gfx950 retires
+# ~1 absolute difference per lane and cycle (tools/dev/sad_bench.hip: v_sad_u8 4 per 4.17 cycles,
+# v_qsad_pk_u16_u8 16 per 14.8), so the chip's ceiling is 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz.
+SAD_OPS_PER_MB = 33 * 33 * 256
+SAD_PEAK_OPS = 256 * 4 * 64 * 2.4e9 * (4 / 4.17)
 
 
 def parse():
@@ -56,19 +79,25 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--streams", type=int, default=1, help="lock-step streams per GPU")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--qp", type=int, default=24)
     ap.add_argument("--keyint", type=int, default=25)
     ap.add_argument("--frames", type=int, default=50, help="distinct synthetic frames per stream (cycled)")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--batched-streams", type=str, default="8,32",
                     help="also report throughput with these many lock-step streams per GPU (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--gop-parallel", type=str, default="8",
+                    help="also report ONE stream with this many closed GOPs side by side (0 = skip)")
+    ap.add_argument("--slices-across-gpus", action="store_true",
+                    help="configs[3]: rank k encodes slice k of one picture (default 3840x2160), no collective")
+    a = ap.parse_args()
+    if not a.width:
+        a.width, a.height = (3840, 2160) if a.slices_across_gpus else (1920, 1080)
+    return a
 
 
 def run_rank(args, rank, world, local_rank):
-    import numpy as np
     import torch
     import torch.distributed as dist
     import cedarx_h264_encoder_amd as ce
@@ -81,12 +110,13 @@ def run_rank(args, rank, world, local_rank):
     torch.cuda.set_device(dev)
     rdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
     W, H = args.width, args.height
+    K = args.keyint
     mbs_per_frame = ((W + 15) // 16) * ((H + 15) // 16)
 
     def make_inputs(S):
         ins = []
         for s in range(S):
-            gs = rank * S + s  # global stream id: seed offset s<<8
+            gs = (0 if args.slices_across_gpus else rank * S) + s  # global stream id: seed offset s<<8
             fr = []
             for f in range(args.frames):
                 y, uv = ce.gen_pattern("B", W, H, f, gs << 8)
@@ -100,62 +130,75 @@ def run_rank(args, rank, world, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def allmax(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allsum(x):
+        if world == 1:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def session(S, **kw):
+        if args.slices_across_gpus:   # this rank's slice of the one picture
+            kw.update(slice_count=world, slice_first=rank, slice_num=1)
+        return ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=K, n_streams=S, device=local_rank, **kw)
+
+    class Pump:
+        """frames through submit / collect with the ring as full as the session allows"""
+
+        def __init__(self, enc, S, inputs, keep=None, keep_n=0):
+            self.enc, self.S, self.inputs, self.keep, self.keep_n = enc, S, inputs, keep, keep_n
+            self.depth, self.in_flight, self.nbytes = enc.pipeline_depth, 0, 0
+
+        def take(self):
+            self.nbytes += self.enc.collect()
+            self.in_flight -= 1
+            if self.keep is not None and len(self.keep) < self.keep_n:
+                self.keep.append(self.enc.output(0))
+
+        def feed(self, first, n):
+            for i in range(first, first + n):
+                if self.in_flight == self.depth:
+                    self.take()
+                for s in range(self.S):
+                    y, uv = self.inputs[s % len(self.inputs)][i % args.frames]
+                    self.enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
+                self.enc.submit()
+                self.in_flight += 1
+            return self
+
+        def drain(self):
+            while self.in_flight:
+                self.take()
+            return self
+
     def prime(S, inputs):
         # Process warm-up, not a benchmark step: the HIP runtime grows its per-queue signal and
         # kernel-argument pools the first time many frames are in flight on a set of streams,
         # which stalls single submits by milliseconds. A throw-away session takes those stalls so
         # that the W warm-up frames of the measured session need not be many (the ring alone is 16
         # deep). Its output is discarded; nothing of it is reused by the measured session.
-        with ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=args.keyint,
-                             n_streams=S, device=local_rank) as pe:
-            depth, q = pe.pipeline_depth, 0
-            for i in range(3 * depth + args.keyint):
-                if q == depth:
-                    pe.collect()
-                    q -= 1
-                for s in range(S):
-                    y, uv = inputs[s % len(inputs)][i % args.frames]
-                    pe.set_device_input(s, y.data_ptr(), uv.data_ptr())
-                pe.submit()
-                q += 1
-            while q:
-                pe.collect()
-                q -= 1
+        with session(S) as pe:
+            Pump(pe, S, inputs).feed(0, 3 * pe.pipeline_depth + K).drain()
 
-    def measure(S, steps, warmup, inputs, profile):
+    def measure(S, steps, warmup, inputs, profile, keep_n=0):
         prime(S, inputs)
-        enc = ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=args.keyint,
-                              n_streams=S, device=local_rank)
-        nbytes = 0
+        enc = session(S)
         first_aus = []
-
-        def feed(i):
-            for s in range(S):
-                y, uv = inputs[s % len(inputs)][i % args.frames]
-                enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
-            enc.submit()
-
-        # warmup (also keeps the first access units for the parity check). Every stage
-        # is timed here to find the dominant one; the timed region below only times that stage:
+        # alignment frames + warm-up (also keeps the first access units for the parity check). Every
+        # stage is timed here to find the dominant one; the timed region below only times that stage:
         # events are stream markers and a dozen per frame cost ~10 % of a pipelined stream.
+        pad = (-warmup) % K
+        while pad + warmup < keep_n:
+            pad += K
         enc.set_profiling(profile)
-        depth = enc.pipeline_depth
-        in_flight = 0
-        # (pipelined like the timed region: the runtime grows its per-queue pools the first time
-        # several frames are in flight, which stalls a few submits by milliseconds)
-        for i in range(warmup):
-            if in_flight == depth:
-                enc.collect()
-                if len(first_aus) < args.cpu_frames:
-                    first_aus.append(enc.output(0))
-                in_flight -= 1
-            feed(i)
-            in_flight += 1
-        while in_flight:
-            enc.collect()
-            if len(first_aus) < args.cpu_frames:
-                first_aus.append(enc.output(0))
-            in_flight -= 1
+        Pump(enc, S, inputs, first_aus, keep_n).feed(0, pad + warmup).drain()
         st_warm = enc.stats() if profile else None
         dominant = None
         if profile and st_warm and any(st_warm["ms"].values()):
@@ -168,95 +211,160 @@ def run_rank(args, rank, world, local_rank):
         barrier()
         t0 = time.perf_counter()
         # pipelined: as many frames in flight as the session allows (cedar_enc_submit / collect)
-        depth = enc.pipeline_depth
-        in_flight = 0
-        for i in range(warmup, warmup + steps):
-            if in_flight == depth:
-                nbytes += enc.collect()
-                in_flight -= 1
-            feed(i)
-            in_flight += 1
-        while in_flight:
-            nbytes += enc.collect()
-            in_flight -= 1
+        pm = Pump(enc, S, inputs).feed(pad + warmup, steps).drain()
         barrier()
         dt = time.perf_counter() - t0
         st = enc.stats()
         st["warmup"] = st_warm
         st["dominant"] = dominant
+        st["first_frame"] = pad + warmup
         enc.close()
-        return dt, nbytes, st, first_aus
+        return dt, pm.nbytes, st, first_aus
+
+    def measure_work(S, inputs):
+        """per-stage kernel time with the frames of the session back to back: durations are work"""
+        os.environ["CEDAR_ROW_PIPE"] = "0"
+        try:
+            with session(S) as enc:
+                enc.set_profiling(True)
+                for i in range(K + 8):
+                    for s in range(S):
+                        y, uv = inputs[s % len(inputs)][i % args.frames]
+                        enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
+                    enc.encode()
+                st = enc.stats()
+        finally:
+            del os.environ["CEDAR_ROW_PIPE"]
+        return {k: st["ms"][k] / max(1, st["launches"][k]) for k in st["ms"]}
+
+    def measure_gop_parallel(G, inputs, steps):
+        """ONE stream, G closed GOPs side by side: frames in and out in stream order, whole groups"""
+        n = max(1, -(-steps // (G * K))) * G * K
+        prime(G, inputs)
+        with session(1, gop_parallel=G) as enc:
+            barrier()
+            t0 = time.perf_counter()
+            pm = Pump(enc, 1, inputs).feed(0, n)
+            enc.flush()
+            pm.drain()
+            barrier()
+            dt = time.perf_counter() - t0
+        return n, dt
 
     S = args.streams
     sweep = [int(x) for x in str(args.batched_streams).split(",") if x.strip() and int(x) > 0 and int(x) != S]
+    gsweep = [int(x) for x in str(args.gop_parallel).split(",") if x.strip() and int(x) > 1]
+    if args.slices_across_gpus:
+        sweep, gsweep = [], []
     # at most 8 distinct synthetic streams are generated; larger batches reuse them cyclically
     inputs = make_inputs(max(S, min(8, max(sweep + [1]))))
-    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, os.environ.get("BENCH_NO_PROFILE") is None)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        nbytes_all = float(b.item())
-    else:
-        dt_max, nbytes_all = dt, float(nbytes)
+    profile = os.environ.get("BENCH_NO_PROFILE") is None
+    keep_n = args.cpu_frames if world == 1 else (3 if args.slices_across_gpus else 0)
+    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, profile, keep_n=keep_n)
+    dt_max = allmax(dt)
+    nbytes_all = allsum(nbytes)
+    slices_equal = None
+    if args.slices_across_gpus and world > 1:
+        # verification, outside the timed region (the data path itself has no collective): the slice
+        # NALs of the first pictures from every rank, concatenated in slice order by rank 0, must be
+        # the access units of ONE session coding all the slices
+        parts = [None] * world
+        dist.all_gather_object(parts, first_aus)
+        if rank == 0:
+            with ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=K, n_streams=S, device=local_rank,
+                                 slice_count=world) as one:
+                whole = []
+                for i in range(len(first_aus)):
+                    for s in range(S):
+                        y, uv = inputs[s % len(inputs)][i % args.frames]
+                        one.set_device_input(s, y.data_ptr(), uv.data_ptr())
+                    one.encode()
+                    whole.append(one.output(0))
+            joined = [b"".join(parts[r][i] for r in range(world)) for i in range(len(first_aus))]
+            slices_equal = joined == whole
+            if not slices_equal:
+                raise SystemExit("slices from %d ranks do not concatenate to the one-session stream" % world)
 
-    total_mbs = world * S * mbs_per_frame * args.steps
+    if args.slices_across_gpus:   # one picture per step, whatever the rank count
+        total_mbs = S * mbs_per_frame * args.steps
+    else:
+        total_mbs = world * S * mbs_per_frame * args.steps
     value = total_mbs / dt_max
 
     batched = []
     for SB in sweep:
         bsteps = max(25, min(args.steps, 50))
-        bdt, _, _, _ = measure(SB, bsteps, args.keyint, inputs, False)
-        if world > 1:
-            t = torch.tensor([bdt], dtype=torch.float64, device=rdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            bdt = float(t.item())
+        bdt, _, _, _ = measure(SB, bsteps, K, inputs, False)
+        bdt = allmax(bdt)
         v = world * SB * mbs_per_frame * bsteps / bdt
         batched.append({"streams_per_gpu": SB, "steps": bsteps, "value": v, "ms_per_step": bdt / bsteps * 1e3,
                         "pipeline_frac_of_hbm_peak": v * 1136.64 / 1e9 / HBM_PEAK_GBS})
+    gop_par = []
+    for G in gsweep:
+        n, gdt = measure_gop_parallel(G, inputs, args.steps)
+        gdt = allmax(gdt)
+        v = world * mbs_per_frame * n / gdt
+        gop_par.append({"gops_side_by_side": G, "frames": n, "value": v, "ms_per_frame": gdt / n * 1e3,
+                        "latency_frames": (G - 1) * K + 1,
+                        "pipeline_frac_of_hbm_peak": v * 1136.64 / 1e9 / HBM_PEAK_GBS})
+    work_ms = measure_work(S, inputs) if profile else None
 
     if rank != 0:
         return None
 
-    # ---- roofline of the dominant kernel (HIP-event durations from the timed region) ----
+    # ---- roofline of the dominant kernel ----
     stage = st.get("dominant") or max(st["ms"], key=lambda k: st["ms"][k])
     launches = max(1, st["launches"][stage])
-    avg_ms = max(st["ms"][stage] / launches, 1e-9)
-    mb_per_launch = S * mbs_per_frame
-    kname, tkey, per_mb = "k_" + stage, stage, KERNEL_BYTES_PER_MB[stage]
-    if stage == "deblock":
-        # one launch filters both planes (luma and chroma workgroups, or both in every wave pair)
-        kname = "k_deblock2_planes"
-    alg_bytes = per_mb * mb_per_launch
-    if stage == "entropy":
-        alg_bytes += nbytes / max(1, args.steps)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    avg_ms = max(st["ms"][stage] / launches, 1e-9)   # in the timed region: resident time for a pipelined deblock kernel
+    my_mbs = mbs_per_frame // world if args.slices_across_gpus else mbs_per_frame
+    mb_per_launch = S * my_mbs
+    wms = (work_ms or {}).get(stage) or avg_ms
+
+    def kernel_line(k, ms):
+        alg = KERNEL_BYTES_PER_MB[k] * mb_per_launch + (nbytes / max(1, args.steps) if k == "entropy" else 0)
+        ach = alg / (ms * 1e-3) / 1e9
+        line = {"kernel": KERNEL_NAME[k], "work_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                "hbm_GBs": round(ach, 2), "hbm_frac": ach / HBM_PEAK_GBS}
+        if k == "inter":
+            ops = SAD_OPS_PER_MB * mb_per_launch / (ms * 1e-3)
+            line["true_bound"] = {"kind": "valu: byte-SAD issue rate", "achieved_Tops": round(ops / 1e12, 2),
+                                  "peak_Tops": round(SAD_PEAK_OPS / 1e12, 1), "frac": ops / SAD_PEAK_OPS}
+        elif k in ("deblock", "intra_recon"):
+            mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
+            nsteps = mb_w + (mb_h - 1) * (1 if k == "deblock" else 2)
+            line["true_bound"] = {"kind": "dependency latency: anti-diagonal wavefront", "wavefront_steps": nsteps,
+                                  "us_per_step": round(ms * 1e3 / nsteps, 3)}
+        else:
+            line["true_bound"] = {"kind": "hbm (latency at this size)", "frac": ach / HBM_PEAK_GBS}
+        return line
+
+    dom = kernel_line(stage, wms)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            key = "%s@%dx%dx%d" % (tkey, W, H, S)
-            traffic = tj.get(key)
+            traffic = json.load(open(tpath)).get("%s@%dx%dx%d" % (stage, W, H, S))
         except Exception:  # noqa: BLE001
             traffic = None
-    n_i = sum(1 for i in range(args.warmup, args.warmup + args.steps) if i % args.keyint == 0)
+    first = st["first_frame"]
+    n_i = sum(1 for i in range(first, first + args.steps) if i % K == 0)
     pipe_bytes = (n_i * PIPELINE_BYTES_PER_MB["I"] + (args.steps - n_i) * PIPELINE_BYTES_PER_MB["P"]) \
-        * S * mbs_per_frame * world + nbytes_all
+        * total_mbs / args.steps + nbytes_all
     roofline = {
-        "bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["hbm_GBs"], "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": dom["hbm_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+        "work_ms": dom["work_ms"], "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+        "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+        "true_bound": dom["true_bound"],
         "wf_split": st.get("wf_split"),
         "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams")},
-        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-        "algorithmic_bytes_per_launch": int(alg_bytes),
         "pipeline_achieved_GBs": round(pipe_bytes / dt_max / 1e9, 3),
         "pipeline_frac": pipe_bytes / dt_max / 1e9 / HBM_PEAK_GBS,
-        # every stage, from the warm-up frames; the dominant stage above is timed inside the timed region
-        "stage_ms_per_launch_warmup": ({k: round(st["warmup"]["ms"][k] / max(1, st["warmup"]["launches"][k]), 4)
-                                        for k in st["warmup"]["ms"]} if st.get("warmup") else None),
+        # every stage with frames back to back (duration = work), against its own bound
+        "kernels": [kernel_line(k, v) for k, v in (work_ms or {}).items() if v > 0],
+        # every stage as launched in the measured (pipelined) session, from its warm-up frames
+        "stage_ms_per_launch_pipelined": ({k: round(st["warmup"]["ms"][k] / max(1, st["warmup"]["launches"][k]), 4)
+                                           for k in st["warmup"]["ms"]} if st.get("warmup") else None),
     }
 
     # ---- CPU baseline: the scalar C oracle on a bounded sample (rank 0, N=1 only) ----
@@ -264,20 +372,22 @@ def run_rank(args, rank, world, local_rank):
     bitexact = None
     if world == 1 and args.cpu_frames > 0:
         from tests import oracle_lib as ol
-        oe = ol.OracleEncoder(ol.default_config(W, H, qp=args.qp, keyint=args.keyint))
+        oe = ol.OracleEncoder(ol.default_config(W, H, qp=args.qp, keyint=K))
         frames = [ce.gen_pattern("B", W, H, f, 0) for f in range(args.cpu_frames)]
         t0 = time.perf_counter()
         cpu_aus = [oe.encode(y, uv) for y, uv in frames]
         cdt = time.perf_counter() - t0
         n_cmp = min(len(cpu_aus), len(first_aus))
-        bitexact = n_cmp > 0 and all(cpu_aus[i] == first_aus[i] for i in range(n_cmp))
+        bitexact = n_cmp == args.cpu_frames and all(cpu_aus[i] == first_aus[i] for i in range(n_cmp))
         cpu = {"value": args.cpu_frames * mbs_per_frame / cdt, "unit": "macroblocks/s", "cores": 1,
                "kind": "port",
                "sample": "%d frames %dx%d pattern-B (1 IDR + %d P), QP %d, single thread, gcc -O2" % (
                    args.cpu_frames, W, H, args.cpu_frames - 1, args.qp),
                "seconds": round(cdt, 2),
-               "fnv_sha": hashlib.sha1(b"".join(cpu_aus)).hexdigest()[:16],
-               "gpu_sha": hashlib.sha1(b"".join(first_aus[:n_cmp])).hexdigest()[:16]}
+               # the SAME access units on both sides: the first cpu_frames of stream 0
+               "access_units_compared": n_cmp,
+               "sha1_cpu": hashlib.sha1(b"".join(cpu_aus[:n_cmp])).hexdigest()[:16],
+               "sha1_gpu": hashlib.sha1(b"".join(first_aus[:n_cmp])).hexdigest()[:16]}
         # (ii) of SURVEY 8(d): the host cores of a one-GPU box, one independent stream per core: N
         # processes of the scalar command line (oracle/build/h264enc_scalar) on the same sample
         # (threads in this process would share one address space and contend on page faults)
@@ -294,7 +404,7 @@ def run_rank(args, rank, world, local_rank):
                 for y, uv in frames[:nfr]:
                     fh.write(y.tobytes())
                     fh.write(uv.tobytes())
-            env = dict(os.environ, H264ENC_QP=str(args.qp), H264ENC_KEYINT=str(args.keyint))
+            env = dict(os.environ, H264ENC_QP=str(args.qp), H264ENC_KEYINT=str(K))
             t0 = time.perf_counter()
             procs = [subprocess.Popen([scalar, src, str(W), str(H), os.path.join(td, "o%d.264" % i)],
                                       stdout=subprocess.DEVNULL, env=env) for i in range(ncores)]
@@ -308,8 +418,16 @@ def run_rank(args, rank, world, local_rank):
                             "sample": "%d processes x %d frames of the same sample, one per core" % (ncores, nfr),
                             "seconds": round(mdt, 2)}
 
+    if args.slices_across_gpus:
+        workload = ("%dx%d nv12 I+P keyint %d QP %d, pattern-B, ONE picture in %d slices, slice k on GPU k "
+                    "(BASELINE configs[3]; no collective, the host concatenates the slice NALs)" % (W, H, K, args.qp, world))
+        par = "slices x%d of one picture, no collective" % world
+    else:
+        workload = ("%dx%d nv12 I+P keyint %d QP %d, pattern-B, %d stream(s) per GPU "
+                    "(BASELINE configs[2]; N GPUs = independent streams, configs[4])" % (W, H, K, args.qp, S))
+        par = "streams x%d, no collective" % world
     out = {
-        "metric": "macroblocks/s @ fixed QP, 1080p nv12",
+        "metric": "macroblocks/s @ fixed QP, 1080p nv12" if (W, H) == (1920, 1080) else "macroblocks/s @ fixed QP, %dx%d nv12" % (W, H),
         "value": value,
         "unit": "macroblocks/s",
         "n_gpus": world,
@@ -317,20 +435,23 @@ def run_rank(args, rank, world, local_rank):
         "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.slices_across_gpus else "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "%dx%d nv12 I+P keyint %d QP %d, pattern-B, %d stream(s) per GPU "
-                               "(BASELINE configs[2]; N GPUs = independent streams, configs[4])" % (
-                                   W, H, args.keyint, args.qp, S),
+        "config": {"workload": workload,
                    "streams_per_gpu": S, "macroblocks_per_frame": mbs_per_frame,
-                   "parallelism": "streams x%d, no collective" % world,
+                   "parallelism": par,
+                   "timed_region": {"first_frame": first, "alignment_frames_before_warmup": first - args.warmup,
+                                    "idr_pictures": n_i, "p_pictures": args.steps - n_i},
+                   "idr_in_timed_region": n_i,
+                   "slices_concatenate_to_one_session_stream": slices_equal,
                    "realtime_4k30_multiple": value / 972000.0,
                    "bitstream_bytes_per_step": nbytes_all / args.steps},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "bitexact_vs_cpu": bitexact,
+        "gop_parallel": gop_par,
         "batched": batched,
     }
     return out

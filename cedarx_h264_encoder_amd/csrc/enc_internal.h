@@ -97,7 +97,7 @@ struct Params {
 	uint32_t *nal_size;              // [n_units]
 	uint32_t *stream_size;           // [n_streams + 3] bytes per stream; [n] total; [n+1] error flags; [n+2] units scanned (k_esc_scan)
 	uint8_t *out;                    // compact output: all streams back to back
-	const SliceHdr *hdr;             // [n_units] (identical across streams per slice)
+	const SliceHdr *hdr;             // [n_units] (streams differ where they are GOP lanes: idr_pic_id)
 	const uint32_t *prefix_len;      // [n_streams] bytes reserved in front (SPS+PPS)
 	const uint8_t *pred4_tab;        // [9][16] intra 4x4 predictor table
 	// wavefront kernels split over wf_split workgroups (CUs) per unit: ticket,

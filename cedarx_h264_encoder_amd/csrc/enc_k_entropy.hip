@@ -761,7 +761,7 @@ __global__ __launch_bounds__(1024) void k_scan(Params p)
 	const bool is_p = !p.is_idr;
 	if (threadIdx.x == 0) {
 		s_carry_max = -1;
-		s_carry_sum = p.hdr[ls].nbits;
+		s_carry_sum = p.hdr[unit].nbits;
 	}
 	__syncthreads();
 	for (int base = 0; base <= n; base += 1024) {
@@ -853,8 +853,8 @@ __global__ __launch_bounds__(256) void k_pack(Params p)
 	const uint32_t *run = p.run_before + (size_t)unit * (p.unit_mb_cap + 2);
 	const bool is_p = !p.is_idr;
 	if (t == 0) {
-		const uint64_t hb = p.hdr[ls].bits;
-		const int hn = p.hdr[ls].nbits;
+		const uint64_t hb = p.hdr[unit].bits;
+		const int hn = p.hdr[unit].nbits;
 		if (hn > 32) {
 			or_bits(w, capw, 0, (uint32_t)(hb >> 32), hn - 32);
 			or_bits(w, capw, (uint32_t)(hn - 32), (uint32_t)hb, 32);

@@ -44,12 +44,16 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 {
 	const int segs = p.cw >> 4;
 	const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-	const int row = blockIdx.y; // [0, ch) luma, [ch, ch + ch/2) chroma
+	// only the macroblock rows this session codes (a slice session on one of several GPUs reads
+	// nothing outside its band: intra prediction and the motion search stop at the slice)
+	const int band_y = 16 * p.row_num;
+	const int row = (int)blockIdx.y < band_y ? 16 * p.row_first + (int)blockIdx.y
+						 : p.ch + 8 * p.row_first + ((int)blockIdx.y - band_y); // [0, ch) luma, [ch, ch + ch/2) chroma
 	const int st = blockIdx.z;
 	// first job of every frame on this stream: the ticket / abort / progress words of the intra
 	// wavefront kernel (region 0) start at zero; the deblock regions are cleared on the deblock
 	// kernel's own stream
-	if (row == 0 && st == 0 && p.wf_split_intra > 1) {
+	if (blockIdx.y == 0 && st == 0 && p.wf_split_intra > 1) {
 		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
 		for (int i = seg; i < used; i += gridDim.x * blockDim.x)
 			p.wf_sync[i] = 0;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 
 int Launch::input(const Params &p, void *stream)
 {
-	dim3 grid((p.cw / 16 + 255) / 256, p.ch + p.ch / 2, p.n_streams);
+	dim3 grid((p.cw / 16 + 255) / 256, 24 * p.row_num, p.n_streams);
 	hipLaunchKernelGGL(k_input, grid, dim3(256), 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }

@@ -33,6 +33,8 @@ namespace {
 // one behind polling kernels of the other on shared hardware queues and wait for each other
 // until the spin bounds. Further sessions run their frames back to back.
 std::atomic<int> g_pipelined_sessions[64];
+const bool g_shared_main_probe = getenv("CEDAR_SHARE_MAIN") != nullptr;
+hipStream_t g_shared_main = nullptr;
 
 constexpr int DB_STREAMS = 3;
 constexpr int AN_STREAMS = 3;
@@ -135,11 +137,25 @@ struct Timing {
 	bool used[CEDAR_ENC_STAGE_COUNT];
 };
 
+// What cedar.c:1193-1201 advances after a frame that worked. A frame in flight keeps the values from
+// before its submit: a failed collect puts them back (cedar.c:1182-1191 returns before the update).
+struct GopState {
+	int frame_count = 0, frame_p_count = 0, cur = 0, prev_slot = -1, prev2_slot = -1;
+	unsigned idr_count = 0;
+};
+
 struct InFlight {
 	bool active = false;
 	bool idr = false;
 	int host_out = 0;      // which host output buffer receives this frame
-	bool with_ps = false;  // SPS+PPS precede this frame's slices
+	std::vector<uint8_t> with_ps; // [n_streams] SPS+PPS precede this frame's slices
+	GopState before;       // the session's GOP / reference state when this frame was submitted
+	// where k_input found every stream of this frame ([2*n_streams]: luma, then chroma) and whether
+	// that was the session's own device copy of the pinned input buffers: what a replay needs
+	std::vector<const uint8_t *> in_used;
+	std::vector<uint8_t> in_own;
+	std::vector<long> lane_gidx; // [n_streams] global frame index per lock-step lane (-1: idle lane)
+	bool gop_start = false;      // gop_parallel: every lane starts a GOP with this step, whatever the counter says
 	int lane = 0;          // entropy lane
 	hipStream_t s_db = nullptr, s_ent = nullptr; // the streams that carry this frame's deblocking / entropy coding
 	bool events = true;    // done_main / done_ent were recorded (frames not pipelined)
@@ -159,6 +175,24 @@ struct InFlight {
 	Timing tm;
 };
 
+// gop_parallel = G: the caller's S streams are encoded as S x G lock-step lanes, lane (s, g) taking
+// every G-th closed GOP of stream s. Frames arrive and leave in stream order; in between they sit
+// in a ring (device frames for the input, host bytes for the output). Lock-step step q encodes
+// position t = q % K of the G GOPs of group q / K, i.e. user frame ((q / K) * G + g) * K + t on lane g.
+struct GopMux {
+	int G = 1, K = 1, S = 1;          // lanes per stream, GOP length, the caller's streams
+	int cap = 0;                      // frames the rings hold
+	long n_sub = 0, n_col = 0;        // user frames submitted / collected
+	long q_sub = 0, q_col = 0;        // lock-step steps submitted / collected
+	bool flushed = false;
+	std::vector<const uint8_t *> in_ring;        // [cap][2 * S] device frame of every stream: luma, chroma
+	uint8_t *d_store_y = nullptr, *d_store_uv = nullptr; // [cap][S] device copies of frames that came in the pinned buffers
+	std::vector<std::vector<uint8_t>> out_ring;  // [cap][S] access units
+	std::vector<int> out_rc;                     // [cap] bytes of the frame (all streams) or -errno
+	std::vector<const uint8_t *> user_in;        // [2 * S] what cedar_enc_set_device_input gave (nullptr: pinned buffers)
+	long last = -1;                              // frame the last collect delivered
+};
+
 } // namespace
 
 struct cedar_enc {
@@ -167,8 +201,18 @@ struct cedar_enc {
 	struct cedar_enc_config cfg{};
 	struct cedar_enc_config_ext ext{};
 	Params P{};
+	GopMux *mux = nullptr;   // gop_parallel sessions
+	int S_user = 1;          // the caller's streams (ext.n_streams counts lock-step lanes)
 	// GOP state (cedar.c:93-95)
 	int frame_count = 0, frame_p_count = 0;
+	// submits ever made: completion and progress tags derive from it, NOT from frame_count, which a
+	// failed frame rolls back -- a retried frame must not find the tags of the failed attempt
+	uint32_t submit_seq = 0;
+	uint32_t slot_tag[CEDAR_ENC_PIPELINE_DEPTH] = {}; // progress tag of the frame that used a device slot last
+	std::vector<long> lane_gidx; // [n_streams] global frame index of the next frame, per lane (mux sessions set it per step)
+	bool next_gop_start = false; // gop_parallel: the next submit starts a GOP on every lane
+	uint32_t fault_at = 0;       // tests (CEDAR_FAULT_INJECT_AT)
+	bool owns_main = true;       // s_main is this session's to destroy
 	int cur = 0; // reconstruction buffer being written (cedar.c:117-119)
 	int depth = 4;  // frames in flight this session allows (<= CEDAR_ENC_PIPELINE_DEPTH) = device slots
 	int nrec = 5;   // reconstruction buffers (depth + 1)
@@ -300,6 +344,11 @@ void free_all(cedar_enc *e)
 		F(e->d_rbsp[l]); F(e->d_esc[l]); F(e->d_nal_off[l]); F(e->d_nal_size[l]); F(e->d_stream_size[l]);
 	}
 	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab);
+	if (e->mux) {
+		F(e->mux->d_store_y); F(e->mux->d_store_uv);
+		delete e->mux;
+		e->mux = nullptr;
+	}
 	H(e->h_luma); H(e->h_chroma);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_wf_err); H((void *)e->fl[i].h_done);
@@ -317,7 +366,7 @@ void free_all(cedar_enc *e)
 	}
 	if (e->ev_host_in) hipEventDestroy(e->ev_host_in);
 	if (e->ev_base) hipEventDestroy(e->ev_base);
-	if (e->s_main) hipStreamDestroy(e->s_main);
+	if (e->s_main && e->owns_main) hipStreamDestroy(e->s_main);
 	for (int i = 1; i < AN_STREAMS; i++)
 		if (e->s_ana[i]) hipStreamDestroy(e->s_ana[i]);
 	if (e->s_ent) hipStreamDestroy(e->s_ent);
@@ -657,6 +706,8 @@ extern "C" int cedar_enc_config(cedar_enc *e, struct cedar_enc_config *cfg)
 	return cedar_enc_config_ext(e, cfg, nullptr);
 }
 
+static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in);
+
 extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
 {
 	if (!e)
@@ -665,6 +716,24 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		return fail(e, -EINVAL, "NULL config");
 	if (e->configured) // cedar.c:744-747
 		return fail(e, -EINVAL, "already configured");
+	const int rc = config_impl(e, cfg, ext_in);
+	if (rc) {
+		// a CONFIG that failed half way leaves nothing behind (cedar.c:834-836 frees what
+		// cedar_buffers_init had got): the session is as freshly opened and may be configured again
+		char msg[sizeof(e->err)];
+		memcpy(msg, e->err, sizeof(msg));
+		hipDeviceSynchronize();
+		if (e->holds_pipe_token)
+			g_pipelined_sessions[e->device & 63].fetch_sub(1);
+		free_all(e);
+		*e = cedar_enc();
+		memcpy(e->err, msg, sizeof(msg));
+	}
+	return rc;
+}
+
+static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
+{
 	struct cedar_enc_config_ext ext{};
 	if (ext_in) {
 		if (ext_in->size != (int)sizeof(struct cedar_enc_config_ext))
@@ -672,6 +741,11 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		ext = *ext_in;
 	}
 	if (ext.n_streams == 0) ext.n_streams = 1;
+	if (ext.gop_parallel < 0 || ext.gop_parallel > MAX_UNITS || ext.n_streams < 1 || ext.n_streams > MAX_UNITS)
+		return fail(e, -EINVAL, "bad stream/slice layout");
+	// the caller's streams x GOP lanes = the lock-step "streams" everything below batches
+	const int S_user = ext.n_streams, G = ext.gop_parallel > 1 ? ext.gop_parallel : 1;
+	ext.n_streams = S_user * G;
 	if (ext.slice_count == 0) ext.slice_count = 1;
 	if (ext.slice_num == 0) { ext.slice_first = 0; ext.slice_num = ext.slice_count; }
 	ext.search_range = ext.search_range == 0 ? 16 : ext.search_range < 0 ? 0 : ext.search_range;
@@ -708,6 +782,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		return fail(e, -EINVAL, "aud must be 0 or 1");
 	if (mb_h > 512 * ext.slice_count)
 		return fail(e, -EINVAL, "picture too tall for one slice");
+	if (ext.first_frame_index < 0 || ext.first_frame_index % cfg->keyframe_interval)
+		return fail(e, -EINVAL, "first_frame_index %d is not the start of a GOP (keyframe interval %d)", ext.first_frame_index,
+			    cfg->keyframe_interval);
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ext.device < 0 || ext.device >= ndev)
 		return fail(e, -ENODEV, "HIP device %d not available", ext.device);
@@ -748,8 +825,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	if (e->out_cap > 0x7fffffffULL)
 		return fail(e, -EINVAL, "too many streams for one session");
 	int rc = 0;
-	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S, hipHostMallocDefault));
-	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S, hipHostMallocDefault));
+	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S_user, hipHostMallocDefault));
+	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S_user, hipHostMallocDefault));
 	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
@@ -757,7 +834,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_sizes[i], e->h_sizes[i], 0));
 	}
 	for (int i = 0; i < e->depth; i++) {
-		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * ext.slice_num, hipHostMallocMapped));
+		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_hdr, sizeof(SliceHdr) * n_units, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_hdr, e->fl[i].h_hdr, 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_prefix, e->fl[i].h_prefix, 0));
@@ -771,8 +848,9 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
 	P.plane_y_stride = (int64_t)plane_y;
 	P.plane_uv_stride = (int64_t)plane_uv;
-	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S * e->depth))) return rc;
-	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S * e->depth))) return rc;
+	// (GOP lanes take their frames from the mux's ring, never from these per-slot copies)
+	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S * (G > 1 ? 1 : e->depth)))) return rc;
+	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S * (G > 1 ? 1 : e->depth)))) return rc;
 	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S * e->depth))) return rc;
 	for (int i = 0; i < e->nrec; i++) {
 		if ((rc = dalloc(e, &e->d_rec_y[i], plane_y * S))) return rc;
@@ -874,7 +952,12 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	for (bool &v : e->in_tab_valid)
 		v = false;
 
-	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+	if (g_shared_main_probe && !g_shared_main) // experiment (CEDAR_SHARE_MAIN): the sessions of a process share one analysis stream
+		HIP_TRY(e, hipStreamCreateWithFlags(&g_shared_main, hipStreamNonBlocking));
+	if (g_shared_main_probe)
+		e->s_main = g_shared_main, e->owns_main = false;
+	else
+		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
 	e->s_ana[0] = e->s_main;
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
 	for (int i = 0; i < DB_STREAMS; i++)
@@ -1098,6 +1181,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	{
 		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO
 		P.fault_inject = env ? atoi(env) : 0;
+		env = getenv("CEDAR_FAULT_INJECT_AT"); // ... of the n-th submit only (1-based; default: of every frame)
+		e->fault_at = env ? (uint32_t)atoi(env) : 0;
 	}
 
 	build_sps_pps(e);
@@ -1105,6 +1190,22 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	e->frame_p_count = 0;
 	e->res_off.assign(S, 0);
 	e->res_size.assign(S, 0);
+	e->lane_gidx.assign(S, 0);
+	e->S_user = S_user;
+	if (G > 1) {
+		GopMux *m = new (std::nothrow) GopMux();
+		if (!m)
+			return fail(e, -ENOMEM, "out of memory");
+		e->mux = m;
+		m->G = G;
+		m->K = cfg->keyframe_interval;
+		m->S = S_user;
+		m->cap = G * m->K + e->depth + 1;
+		m->in_ring.assign((size_t)m->cap * 2 * S_user, nullptr);
+		m->out_ring.resize((size_t)m->cap * S_user);
+		m->out_rc.assign((size_t)m->cap, INT32_MIN);
+		m->user_in.assign((size_t)2 * S_user, nullptr);
+	}
 	e->configured = true;
 
 	// outputs (cedar.c:840-860), host pointers instead of DMA addresses
@@ -1125,8 +1226,14 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 
 extern "C" int cedar_enc_set_device_input(cedar_enc *e, int stream, const void *d_luma, const void *d_chroma)
 {
-	if (!e || !e->configured || stream < 0 || stream >= e->ext.n_streams)
+	if (!e || !e->configured || stream < 0 || stream >= e->S_user)
 		return -EINVAL;
+	if (e->mux) { // the frame is filed under its index at submit; lanes get their pointers per step
+		const bool dev = d_luma && d_chroma;
+		e->mux->user_in[stream] = dev ? (const uint8_t *)d_luma : nullptr;
+		e->mux->user_in[e->S_user + stream] = dev ? (const uint8_t *)d_chroma : nullptr;
+		return 0;
+	}
 	const int S = e->ext.n_streams;
 	if (d_luma && d_chroma) {
 		e->h_in_ptrs[stream] = (const uint8_t *)d_luma;
@@ -1160,15 +1267,22 @@ extern "C" int cedar_enc_pipeline_depth(void)
 
 extern "C" int cedar_enc_session_depth(const cedar_enc *e)
 {
-	return e && e->configured ? e->depth : -EINVAL;
+	if (!e || !e->configured)
+		return -EINVAL;
+	// gop_parallel: frame n needs frame n + (G-1)*K submitted before it can be delivered
+	return e->mux ? (e->mux->G - 1) * e->mux->K + e->depth : e->depth;
 }
 
-extern "C" int cedar_enc_submit(cedar_enc *e)
+// The inputs of a frame that is encoded again after a frame before it failed (see recover()).
+struct ReplayIn {
+	std::vector<const uint8_t *> in;
+	std::vector<uint8_t> own;
+	std::vector<long> gidx;
+	bool gop_start;
+};
+
+static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 {
-	if (!e)
-		return -EINVAL;
-	if (!e->configured) // cedar.c:1039-1043
-		return fail(e, -EINVAL, "CONFIG not run yet");
 	if (e->fl_count >= e->depth)
 		return fail(e, -EBUSY, "pipeline full: collect first");
 	const double t0 = now_ms();
@@ -1179,15 +1293,23 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	const int slot = (e->fl_head + e->fl_count) % e->depth;
 	InFlight &f = e->fl[slot];
 	memset(f.tm.used, 0, sizeof(f.tm.used));
+	f.gop_start = replay ? replay->gop_start : e->next_gop_start;
+	e->next_gop_start = false;
+	if (f.gop_start) // a group of GOP lanes begins: also when a failed step left the group before it a frame short
+		e->frame_p_count = 0;
+	f.before = GopState{ e->frame_count, e->frame_p_count, e->cur, e->prev_slot, e->prev2_slot, e->idr_count };
 	// frames in flight were submitted in order, so counters advance at submit
 	const bool idr = e->frame_p_count == 0; // cedar.c:1047-1050
 	// Device-side per-frame state rotates with the frame number (never the slot of the frame
 	// before, even when the ring of frames in flight restarts at 0)
 	const int ds = e->frame_count % e->depth;
 	f.ds = ds;
-	f.done_tag = (uint32_t)e->frame_count + 1u;
+	const uint32_t seq = ++e->submit_seq;
+	f.done_tag = seq;
 	Params P = e->P;
 	P.is_idr = idr;
+	if (e->fault_at && seq != e->fault_at) // tests: lose the hand-off of one chosen submit only
+		P.fault_inject = 0;
 	P.rec_y = e->d_rec_y[e->cur];
 	P.rec_uv = e->d_rec_uv[e->cur];
 	const int ref = (e->cur + e->nrec - 1) % e->nrec;
@@ -1210,8 +1332,9 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		P.prog_db = e->d_prog[ds] + 16;
 		P.prog_intra = e->d_prog[ds] + 16 + 2 * (size_t)S * e->ext.slice_num * PROG_BANDS;
 		P.prev_db = prev >= 0 ? e->d_prog[prev] + 16 : nullptr;
-		P.prog_tag = (uint32_t)(e->frame_count + 1) << 16;
-		P.prev_tag = (uint32_t)e->frame_count << 16;
+		P.prog_tag = seq << 16;
+		P.prev_tag = prev >= 0 ? e->slot_tag[prev] : 0;
+		e->slot_tag[ds] = P.prog_tag;
 	}
 	// Which streams carry this frame. With look-ahead an IDR picture has streams of its own and
 	// waits for nothing but its input: it runs beside the P pictures submitted before it.
@@ -1230,26 +1353,48 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
 	bool any_host = false;
 	const size_t in_y_slot = (size_t)ds * e->cfg.input_luma_size * S, in_uv_slot = (size_t)ds * e->cfg.input_chroma_size * S;
+	f.in_own.assign((size_t)S, 0);
 	for (int s = 0; s < S; s++) {
 		// a stream without a device frame of its own points at the session's device copy (slot 0 is the mark)
 		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
-		if (e->h_in_ptrs[s] == own) {
-			any_host = true;
-			HIP_TRY(e, hipMemcpyAsync(e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size,
-						  e->h_luma + (size_t)s * e->cfg.input_luma_size,
-						  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_in));
-			HIP_TRY(e, hipMemcpyAsync(e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size,
-						  e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
-						  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_in));
+		f.in_own[s] = replay ? replay->own[s] : (uint8_t)(e->h_in_ptrs[s] == own);
+		if (!f.in_own[s])
+			continue;
+		uint8_t *dy = e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
+		uint8_t *duv = e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size;
+		if (replay) {
+			// the frame's data sits in the device copy of the slot it was first submitted to: move it to
+			// this slot's, so that "a frame in flight owns the copy of its slot" holds again
+			if (replay->in[s] != dy) {
+				HIP_TRY(e, hipMemcpyAsync(dy, replay->in[s], (size_t)P.width * P.height, hipMemcpyDeviceToDevice, s_in));
+				HIP_TRY(e, hipMemcpyAsync(duv, replay->in[S + s], (size_t)P.width * P.height / 2, hipMemcpyDeviceToDevice, s_in));
+			}
+			continue;
 		}
+		any_host = true;
+		HIP_TRY(e, hipMemcpyAsync(dy, e->h_luma + (size_t)s * e->cfg.input_luma_size,
+					  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_in));
+		HIP_TRY(e, hipMemcpyAsync(duv, e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
+					  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_in));
 	}
 	auto in_ptr = [&](int s, bool chroma) -> const uint8_t * { // where k_input finds stream s of this frame
-		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
-		if (e->h_in_ptrs[s] != own)
-			return e->h_in_ptrs[(chroma ? S : 0) + s];
+		if (!f.in_own[s])
+			return replay ? replay->in[(chroma ? S : 0) + s] : e->h_in_ptrs[(chroma ? S : 0) + s];
 		return chroma ? e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size
 			      : e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
 	};
+	f.in_used.resize((size_t)2 * S);
+	for (int s = 0; s < S; s++) {
+		f.in_used[s] = in_ptr(s, false);
+		f.in_used[S + s] = in_ptr(s, true);
+	}
+	// (a plain session counts its frames itself, replayed or not; GOP lanes keep the frame they were given)
+	if (!e->mux)
+		f.lane_gidx.assign((size_t)S, (long)e->ext.first_frame_index + e->frame_count);
+	else
+		f.lane_gidx = replay ? replay->gidx : e->lane_gidx;
+	if (replay)
+		e->in_tab_valid[ds] = false; // the table of this slot, if any, describes another frame
 	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
 		P.in_luma = P.in_chroma = nullptr;
 		for (int s = 0; s < S; s++) {
@@ -1267,7 +1412,7 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 		}
 		HIP_TRY(e, hipMemcpyAsync((void *)(e->d_in_ptrs + (size_t)ds * 2 * S), t.data(), sizeof(void *) * 2 * S,
 					  hipMemcpyHostToDevice, s_in));
-		e->in_tab_valid[ds] = true;
+		e->in_tab_valid[ds] = !replay;
 	}
 	if (S > IN_K_STREAMS) {
 		P.in_luma = (const uint8_t *const *)(e->d_in_ptrs + (size_t)ds * 2 * S);
@@ -1375,17 +1520,23 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	const double t_main = now_ms();
 
 	// ---- entropy coding on its own stream, concurrent with deblocking ----
-	const int idr_pic_id = (e->frame_count / e->cfg.keyframe_interval) & 1;
-	for (int k = 0; k < e->ext.slice_num; k++) {
-		int r0, r1;
-		slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
-		f.h_hdr[k] = build_slice_header(e, idr, e->frame_p_count, idr_pic_id, r0 * P.mb_w);
-	}
-	const bool with_ps = (e->frame_count == 0 || (idr && e->ext.repeat_headers)) && e->ext.slice_first == 0; // cedar.c:1058-1061
-	f.with_ps = with_ps;
+	// Headers per lane: idr_pic_id and "parameter sets in front of frame 0" follow the GLOBAL frame
+	// index (the reference counts the frames of its one device, cedar.c:1001, :1058-1061; a shard or a
+	// GOP lane starts somewhere in the stream). frame_num restarts with every IDR picture (cedar.c:1001).
 	f.aud = e->ext.aud && e->ext.slice_first == 0 ? (idr ? 1 : 2) : 0; // the first slice's session opens the access unit
-	for (int s = 0; s < S; s++)
-		f.h_prefix[s] = (with_ps ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
+	f.with_ps.assign((size_t)S, 0);
+	for (int s = 0; s < S; s++) {
+		const long gidx = f.lane_gidx[s] < 0 ? 0 : f.lane_gidx[s];
+		const long gop = gidx / e->cfg.keyframe_interval;
+		for (int k = 0; k < e->ext.slice_num; k++) {
+			int r0, r1;
+			slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
+			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, (int)(gop & 1), r0 * P.mb_w);
+		}
+		// cedar.c:1058-1061: SPS + PPS in front of the stream's first picture (the IDR picture of GOP 0)
+		f.with_ps[s] = idr && (gop == 0 || e->ext.repeat_headers) && e->ext.slice_first == 0;
+		f.h_prefix[s] = (f.with_ps[s] ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
+	}
 	// entropy lanes: frames alternate between two streams with scratch buffers of their own
 	const int lane = e->ent_lanes > 1 && e->s_ent2 ? e->frame_count % e->ent_lanes : 0;
 	hipStream_t s_ent = lane ? e->s_ent2 : e->s_ent;
@@ -1456,10 +1607,49 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	return 0;
 }
 
-extern "C" int cedar_enc_collect(cedar_enc *e)
+// A frame failed (cedar.c:1182-1191: time-out or bad status -> -1 before the GOP counter and the
+// reference swap, :1193-1201). The reference's caller then goes on with the next frame
+// (h264enc.c:189-192). With frames in flight "the next frame" has already been submitted on top
+// of the broken one: drain the device, put the GOP / reference state back to what it was before
+// the failed frame, and encode the frames behind it again from the inputs the session still holds.
+static int recover(cedar_enc *e, const InFlight &failed)
 {
-	if (!e || !e->configured)
-		return -EINVAL;
+	hipDeviceSynchronize();
+	std::vector<ReplayIn> later;
+	for (int k = 0; k < e->fl_count; k++) {
+		InFlight &g = e->fl[(e->fl_head + k) % e->depth];
+		later.push_back(ReplayIn{ g.in_used, g.in_own, g.lane_gidx, g.gop_start });
+		g.active = false;
+	}
+	const GopState &b = failed.before;
+	e->frame_count = b.frame_count;
+	e->frame_p_count = b.frame_p_count;
+	e->cur = b.cur;
+	e->prev_slot = b.prev_slot;
+	e->prev2_slot = b.prev2_slot;
+	e->idr_count = b.idr_count;
+	e->fl_count = 0;
+	e->fl_head = 0;
+	// tickets, abort flags and hand-off progress of the wavefront kernels; the size / error words of
+	// the entropy lanes (a kernel that gave up leaves them as they were)
+	const int n_units = e->ext.n_streams * e->ext.slice_num;
+	(void)n_units;
+	for (int i = 0; i < e->depth; i++) {
+		HIP_TRY(e, hipMemset(e->d_wf_sync[i], 0, sizeof(uint32_t) * 3 * WF_SYNC_WORDS));
+		*e->fl[i].h_wf_err = 0;
+	}
+	for (int l = 0; l < e->ent_lanes; l++)
+		HIP_TRY(e, hipMemset(e->d_stream_size[l], 0, sizeof(uint32_t) * (e->ext.n_streams + 4)));
+	for (const ReplayIn &r : later) {
+		const int rc = submit_frame(e, &r);
+		if (rc)
+			return rc;
+	}
+	return 0;
+}
+
+static int collect_frame(cedar_enc *e)
+{
 	if (e->fl_count == 0)
 		return fail(e, -EINVAL, "nothing in flight");
 	const double t0 = now_ms();
@@ -1467,6 +1657,7 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	const int slot = e->fl_head;
 	InFlight &f = e->fl[slot];
 	HIP_TRY(e, hipSetDevice(e->device));
+	bool hip_failed = false;
 	{
 		// poll the frame's own completion flags (see InFlight::h_done); fall back to the events
 		// if they do not show up (they are written after everything the events cover)
@@ -1481,8 +1672,9 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 		}
 		if (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
 			// (pipelined frames record no events: their streams are kept to the fewest packets)
-			HIP_TRY(e, f.events ? hipEventSynchronize(f.done_ent) : hipStreamSynchronize(f.s_ent));
-			HIP_TRY(e, f.events ? hipEventSynchronize(f.done_main) : hipStreamSynchronize(f.s_db));
+			hipError_t r1 = f.events ? hipEventSynchronize(f.done_ent) : hipStreamSynchronize(f.s_ent);
+			hipError_t r2 = f.events ? hipEventSynchronize(f.done_main) : hipStreamSynchronize(f.s_db);
+			hip_failed = r1 != hipSuccess || r2 != hipSuccess;
 		}
 		std::atomic_thread_fence(std::memory_order_acquire);
 	}
@@ -1491,10 +1683,18 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	f.active = false;
 	const uint32_t *sz = e->h_sizes[slot];
 	const uint32_t total = sz[S], flags = sz[S + 1];
-	if (*f.h_wf_err)
-		return fail(e, -EIO, "wavefront hand-off timed out (flags %u)", *f.h_wf_err);
-	if (flags || total > e->out_cap)
+	const uint32_t wf_err = *f.h_wf_err;
+	if (hip_failed || wf_err || flags || total > e->out_cap) {
+		// this frame is dropped, the session is where it was before it, the frames behind it run again
+		const int rc = recover(e, f);
+		if (rc)
+			return rc;
+		if (hip_failed)
+			return fail(e, -EIO, "the device reported an error for this frame");
+		if (wf_err)
+			return fail(e, -EIO, "wavefront hand-off timed out (flags %u)", wf_err);
 		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
+	}
 	uint32_t off = 0;
 	for (int s = 0; s < S; s++) {
 		e->res_off[s] = off;
@@ -1505,7 +1705,7 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 			memcpy(front, a.data(), a.size());
 			front += a.size();
 		}
-		if (f.with_ps)
+		if (f.with_ps[s])
 			memcpy(front, e->sps_pps.data(), e->sps_pps.size());
 		off += sz[s];
 	}
@@ -1535,32 +1735,201 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	return (int)total; // cedar.c:1207-1208: bytes now valid at bytestream offset 0
 }
 
+// ---- gop_parallel: S streams x G closed GOPs side by side (see GopMux) ----
+
+static long mux_frame_of(const GopMux &m, long q, int g) { return ((q / m.K) * m.G + g) * m.K + q % m.K; }
+static long mux_step_of(const GopMux &m, long n) { return (n / m.K / m.G) * m.K + n % m.K; }
+
+// submit lock-step steps while their frames are there and the session has room
+static int mux_pump(cedar_enc *e)
+{
+	GopMux &m = *e->mux;
+	while (e->fl_count < e->depth) {
+		const long q = m.q_sub;
+		// the step's last lane holds its latest frame; after a flush lanes without a frame idle
+		const long first = mux_frame_of(m, q, 0);
+		if (first >= m.n_sub)
+			break;
+		if (mux_frame_of(m, q, m.G - 1) >= m.n_sub && !m.flushed)
+			break;
+		for (int s = 0; s < m.S; s++)
+			for (int g = 0; g < m.G; g++) {
+				long n = mux_frame_of(m, q, g);
+				const int lane = s * m.G + g;
+				e->lane_gidx[lane] = n < m.n_sub ? e->ext.first_frame_index + n : -1;
+				if (n >= m.n_sub)
+					n = first; // an idle lane encodes lane 0's frame again; nobody reads the result
+				const uint8_t *const *src = &m.in_ring[(size_t)(n % m.cap) * 2 * m.S];
+				e->h_in_ptrs[lane] = src[s];
+				e->h_in_ptrs[m.S * m.G + lane] = src[m.S + s];
+			}
+		for (bool &v : e->in_tab_valid)
+			v = false;
+		e->next_gop_start = q % m.K == 0;
+		const int rc = submit_frame(e, nullptr);
+		if (rc)
+			return rc;
+		m.q_sub++;
+	}
+	return 0;
+}
+
+// take the oldest step off the session and file its access units under their frames
+static int mux_collect_step(cedar_enc *e)
+{
+	GopMux &m = *e->mux;
+	const long q = m.q_col;
+	const int rc = collect_frame(e);
+	m.q_col++;
+	for (int g = 0; g < m.G; g++) {
+		const long n = mux_frame_of(m, q, g);
+		if (n >= m.n_sub)
+			continue; // idle lane
+		int total = 0;
+		for (int s = 0; s < m.S; s++) {
+			std::vector<uint8_t> &o = m.out_ring[(size_t)(n % m.cap) * m.S + s];
+			o.clear();
+			if (rc >= 0) {
+				const int lane = s * m.G + g;
+				const uint8_t *src = e->h_out[e->res_host] + e->res_off[lane];
+				o.assign(src, src + e->res_size[lane]);
+				total += (int)e->res_size[lane];
+			}
+		}
+		m.out_rc[(size_t)(n % m.cap)] = rc >= 0 ? total : rc;
+	}
+	return rc < 0 && rc != -EIO && rc != -ENOSPC ? rc : 0; // a dropped step is reported per frame
+}
+
+static int mux_submit(cedar_enc *e)
+{
+	GopMux &m = *e->mux;
+	if (m.flushed)
+		return fail(e, -EINVAL, "submit after flush");
+	if (m.n_sub - m.n_col >= m.cap)
+		return fail(e, -EBUSY, "pipeline full: collect first");
+	HIP_TRY(e, hipSetDevice(e->device));
+	const size_t ring = (size_t)(m.n_sub % m.cap);
+	const size_t ysz = (size_t)e->cfg.input_luma_size, csz = (size_t)e->cfg.input_chroma_size;
+	bool any_host = false;
+	hipStream_t s_in = e->lookahead ? e->s_in : e->s_main; // where every frame's k_input runs: copies land in front of it
+	for (int s = 0; s < m.S; s++) {
+		const uint8_t **dst = &m.in_ring[ring * 2 * m.S];
+		if (m.user_in[s]) {
+			dst[s] = m.user_in[s];
+			dst[m.S + s] = m.user_in[m.S + s];
+			continue;
+		}
+		if (!m.d_store_y) { // first frame that comes through the pinned buffers: a device frame per ring entry
+			int rc2;
+			if ((rc2 = dalloc(e, &m.d_store_y, (size_t)m.cap * m.S * ysz)) || (rc2 = dalloc(e, &m.d_store_uv, (size_t)m.cap * m.S * csz)))
+				return rc2;
+		}
+		uint8_t *dy = m.d_store_y + (ring * m.S + s) * ysz, *duv = m.d_store_uv + (ring * m.S + s) * csz;
+		HIP_TRY(e, hipMemcpyAsync(dy, e->h_luma + (size_t)s * ysz, (size_t)e->cfg.src_width * e->cfg.src_height, hipMemcpyHostToDevice, s_in));
+		HIP_TRY(e, hipMemcpyAsync(duv, e->h_chroma + (size_t)s * csz, (size_t)e->cfg.src_width * e->cfg.src_height / 2, hipMemcpyHostToDevice, s_in));
+		dst[s] = dy;
+		dst[m.S + s] = duv;
+		any_host = true;
+	}
+	if (any_host) {
+		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_in));
+		HIP_TRY(e, hipEventSynchronize(e->ev_host_in)); // the caller may refill the pinned buffers
+	}
+	m.out_rc[ring] = INT32_MIN;
+	m.n_sub++;
+	// queue what has become ready; when a step is ready and the session is full, wait for its oldest
+	for (;;) {
+		int rc = mux_pump(e);
+		if (rc)
+			return rc;
+		const bool ready = mux_frame_of(m, m.q_sub, 0) < m.n_sub && mux_frame_of(m, m.q_sub, m.G - 1) < m.n_sub;
+		if (!ready || e->fl_count < e->depth)
+			return 0;
+		if ((rc = mux_collect_step(e)))
+			return rc;
+	}
+}
+
+static int mux_collect(cedar_enc *e)
+{
+	GopMux &m = *e->mux;
+	if (m.n_col >= m.n_sub)
+		return fail(e, -EINVAL, "nothing in flight");
+	const long n = m.n_col, q = mux_step_of(m, n);
+	while (m.q_col <= q) {
+		int rc = mux_pump(e);
+		if (rc)
+			return rc;
+		if (m.q_sub == m.q_col)
+			return fail(e, -EAGAIN, "frame %ld needs %ld more frame(s) submitted, or a flush", n,
+				    mux_frame_of(m, m.q_col, m.G - 1) - m.n_sub + 1);
+		if ((rc = mux_collect_step(e)))
+			return rc;
+	}
+	m.n_col++;
+	m.last = n;
+	e->stats.frames = (uint64_t)m.n_col;
+	const int rc = m.out_rc[(size_t)(n % m.cap)];
+	if (rc < 0)
+		return fail(e, rc, "frame %ld was dropped with its lock-step step", n);
+	return rc;
+}
+
+extern "C" int cedar_enc_submit(cedar_enc *e)
+{
+	if (!e)
+		return -EINVAL;
+	if (!e->configured) // cedar.c:1039-1043
+		return fail(e, -EINVAL, "CONFIG not run yet");
+	if (e->mux)
+		return mux_submit(e);
+	return submit_frame(e, nullptr);
+}
+
+extern "C" int cedar_enc_collect(cedar_enc *e)
+{
+	if (!e || !e->configured)
+		return -EINVAL;
+	return e->mux ? mux_collect(e) : collect_frame(e);
+}
+
+extern "C" int cedar_enc_flush(cedar_enc *e)
+{
+	if (!e || !e->configured)
+		return -EINVAL;
+	if (e->mux)
+		e->mux->flushed = true;
+	return 0;
+}
+
 extern "C" int cedar_enc_encode(cedar_enc *e)
 {
 	if (!e)
 		return -EINVAL;
+	if (e->configured && e->mux)
+		return fail(e, -EINVAL, "gop_parallel sessions take frames through submit / collect / flush");
 	if (e->fl_count != 0)
 		return fail(e, -EBUSY, "frames in flight: collect them before a synchronous encode");
 	// a failed encode leaves GOP counters and reference frames untouched
-	// (cedar.c:1182-1191 return before :1193-1201)
-	const int fc = e->frame_count, fpc = e->frame_p_count, cur = e->cur, ps = e->prev_slot, ps2 = e->prev2_slot;
-	const unsigned ic = e->idr_count;
+	// (cedar.c:1182-1191 return before :1193-1201): collect puts them back itself; a submit that
+	// failed half way is undone here
+	const GopState b{ e->frame_count, e->frame_p_count, e->cur, e->prev_slot, e->prev2_slot, e->idr_count };
 	int r = cedar_enc_submit(e);
+	if (r < 0 && e->configured) {
+		hipDeviceSynchronize();
+		e->fl_count = 0;
+		e->fl_head = 0;
+		e->frame_count = b.frame_count;
+		e->frame_p_count = b.frame_p_count;
+		e->cur = b.cur;
+		e->prev_slot = b.prev_slot;
+		e->prev2_slot = b.prev2_slot;
+		e->idr_count = b.idr_count;
+		return r;
+	}
 	if (r >= 0)
 		r = cedar_enc_collect(e);
-	if (r < 0) {
-		if (e->configured) {
-			hipDeviceSynchronize();
-			e->fl_count = 0;
-			e->fl_head = 0;
-		}
-		e->frame_count = fc;
-		e->frame_p_count = fpc;
-		e->cur = cur;
-		e->prev_slot = ps;
-		e->prev2_slot = ps2;
-		e->idr_count = ic;
-	}
 	return r;
 }
 
@@ -1568,6 +1937,16 @@ extern "C" int cedar_enc_stream_output(cedar_enc *e, int stream, const uint8_t *
 {
 	if (!e || !e->configured || stream < 0 || stream >= e->ext.n_streams)
 		return -EINVAL;
+	if (e->mux) { // the access unit of the frame the last collect delivered
+		if (stream >= e->mux->S || e->mux->last < 0)
+			return -EINVAL;
+		const std::vector<uint8_t> &o = e->mux->out_ring[(size_t)(e->mux->last % e->mux->cap) * e->mux->S + stream];
+		if (data)
+			*data = o.data();
+		if (size)
+			*size = (int)o.size();
+		return 0;
+	}
 	if (data)
 		*data = e->h_out[e->res_host] + e->res_off[stream];
 	if (size)

@@ -8,7 +8,9 @@
  * C-ABI of include/cedar_h264enc.h. Two literals differ from ve_config()
  * (h264enc.c:61,66): profile 66 and CAVLC, which this path implements.
  * Optional knobs come from the environment so the four positional arguments
- * stay: H264ENC_QP, H264ENC_KEYINT, H264ENC_SLICES, H264ENC_SEARCH, H264ENC_DEVICE.
+ * stay: H264ENC_QP, H264ENC_KEYINT, H264ENC_SLICES, H264ENC_SEARCH, H264ENC_DEVICE,
+ * H264ENC_GOP_PARALLEL (G closed GOPs side by side, same bytes), H264ENC_FIRST_FRAME (global index
+ * of the first frame when the stream is sharded by GOPs over several processes / GPUs).
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -57,6 +59,8 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.aud = env_int("H264ENC_AUD", 0);
 	ext.fps_num = env_int("H264ENC_FPS_NUM", 0);
 	ext.fps_den = env_int("H264ENC_FPS_DEN", ext.fps_num > 0 ? 1 : 0);
+	ext.gop_parallel = env_int("H264ENC_GOP_PARALLEL", 0);
+	ext.first_frame_index = env_int("H264ENC_FIRST_FRAME", 0);
 
 	ret = cedar_enc_config_ext(cedar, &config, &ext);
 	if (ret) {
@@ -125,7 +129,7 @@ int main(int argc, char **argv)
 	 * cedar_enc_submit() returns as soon as the input buffers may be refilled,
 	 * cedar_enc_collect() delivers the oldest frame. Same bytes, same order.
 	 * H264ENC_PIPELINE=0 restores the serial loop. */
-	if (env_int("H264ENC_PIPELINE", 1)) {
+	if (env_int("H264ENC_PIPELINE", 1) || env_int("H264ENC_GOP_PARALLEL", 0) > 1) {
 		int in_flight = 0;
 		const int depth = cedar_enc_session_depth(cedar);
 
@@ -141,6 +145,8 @@ int main(int argc, char **argv)
 				else
 					in_flight++;
 			}
+			if (!got)
+				cedar_enc_flush(cedar);
 			while (in_flight > (got ? depth - 1 : 0)) {
 				const uint8_t *data;
 				int size;
@@ -148,6 +154,9 @@ int main(int argc, char **argv)
 				ret = cedar_enc_collect(cedar);
 				in_flight--;
 				if (ret < 0) {
+					/* h264enc.c:189-192: that frame is not written, the loop goes on; the session
+					 * has dropped exactly it and codes the frames behind it again (cedar.c:1182-1201
+					 * leaves the GOP counter and the reference swap untouched on failure) */
 					fprintf(stderr, "%s(): %d: CEDAR_IOCTL_ENCODE failed: %s\n", __func__, frame_count, strerror(-ret));
 					continue;
 				}

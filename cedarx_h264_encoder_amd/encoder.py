@@ -41,7 +41,8 @@ class _Config(ctypes.Structure):
 class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
-        "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den")] + [("reserved", ctypes.c_int * 4)]
+        "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
+        "gop_parallel")] + [("reserved", ctypes.c_int * 2)]
 
 
 class _Stats(ctypes.Structure):
@@ -107,6 +108,7 @@ def load_library():
     L.cedar_enc_session_depth.argtypes = [vp]
     L.cedar_enc_submit.argtypes = [vp]
     L.cedar_enc_collect.argtypes = [vp]
+    L.cedar_enc_flush.argtypes = [vp]
     L.cedar_enc_close.argtypes = [vp]
     L.cedar_enc_close.restype = None
     L.cedar_enc_stream_output.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ci)]
@@ -160,6 +162,8 @@ class EncoderConfig:
     aud: int = 0              # 1: access unit delimiter in front of every access unit
     fps_num: int = 0          # both > 0: VUI timing + bitstream restriction in the SPS
     fps_den: int = 0
+    first_frame_index: int = 0  # global index of this session's first frame (a multiple of keyframe_interval)
+    gop_parallel: int = 0       # G > 1: G consecutive closed GOPs of every stream are encoded side by side
 
 
 class CedarEncoder:
@@ -187,7 +191,8 @@ class CedarEncoder:
         x = _ConfigExt()
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
-                  "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den"):
+                  "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
+                  "gop_parallel"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")
@@ -235,6 +240,10 @@ class CedarEncoder:
 
     def collect(self):
         return self._check(self._L.cedar_enc_collect(self._h), "collect")
+
+    def flush(self):
+        """gop_parallel sessions: no more frames will come, deliver what is buffered."""
+        return self._check(self._L.cedar_enc_flush(self._h), "flush")
 
     def output(self, stream=0):
         p, n = ctypes.c_void_p(), ctypes.c_int()

@@ -93,7 +93,18 @@ struct cedar_enc_config_ext {
 	int fps_den;         /*   frame rate fps_num/fps_den) and a bitstream restriction
 				(no reordering, one reference frame); 0/0: no VUI, as the
 				reference (cedar.c:933)                                  */
-	int reserved[4];
+	int first_frame_index; /* global index of the first frame this session encodes (default 0): a
+				multiple of keyframe_interval. idr_pic_id and "SPS+PPS only in front of
+				frame 0" derive from the GLOBAL index (cedar.c:1001, :1047, :1058-1061 count
+				frames of the one device), so closed GOPs encoded by different sessions /
+				GPUs concatenate to exactly the serial stream        */
+	int gop_parallel;    /* G > 1: the session encodes G consecutive closed GOPs of every stream side by
+				side (they depend on nothing of each other), as G lock-step lanes of the same
+				kernel launches. Same bytes, same order as G = 1; the price is latency: frame
+				n is delivered once frame n + (G-1)*keyframe_interval has been submitted (or
+				after cedar_enc_flush). cedar_enc_session_depth() says how many frames the
+				caller may have in flight. 0 / 1: off                                    */
+	int reserved[2];
 };
 
 typedef struct cedar_enc cedar_enc;
@@ -141,12 +152,27 @@ int cedar_enc_set_device_input(cedar_enc *enc, int stream, const void *d_luma, c
  * picture, which depends on no other frame, runs beside the P pictures submitted
  * before it, so it costs no time when the caller keeps the ring full. The bytes
  * are the same at any depth. Device input frames (cedar_enc_set_device_input)
- * must stay untouched until their frame is collected. */
+ * must stay untouched until their frame is collected.
+ *
+ * Failure (the reference: cedar.c:1182-1201 returns before the GOP counter and the reference
+ * swap, and h264enc.c:189-192 goes on with the next frame): a collect that returns < 0 has
+ * dropped exactly that frame. GOP counters and reference frames are as they were before it, and
+ * the frames submitted after it are encoded again by the session itself, from the inputs it
+ * still holds (its own device copies; device input frames, which the caller keeps untouched
+ * until their frame is collected anyway) -- the next collect delivers the frame after the failed
+ * one, coded as if the failed one had never been submitted.
+ *
+ * Outputs (cedar_enc_stream_output, cfg->bytestream) stay valid until the next cedar_enc_submit
+ * or cedar_enc_encode on the session: the ring slot they live in is then written again. */
 #define CEDAR_ENC_PIPELINE_DEPTH 16
-int cedar_enc_pipeline_depth(void);                  /* the compile-time maximum */
+int cedar_enc_pipeline_depth(void);                  /* the compile-time maximum (gop_parallel = 0) */
 int cedar_enc_session_depth(const cedar_enc *enc);   /* this session's; -EINVAL before CONFIG */
 int cedar_enc_submit(cedar_enc *enc);
 int cedar_enc_collect(cedar_enc *enc);
+/* gop_parallel sessions: no more frames will come; the GOPs buffered so far are encoded with the
+ * missing lanes idle, and cedar_enc_collect delivers what is left. collect returns -EAGAIN when
+ * the next frame in order needs more input (or a flush) first. A no-op for other sessions. */
+int cedar_enc_flush(cedar_enc *enc);
 
 /* Timing of the kernels, measured with hipEvents on the stream they run on
  * (replaces the driver's "Time spent" accounting, cedar.c:715-719, :1203-1205). */

@@ -562,6 +562,162 @@ def test_lost_handoff_drains_and_reports_eio(ce, monkeypatch, which, keyint):
             assert good.encode_frame(y, uv) == oe.encode(y, uv)
 
 
+def test_failed_encode_is_retryable_on_the_same_session(ce, monkeypatch):
+    """cedar.c:1182-1191 return before the GOP counter and the reference swap (:1193-1201): the caller
+    may simply call ENCODE again. Here the failed attempt leaves completion words, progress words and
+    abort flags behind in the very slots the retry uses; they are tagged by a submit sequence that is
+    never rolled back, so the retry must neither see "done" early nor a finished analysis."""
+    w, h = 640, 368
+    frames = [ol.gen_frame("B", w, h, f) for f in range(4)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=25))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    monkeypatch.setenv("CEDAR_FAULT_INJECT", "1")
+    monkeypatch.setenv("CEDAR_FAULT_INJECT_AT", "2")   # the second submit (frame 1, a P picture) loses a hand-off
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=25) as enc:
+        assert enc.encode_frame(*frames[0]) == want[0]
+        with pytest.raises(ce.EncoderError) as ex:
+            enc.encode_frame(*frames[1])
+        assert ex.value.errno == errno.EIO
+        for f in (1, 2, 3):                            # the same frame again, then on as if nothing had happened
+            assert enc.encode_frame(*frames[f]) == want[f], f
+            ry, ruv = enc.debug_read("recon_y"), enc.debug_read("recon_uv")
+        dec = ol.OracleDecoder()
+        for au in want:
+            dec.decode(au)
+        dy, duv = dec.picture()
+        assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
+
+
+@pytest.mark.parametrize("at,keyint", [(3, 25), (1, 4), (5, 4)], ids=["p-picture", "first-idr", "later-idr"])
+def test_pipelined_failure_drops_exactly_that_frame(ce, monkeypatch, at, keyint):
+    """The reference's loop goes on with the next frame after a failed ENCODE, with the GOP counter
+    and the reference frames untouched (h264enc.c:189-192, cedar.c:1182-1201). With frames in flight
+    the session does the same: the failed collect drops that frame, the frames submitted behind it
+    are coded again on the state from before it. The stream equals the oracle's encode of the
+    sequence WITHOUT the failed frame."""
+    w, h = 640, 368
+    n = 9
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    monkeypatch.setenv("CEDAR_FAULT_INJECT", "1" if keyint == 25 else "2" if at in (1, 5) else "1")
+    monkeypatch.setenv("CEDAR_FAULT_INJECT_AT", str(at))
+    got, failed = [], []
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=keyint) as enc:
+        depth, q, nxt = min(enc.pipeline_depth, 6), 0, 0
+        def take():
+            nonlocal nxt
+            try:
+                enc.collect()
+                got.append(enc.output())
+            except ce.EncoderError as ex:
+                assert ex.errno == errno.EIO
+                failed.append(nxt)
+            nxt += 1
+        for f in range(n):
+            if q == depth:
+                take()
+                q -= 1
+            enc.set_input(*frames[f])
+            enc.submit()
+            q += 1
+        while q:
+            take()
+            q -= 1
+    assert failed == [at - 1]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=keyint))
+    want = [oe.encode(*frames[f]) for f in range(n) if f != at - 1]
+    assert got == want
+
+
+def test_closed_gop_shards_concatenate_to_the_serial_stream(ce):
+    """GOP g on session (GPU) g mod N. idr_pic_id and "SPS + PPS in front of
+    frame 0 only" derive from the global frame index (first_frame_index), so the shards' bytes,
+    concatenated in GOP order, ARE the serial stream of the oracle -- no repeat_headers needed."""
+    w, h, K, gops = 320, 240, 5, 6
+    frames = [ol.gen_frame("B", w, h, f) for f in range(K * gops)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=28, keyint=K))
+    want = b"".join(oe.encode(y, uv) for y, uv in frames)
+    n_shards = 4
+    parts = {}
+    for shard in range(n_shards):
+        for g in range(shard, gops, n_shards):       # every GOP is a fresh session start: nothing carries over
+            with ce.CedarEncoder(width=w, height=h, qp=28, keyframe_interval=K, first_frame_index=g * K) as enc:
+                parts[g] = b"".join(enc.encode_frame(*frames[g * K + t]) for t in range(K))
+    assert b"".join(parts[g] for g in range(gops)) == want
+    with pytest.raises(ce.EncoderError) as ex:       # a shard starts with a GOP
+        ce.CedarEncoder(width=w, height=h, qp=28, keyframe_interval=K, first_frame_index=K + 1)
+    assert ex.value.errno == errno.EINVAL
+
+
+def _encode_gop_parallel(enc, frames, streams=1, device=False):
+    torch = None
+    keep = []
+    if device:
+        import torch
+    depth, out, q = enc.pipeline_depth, [], 0
+    def take():
+        enc.collect()
+        out.append(enc.output() if streams == 1 else [enc.output(s) for s in range(streams)])
+    for fr in frames:
+        if q == depth:
+            take()
+            q -= 1
+        for s in range(streams):
+            y, uv = fr if streams == 1 else fr[s]
+            if device:
+                ty, tuv = torch.from_numpy(y).cuda(), torch.from_numpy(uv).cuda()
+                keep.append((ty, tuv))
+                torch.cuda.synchronize()
+                enc.set_device_input(s, ty.data_ptr(), tuv.data_ptr())
+            else:
+                enc.set_input(y, uv, s)
+        enc.submit()
+        q += 1
+    enc.flush()
+    while q:
+        take()
+        q -= 1
+    return out
+
+
+@pytest.mark.parametrize("w,h,K,G,n,device", [(320, 240, 5, 4, 43, False), (320, 240, 5, 4, 20, True),
+                                              (640, 368, 3, 8, 50, False), (64, 48, 1, 3, 7, False),
+                                              (1920, 1080, 4, 3, 14, True)])
+def test_gop_parallel_session_equals_the_serial_stream(ce, w, h, K, G, n, device):
+    """gop_parallel = G: G consecutive closed GOPs of one stream run as lock-step lanes of the same
+    launches (they depend on nothing of each other). Frames go in and come out in stream order; the
+    bytes are the serial encode's, whole groups, partial last group and partial last GOP included."""
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=K))
+    want = [oe.encode(y, uv) for y, uv in frames]
+    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=K, gop_parallel=G) as enc:
+        assert enc.pipeline_depth >= (G - 1) * K + 2
+        got = _encode_gop_parallel(enc, frames, device=device)
+    bad = [i for i in range(n) if got[i] != want[i]]
+    assert not bad, "first differing frames: %s" % bad[:8]
+
+
+def test_gop_parallel_two_streams_and_collect_before_input_is_there(ce):
+    w, h, K, G, n = 320, 240, 4, 3, 19
+    frames = [[ol.gen_frame("B", w, h, f, s << 8) for s in range(2)] for f in range(n)]
+    want = []
+    for s in range(2):
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=K))
+        want.append([oe.encode(*frames[f][s]) for f in range(n)])
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=K, gop_parallel=G, n_streams=2) as enc:
+        for s in range(2):
+            enc.set_input(*frames[0][s], stream=s)
+        enc.submit()
+        with pytest.raises(ce.EncoderError) as ex:   # frame 0 needs frame (G-1)*K too, or a flush
+            enc.collect()
+        assert ex.value.errno == errno.EAGAIN
+        with pytest.raises(ce.EncoderError):          # lanes are fed through submit / collect / flush
+            enc.encode()
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=K, gop_parallel=G, n_streams=2) as enc:
+        got = _encode_gop_parallel(enc, frames, streams=2)
+    for s in range(2):
+        assert [g[s] for g in got] == want[s], s
+
+
 @pytest.mark.parametrize("mode", ["plain", "narrow", "wide"])
 def test_fuzz_sweep_against_oracle(mode):
     """tools/fuzz_parity.py with a fixed seed: random geometry (every other picture 1-3 macroblocks
