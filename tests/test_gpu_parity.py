@@ -562,6 +562,29 @@ def test_lost_handoff_drains_and_reports_eio(ce, monkeypatch, which, keyint):
             assert good.encode_frame(y, uv) == oe.encode(y, uv)
 
 
+def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
+    """tests/golden/indep_decode.json (tools/gen_indep_golden.py): the bytes the HIP path emits for
+    the fifteen cases must hash to the committed stream vectors, and the independent Python decoder
+    (tests/indep/h264_refdec.py: own code and tables, nothing shared with oracle/ or csrc/) must turn
+    them into the session's own deblocked reconstruction."""
+    import hashlib
+    import json
+    from tests.indep import h264_refdec as rd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(root, "tests", "golden", "indep_decode.json")))["cases"]
+    for c in cases:
+        w, h, qp, keyint, frames, pattern, slices = c["case"]
+        sh, dec = hashlib.sha1(), rd.Decoder()
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices) as ge:
+            for f in range(frames):
+                au = ge.encode_frame(*ol.gen_frame(pattern, w, h, f))
+                sh.update(au)
+                pic, = dec.decode(au)
+                assert pic.luma_bytes() == ge.debug_read("recon_y").tobytes(), (c["case"], f)
+                assert pic.nv12_chroma_bytes() == ge.debug_read("recon_uv").tobytes(), (c["case"], f)
+        assert sh.hexdigest() == c["stream_sha1"], c["case"]
+
+
 def test_failed_encode_is_retryable_on_the_same_session(ce, monkeypatch):
     """cedar.c:1182-1191 return before the GOP counter and the reference swap (:1193-1201): the caller
     may simply call ENCODE again. Here the failed attempt leaves completion words, progress words and

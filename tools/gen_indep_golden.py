@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/indep_decode.json: for a fixed list of small encodes, the SHA-1 of the
+Annex-B stream the C oracle emits and the SHA-1 of the pictures that the INDEPENDENT Python
+decoder (tests/indep/h264_refdec.py: own code, own tables) makes of it. The vectors pin the
+oracle (and through it the HIP path, which must emit the same bytes) to a reading of the
+standard that shares nothing with oracle/ -- see DESIGN.md section 2.
+Run from the repo root: python tools/gen_indep_golden.py"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import oracle_lib as ol                      # noqa: E402
+from tests.indep import h264_refdec as rd               # noqa: E402
+
+# w, h, qp, keyint, frames, pattern, slices
+CASES = [
+    (64, 48, 30, 25, 4, "B", 1), (64, 48, 24, 25, 3, "C", 1), (64, 48, 30, 25, 3, "A", 1), (70, 50, 24, 25, 3, "B", 1),
+    (64, 48, 5, 3, 4, "C", 1), (64, 48, 47, 3, 4, "B", 1), (16, 16, 24, 2, 3, "C", 1), (48, 80, 24, 4, 5, "B", 5),
+    (96, 64, 36, 4, 5, "B", 2), (64, 48, 1, 2, 2, "C", 1), (128, 96, 40, 25, 3, "B", 1), (96, 112, 18, 25, 3, "C", 1),
+    (16, 96, 24, 3, 6, "B", 1), (320, 240, 30, 25, 3, "B", 1), (320, 240, 24, 1, 2, "B", 4),
+]
+
+
+def encode_and_decode(case):
+    w, h, qp, keyint, frames, pattern, slices = case
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices))
+    dec = rd.Decoder()
+    stream, pics, same = hashlib.sha1(), hashlib.sha1(), True
+    for f in range(frames):
+        y, uv = ol.gen_frame(pattern, w, h, f)
+        au = oe.encode(y, uv)
+        stream.update(au)
+        out = dec.decode(au)
+        assert len(out) == 1, "one access unit, one picture"
+        ly, lc = out[0].luma_bytes(), out[0].nv12_chroma_bytes()
+        pics.update(ly)
+        pics.update(lc)
+        ry, ruv = oe.recon()
+        same = same and ly == ry.tobytes() and lc == ruv.tobytes()
+    return stream.hexdigest(), pics.hexdigest(), same, dec.cover
+
+
+def main():
+    out = []
+    for case in CASES:
+        s, p, same, _ = encode_and_decode(case)
+        if not same:
+            raise SystemExit("case %s: the independent decoder and the oracle's reconstruction differ" % (case,))
+        out.append({"case": list(case), "stream_sha1": s, "pictures_sha1": p})
+    path = os.path.join(ROOT, "tests", "golden", "indep_decode.json")
+    json.dump({"_made_by": "tools/gen_indep_golden.py", "cases": out}, open(path, "w"), indent=1)
+    print("wrote", path, len(out), "cases")
+
+
+if __name__ == "__main__":
+    main()
