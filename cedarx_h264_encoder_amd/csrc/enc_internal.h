@@ -122,6 +122,7 @@ struct Params {
 	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + 2*y < s1 (stripe_s1 <= 0: the whole picture)
 	const uint32_t *stripe_tab;      // [row_num + 1] macroblocks of the stripe in the rows before row r (per stream)
 	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
+	int64_t dummy_mb;                // ... and the macroblock record they fill: one past the session's last stream
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
 	// Frame pipelining keeps the deblock stream to ONE packet per frame (every packet queued behind a
 	// resident kernel costs its hardware pipe ~20 us): the last workgroup of the deblock launch

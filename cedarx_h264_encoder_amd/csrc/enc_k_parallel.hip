@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	uint8_t *rec_y = valid ? p.rec_y + (size_t)st * p.plane_y_stride + (size_t)y0 * p.cw + x0 : p.dummy_rec;
 	uint8_t *rec_uv = valid ? p.rec_uv + (size_t)st * p.plane_uv_stride + (size_t)(my * 8) * p.cw + x0 : p.dummy_rec + (size_t)16 * p.cw;
 	// records, counts and levels of the dummy macroblock live one past the last stream
-	const size_t mbaddr = valid ? (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx : (size_t)p.n_streams * p.n_mb;
+	const size_t mbaddr = valid ? (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx : (size_t)p.dummy_mb;
 
 	// ---- stage tiles through LDS with 16-byte loads ----
 	if (lane < 16)

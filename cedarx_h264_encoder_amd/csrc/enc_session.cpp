@@ -33,9 +33,8 @@ namespace {
 // one behind polling kernels of the other on shared hardware queues and wait for each other
 // until the spin bounds. Further sessions run their frames back to back.
 std::atomic<int> g_pipelined_sessions[64];
-const bool g_shared_main_probe = getenv("CEDAR_SHARE_MAIN") != nullptr;
-hipStream_t g_shared_main = nullptr;
 
+constexpr int MAX_COHORTS = 4; // see submit_frame
 constexpr int DB_STREAMS = 3;
 constexpr int AN_STREAMS = 3;
 constexpr int ENT_LANES = 2;
@@ -212,7 +211,8 @@ struct cedar_enc {
 	std::vector<long> lane_gidx; // [n_streams] global frame index of the next frame, per lane (mux sessions set it per step)
 	bool next_gop_start = false; // gop_parallel: the next submit starts a GOP on every lane
 	uint32_t fault_at = 0;       // tests (CEDAR_FAULT_INJECT_AT)
-	bool owns_main = true;       // s_main is this session's to destroy
+	int cohorts = 1;             // big batches go through the stages in this many groups of streams (submit_frame)
+	size_t stream_out_cap = 0;   // bytes of output per stream: cohort c packs its streams from (first stream) x this on
 	int cur = 0; // reconstruction buffer being written (cedar.c:117-119)
 	int depth = 4;  // frames in flight this session allows (<= CEDAR_ENC_PIPELINE_DEPTH) = device slots
 	int nrec = 5;   // reconstruction buffers (depth + 1)
@@ -281,7 +281,8 @@ struct cedar_enc {
 	hipEvent_t ev_base = nullptr;    // time zero of CEDAR_TRACE_TIMELINE
 	// per device slot: source planes + sync words ready (s_main), records complete (s_main),
 	// reconstruction deblocked (s_db)
-	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH] = {}, ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	// (x MAX_COHORTS: index slot * MAX_COHORTS + cohort)
+	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH * 4] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH * 4] = {}, ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH * 4] = {};
 	InFlight fl[CEDAR_ENC_PIPELINE_DEPTH];
 	int fl_head = 0, fl_count = 0; // ring of frames in flight
 	// results of the last collected frame
@@ -356,9 +357,11 @@ void free_all(cedar_enc *e)
 			hipEventDestroy(e->fl[i].done_main);
 		if (e->fl[i].done_ent)
 			hipEventDestroy(e->fl[i].done_ent);
-		if (e->ev_input[i]) hipEventDestroy(e->ev_input[i]);
-		if (e->ev_analysis[i]) hipEventDestroy(e->ev_analysis[i]);
-		if (e->ev_deblocked[i]) hipEventDestroy(e->ev_deblocked[i]);
+		for (int c = 0; c < 4; c++) {
+			if (e->ev_input[4 * i + c]) hipEventDestroy(e->ev_input[4 * i + c]);
+			if (e->ev_analysis[4 * i + c]) hipEventDestroy(e->ev_analysis[4 * i + c]);
+			if (e->ev_deblocked[4 * i + c]) hipEventDestroy(e->ev_deblocked[4 * i + c]);
+		}
 		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
 			for (int k = 0; k < 2; k++)
 				if (e->fl[i].tm.ev[s][k])
@@ -366,7 +369,7 @@ void free_all(cedar_enc *e)
 	}
 	if (e->ev_host_in) hipEventDestroy(e->ev_host_in);
 	if (e->ev_base) hipEventDestroy(e->ev_base);
-	if (e->s_main && e->owns_main) hipStreamDestroy(e->s_main);
+	if (e->s_main) hipStreamDestroy(e->s_main);
 	for (int i = 1; i < AN_STREAMS; i++)
 		if (e->s_ana[i]) hipStreamDestroy(e->s_ana[i]);
 	if (e->s_ent) hipStreamDestroy(e->s_ent);
@@ -588,6 +591,7 @@ void fill_static_params(cedar_enc *e)
 	P.mb_h = P.ch / 16;
 	P.n_mb = P.mb_w * P.mb_h;
 	P.n_streams = e->ext.n_streams;
+	P.dummy_mb = (int64_t)e->ext.n_streams * P.n_mb; // one record past the last stream (set again per cohort)
 	P.slice_count = e->ext.slice_count;
 	P.slice_first = e->ext.slice_first;
 	P.slice_num = e->ext.slice_num;
@@ -822,6 +826,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	int bs_sz = P.n_mb * 1024 + 4096;
 	if (bs_sz < (1 << 20)) bs_sz = 1 << 20;
 	e->out_cap = (size_t)bs_sz * S;
+	e->stream_out_cap = (size_t)bs_sz;
 	if (e->out_cap > 0x7fffffffULL)
 		return fail(e, -EINVAL, "too many streams for one session");
 	int rc = 0;
@@ -830,7 +835,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
-		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (S + 2) * sizeof(uint32_t), hipHostMallocMapped));
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (size_t)MAX_COHORTS * (S + 2) * sizeof(uint32_t), hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_sizes[i], e->h_sizes[i], 0));
 	}
 	for (int i = 0; i < e->depth; i++) {
@@ -894,7 +899,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if ((rc = dalloc(e, &e->d_esc[l], (size_t)n_units * P.esc_chunks_cap))) return rc;
 		if ((rc = dalloc(e, &e->d_nal_off[l], (size_t)n_units))) return rc;
 		if ((rc = dalloc(e, &e->d_nal_size[l], (size_t)n_units))) return rc;
-		if ((rc = dalloc(e, &e->d_stream_size[l], (size_t)S + 4))) return rc; // + k_copy_out's workgroup counter
+		if ((rc = dalloc(e, &e->d_stream_size[l], (size_t)MAX_COHORTS * (S + 4)))) return rc; // + k_copy_out's workgroup counter; per cohort
 	}
 	for (int i = 0; i < e->depth; i++)
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
@@ -933,7 +938,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 3) / 4);
 	}
 	for (int i = 0; i < e->depth; i++) {
-		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)3 * WF_SYNC_WORDS))) return rc;
+		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
 		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
 		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 3 * n_units * PROG_BANDS))) return rc;
 		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 3 * (size_t)n_units * PROG_BANDS)));
@@ -952,12 +957,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (bool &v : e->in_tab_valid)
 		v = false;
 
-	if (g_shared_main_probe && !g_shared_main) // experiment (CEDAR_SHARE_MAIN): the sessions of a process share one analysis stream
-		HIP_TRY(e, hipStreamCreateWithFlags(&g_shared_main, hipStreamNonBlocking));
-	if (g_shared_main_probe)
-		e->s_main = g_shared_main, e->owns_main = false;
-	else
-		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
 	e->s_ana[0] = e->s_main;
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
 	for (int i = 0; i < DB_STREAMS; i++)
@@ -1102,9 +1102,25 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 				e->lookahead = true;
 			}
 		}
+		{
+			// cohorts (submit_frame): off unless asked for. Measured on MI355X, 32 x 1080p: 2 cohorts 2.29 ms
+			// per step against 2.20 ms with one, 16 x 1080p 1.63 against 1.32 -- the deblocking of one
+			// cohort does NOT run beside the search of the other: a deblock workgroup is 16 waves of 128
+			// registers, i.e. a whole CU's register file, and never finds an empty CU while k_inter's
+			// small workgroups keep refilling them (CU masks for the two streams: 2.96 ms; a higher
+			// stream priority for the deblocking: no change). Kept for the day the wavefront kernels
+			// come in a small-workgroup form.
+			const char *envc = getenv("CEDAR_COHORTS");
+			int C = envc ? atoi(envc) : 1;
+			if (e->row_pipe || C < 1)
+				C = 1;
+			if (C > MAX_COHORTS) C = MAX_COHORTS;
+			if (C > S) C = S;
+			e->cohorts = C;
+		}
 		if (getenv("CEDAR_TRACE_SUBMIT"))
-			fprintf(stderr, "config: row_pipe %d, deblock streams %d, analysis streams %d, stripes %d, look-ahead %d, depth %d\n",
-				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth);
+			fprintf(stderr, "config: row_pipe %d, deblock streams %d, analysis streams %d, stripes %d, look-ahead %d, depth %d, cohorts %d\n",
+				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth, e->cohorts);
 	}
 	{
 		// diagonal stripes s = x + 2*y of a P picture and, per stripe, how many of its macroblocks
@@ -1135,9 +1151,11 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	}
 	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
-		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input[i], hipEventDisableTiming));
-		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis[i], hipEventDisableTiming));
-		HIP_TRY(e, hipEventCreateWithFlags(&e->ev_deblocked[i], hipEventDisableTiming));
+		for (int c = 0; c < e->cohorts; c++) {
+			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input[i * MAX_COHORTS + c], hipEventDisableTiming));
+			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis[i * MAX_COHORTS + c], hipEventDisableTiming));
+			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_deblocked[i * MAX_COHORTS + c], hipEventDisableTiming));
+		}
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_ent, hipEventDisableTiming));
 		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
 			for (int k = 0; k < 2; k++)
@@ -1271,6 +1289,59 @@ extern "C" int cedar_enc_session_depth(const cedar_enc *e)
 		return -EINVAL;
 	// gop_parallel: frame n needs frame n + (G-1)*K submitted before it can be delivered
 	return e->mux ? (e->mux->G - 1) * e->mux->K + e->depth : e->depth;
+}
+
+// Cohort c of a big batch: the same kernels on the streams [S*c/C, S*(c+1)/C) -- every per-stream and
+// per-unit array is one allocation with a fixed stride, so a cohort is an offset -- with scratch of
+// its own where a launch counts or compacts (wavefront tickets, size words, the packed output).
+static Params cohort_params(const cedar_enc *e, const Params &P, int c)
+{
+	const int C = e->cohorts;
+	if (C == 1)
+		return P;
+	const int S = P.n_streams, s0 = S * c / C, n = S * (c + 1) / C - s0;
+	const size_t u0 = (size_t)s0 * P.slice_num, m0 = (size_t)s0 * P.n_mb;
+	Params Q = P;
+	Q.n_streams = n;
+	Q.dummy_mb = (int64_t)((size_t)S * P.n_mb - m0);
+	if (Q.in_luma) {
+		Q.in_luma += s0;
+		Q.in_chroma += s0;
+	} else {
+		for (int s = 0; s < IN_K_STREAMS; s++) {
+			Q.in_k[s] = s0 + s < IN_K_STREAMS ? P.in_k[s0 + s] : nullptr;
+			Q.in_k[IN_K_STREAMS + s] = s0 + s < IN_K_STREAMS ? P.in_k[IN_K_STREAMS + s0 + s] : nullptr;
+		}
+	}
+	Q.src_y += (size_t)s0 * P.plane_y_stride;
+	Q.src_uv += (size_t)s0 * P.plane_uv_stride;
+	Q.rec_y += (size_t)s0 * P.plane_y_stride;
+	Q.rec_uv += (size_t)s0 * P.plane_uv_stride;
+	Q.ref_y += (size_t)s0 * P.plane_y_stride;
+	Q.ref_uv += (size_t)s0 * P.plane_uv_stride;
+	Q.mbi += m0;
+	Q.i4modes += m0 * 16;
+	Q.nnz += m0 * NNZ_PER_MB;
+	Q.coef += m0 * COEF_PER_MB;
+	Q.slot += m0 * SLOT_WORDS;
+	Q.mb_bits += m0;
+	Q.skip += m0;
+	Q.bit_off += u0 * (P.unit_mb_cap + 2);
+	Q.run_before += u0 * (P.unit_mb_cap + 2);
+	Q.unit_bits += u0;
+	Q.rbsp += u0 * P.rbsp_cap;
+	Q.esc_cnt += u0 * P.esc_chunks_cap;
+	Q.nal_off += u0;
+	Q.nal_size += u0;
+	Q.hdr += u0;
+	Q.prefix_len += s0;
+	Q.stream_size += (size_t)c * (S + 4);
+	Q.out += (size_t)s0 * e->stream_out_cap;
+	Q.out_cap = (int32_t)((size_t)n * e->stream_out_cap);
+	Q.wf_sync += (size_t)c * 3 * WF_SYNC_WORDS;
+	Q.wf_hbuf += u0 * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
+	Q.wf_hbuf_intra += u0 * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
+	return Q;
 }
 
 // The inputs of a frame that is encoded again after a frame before it failed (see recover()).
@@ -1423,103 +1494,9 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	// (k_input also zeroes the ticket / abort / progress words of the wavefront kernels)
 	*f.h_wf_err = 0;
 	P.wf_err = f.d_wf_err;
-	if (Launch::input(P, s_in))
-		return fail(e, -EIO, "k_input launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
-	HIP_TRY(e, hipEventRecord(e->ev_input[ds], s_in));
-	if (s_in != s_ana)
-		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[ds], 0));
+	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
+	P.prefix_len = f.dv_prefix;
 
-	auto launch_deblock = [&]() -> int {
-	// ---- in-loop deblocking: produces the next frame's reference ----
-		// Row-pipelined it starts at once and polls the analysis progress itself; otherwise it
-		// waits for the whole analysis.
-		// No event here: a cross-stream wait resolves to a later point of s_main than the record.
-		// The kernel needs nothing of this frame's s_main work up front: its sync words are zeroed
-		// on its own stream, the progress words need no zeroing (frame tags).
-		if (!pipe)
-			HIP_TRY(e, hipStreamWaitEvent(s_db, e->ev_analysis[ds], 0));
-		if (db_late) // same stream: everything is there when the kernel starts, nothing to poll
-			P.prog_intra = nullptr;
-		// Pipelined: ONE packet on the deblock stream per frame -- every packet queued behind a
-		// resident kernel costs the hardware pipe ~20 us. The kernel's last workgroup zeroes the
-		// sync words for the slot's next frame and raises the frame's done flag itself.
-		P.db_self_reset = pipe ? 1 : 0;
-		P.done_flag = f.d_done + 1;
-		P.done_tag = f.done_tag;
-		if (!pipe && e->wf_split > 1)
-			HIP_TRY(e, hipMemsetAsync(e->d_wf_sync[ds] + WF_SYNC_WORDS, 0,
-						  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)S * e->ext.slice_num * WF_MAX_SPLIT), s_db));
-		tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
-		// luma and chroma are independent wavefronts: one launch, the plane picked per workgroup
-		// (few units), or both planes in every wave pair (many units: CUs are the scarce thing)
-		if (Launch::deblock(P, s_db, e->split_planes ? 4 : 3))
-			return fail(e, -EIO, "k_deblock launch failed");
-		tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
-		P.db_self_reset = 0;
-		f.s_db = s_db;
-		if (!pipe) {
-			// the frame is complete when deblocking and entropy coding are (collect waits for both)
-			HIP_TRY(e, hipEventRecord(f.done_main, s_db));
-			HIP_TRY(e, hipEventRecord(e->ev_deblocked[ds], s_db));
-			if (Launch::flag(s_db, f.d_done + 1, f.done_tag))
-				return fail(e, -EIO, "k_flag launch failed");
-		}
-		return 0;
-	};
-	// Row-pipelined, the deblock kernel only polls progress words: it is queued BEFORE this
-	// frame's analysis so that it is resident and waiting when the first stripe arrives.
-	if (pipe && !db_late) {
-		const int rc_db = launch_deblock();
-		if (rc_db)
-			return rc_db;
-	}
-
-	// ---- analysis + reconstruction ----
-	// What this frame overwrites or reads of its predecessors: rec[cur] was last touched by frames
-	// that have been collected (the buffers rotate through depth + 1); a P picture reads the
-	// reconstruction frame n-1 is deblocking. Row-pipelined, a P picture follows that deblocking
-	// band by band (k_gate); otherwise it waits for the whole frame. An IDR picture waits for nothing.
-	if (prev >= 0 && !idr && !pipe)
-		HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_deblocked[prev], 0));
-	if (idr) {
-		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
-		if (Launch::intra_decide(P, s_ana))
-			return fail(e, -EIO, "k_intra_decide launch failed");
-		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
-		tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_RECON, s_ana);
-		if (Launch::intra_recon(P, s_ana))
-			return fail(e, -EIO, "k_intra_recon launch failed");
-		tm_end(e, f, CEDAR_ENC_STAGE_INTRA_RECON, s_ana);
-		if (pipe && Launch::gate(P, s_ana, PROG_ALL, 0))
-			return fail(e, -EIO, "k_gate launch failed");
-	} else {
-		tm_begin(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
-		if (pipe) {
-			// diagonal stripes s = x + 2*y: the order in which the deblock wavefront of the
-			// previous frame releases the reference and in which this frame's own can follow
-			const int nb = e->inter_bands;
-			for (int k = 0; k < nb; k++) {
-				P.stripe_s0 = e->stripe_s[k];
-				P.stripe_s1 = e->stripe_s[k + 1];
-				P.stripe_tab = e->d_stripe_tab + (size_t)k * (P.row_num + 1);
-				if (Launch::gate(P, s_ana, k > 0 ? P.stripe_s0 : -1, P.stripe_s1 + 5))
-					return fail(e, -EIO, "k_gate launch failed");
-				if (e->stripe_n[k] > 0 && Launch::inter(P, s_ana, e->stripe_n[k] * S))
-					return fail(e, -EIO, "k_inter launch failed");
-			}
-			if (Launch::gate(P, s_ana, PROG_ALL, 0))
-				return fail(e, -EIO, "k_gate launch failed");
-			P.stripe_s0 = P.stripe_s1 = 0;
-		} else if (Launch::inter(P, s_ana, P.mb_w * P.row_num * S)) {
-			return fail(e, -EIO, "k_inter launch failed");
-		}
-		tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
-	}
-	HIP_TRY(e, hipEventRecord(e->ev_analysis[ds], s_ana));
-	const double t_main = now_ms();
-
-	// ---- entropy coding on its own stream, concurrent with deblocking ----
 	// Headers per lane: idr_pic_id and "parameter sets in front of frame 0" follow the GLOBAL frame
 	// index (the reference counts the frames of its one device, cedar.c:1001, :1058-1061; a shard or a
 	// GOP lane starts somewhere in the stream). frame_num restarts with every IDR picture (cedar.c:1001).
@@ -1552,35 +1529,161 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.nal_size = e->d_nal_size[lane];
 	P.stream_size = e->d_stream_size[lane];
 	f.lane = lane;
-	HIP_TRY(e, hipStreamWaitEvent(s_ent, e->ev_analysis[ds], 0));
-	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
-	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
-	P.prefix_len = f.dv_prefix;
-	// Pipelined: as few packets on the entropy stream as possible (see launch_deblock): the size
-	// words are left zeroed and the done flag raised by k_copy_out's last workgroup
-	if (!pipe)
-		HIP_TRY(e, hipMemsetAsync(e->d_stream_size[lane], 0, sizeof(uint32_t) * (S + 4), s_ent));
-	if (Launch::entropy(P, s_ent))
-		return fail(e, -EIO, "entropy launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
 	f.host_out = slot; // every frame in flight owns one host buffer until it is collected
 	f.s_ent = s_ent;
+	f.s_db = s_db;
 	f.events = !pipe;
-	P.done_flag = pipe ? f.d_done : nullptr;
-	P.done_tag = f.done_tag;
-	if (Launch::copy_out(P, s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
-		return fail(e, -EIO, "k_copy_out launch failed");
-	if (!pipe) {
-		HIP_TRY(e, hipEventRecord(f.done_ent, s_ent));
-		if (Launch::flag(s_ent, f.d_done, f.done_tag))
-			return fail(e, -EIO, "k_flag launch failed");
-	}
-	const double t_ent = now_ms();
+	double t_main = t0, t_ent = t0;
 
-	if (!pipe || db_late) {
-		const int rc_db = launch_deblock();
-		if (rc_db)
-			return rc_db;
+	// The streams of a big batch go through the stages in COHORTS (sessions whose frames run back to
+	// back): a P picture's search waits for the deblocking of the picture before it, and with all
+	// streams in one launch the GPU does search, THEN deblocking -- the one fills the chip with SAD
+	// issue, the other is a dependency chain on a few waves per CU. Two cohorts enqueue
+	//   analysis stream   search(A, n)   search(B, n)   [db(A, n)] search(A, n+1)  [db(B, n)] search(B, n+1)
+	//   deblock stream    [an(A, n)] db(A, n)           [an(B, n)] db(B, n)
+	// so cohort A's deblocking runs beside cohort B's search. A cohort is the same launches on
+	// offset pointers; scratch that a launch counts or compacts in (tickets, size words, the packed
+	// output) is per cohort.
+	const int C = e->cohorts;
+	for (int c = 0; c < C; c++) {
+		Params Pc = cohort_params(e, P, c);
+		const int ei = ds * MAX_COHORTS + c, eprev = prev * MAX_COHORTS + c;
+		if (Launch::input(Pc, s_in))
+			return fail(e, -EIO, "k_input launch failed");
+		if (c == C - 1)
+			tm_end(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
+		HIP_TRY(e, hipEventRecord(e->ev_input[ei], s_in));
+		if (s_in != s_ana)
+			HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[ei], 0));
+
+		auto launch_deblock = [&]() -> int {
+		// ---- in-loop deblocking: produces the next frame's reference ----
+			// Row-pipelined it starts at once and polls the analysis progress itself; otherwise it
+			// waits for the whole analysis.
+			// No event here: a cross-stream wait resolves to a later point of s_main than the record.
+			// The kernel needs nothing of this frame's s_main work up front: its sync words are zeroed
+			// on its own stream, the progress words need no zeroing (frame tags).
+			if (!pipe)
+				HIP_TRY(e, hipStreamWaitEvent(s_db, e->ev_analysis[ei], 0));
+			if (db_late) // same stream: everything is there when the kernel starts, nothing to poll
+				Pc.prog_intra = nullptr;
+			// Pipelined: ONE packet on the deblock stream per frame -- every packet queued behind a
+			// resident kernel costs the hardware pipe ~20 us. The kernel's last workgroup zeroes the
+			// sync words for the slot's next frame and raises the frame's done flag itself.
+			Pc.db_self_reset = pipe ? 1 : 0;
+			Pc.done_flag = f.d_done + 1;
+			Pc.done_tag = f.done_tag;
+			if (!pipe && e->wf_split > 1)
+				HIP_TRY(e, hipMemsetAsync(Pc.wf_sync + WF_SYNC_WORDS, 0,
+							  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)Pc.n_streams * e->ext.slice_num * WF_MAX_SPLIT), s_db));
+			if (c == 0)
+				tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
+			// luma and chroma are independent wavefronts: one launch, the plane picked per workgroup
+			// (few units), or both planes in every wave pair (many units: CUs are the scarce thing)
+			if (Launch::deblock(Pc, s_db, e->split_planes ? 4 : 3))
+				return fail(e, -EIO, "k_deblock launch failed");
+			if (c == C - 1)
+				tm_end(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_db);
+			Pc.db_self_reset = 0;
+			if (!pipe)
+				HIP_TRY(e, hipEventRecord(e->ev_deblocked[ei], s_db));
+			if (!pipe && c == C - 1) {
+				// the frame is complete when deblocking and entropy coding are (collect waits for both)
+				HIP_TRY(e, hipEventRecord(f.done_main, s_db));
+				if (Launch::flag(s_db, f.d_done + 1, f.done_tag))
+					return fail(e, -EIO, "k_flag launch failed");
+			}
+			return 0;
+		};
+		// Row-pipelined, the deblock kernel only polls progress words: it is queued BEFORE this
+		// frame's analysis so that it is resident and waiting when the first stripe arrives.
+		if (pipe && !db_late) {
+			const int rc_db = launch_deblock();
+			if (rc_db)
+				return rc_db;
+		}
+
+		// ---- analysis + reconstruction ----
+		// What this frame overwrites or reads of its predecessors: rec[cur] was last touched by frames
+		// that have been collected (the buffers rotate through depth + 1); a P picture reads the
+		// reconstruction frame n-1 is deblocking. Row-pipelined, a P picture follows that deblocking
+		// band by band (k_gate); otherwise it waits for the whole frame. An IDR picture waits for nothing.
+		if (prev >= 0 && !idr && !pipe)
+			HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_deblocked[eprev], 0));
+		if (idr) {
+			if (c == 0)
+				tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
+			if (Launch::intra_decide(Pc, s_ana))
+				return fail(e, -EIO, "k_intra_decide launch failed");
+			if (C == 1)
+				tm_end(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
+			if (C == 1)
+				tm_begin(e, f, CEDAR_ENC_STAGE_INTRA_RECON, s_ana);
+			if (Launch::intra_recon(Pc, s_ana))
+				return fail(e, -EIO, "k_intra_recon launch failed");
+			if (C == 1)
+				tm_end(e, f, CEDAR_ENC_STAGE_INTRA_RECON, s_ana);
+			else if (c == C - 1) // cohorts: both intra stages of all cohorts, under the first stage's name
+				tm_end(e, f, CEDAR_ENC_STAGE_INTRA_DECIDE, s_ana);
+			if (pipe && Launch::gate(Pc, s_ana, PROG_ALL, 0))
+				return fail(e, -EIO, "k_gate launch failed");
+		} else {
+			if (c == 0)
+				tm_begin(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
+			if (pipe) {
+				// diagonal stripes s = x + 2*y: the order in which the deblock wavefront of the
+				// previous frame releases the reference and in which this frame's own can follow
+				const int nb = e->inter_bands;
+				for (int k = 0; k < nb; k++) {
+					Pc.stripe_s0 = e->stripe_s[k];
+					Pc.stripe_s1 = e->stripe_s[k + 1];
+					Pc.stripe_tab = e->d_stripe_tab + (size_t)k * (Pc.row_num + 1);
+					if (Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 5))
+						return fail(e, -EIO, "k_gate launch failed");
+					if (e->stripe_n[k] > 0 && Launch::inter(Pc, s_ana, e->stripe_n[k] * S))
+						return fail(e, -EIO, "k_inter launch failed");
+				}
+				if (Launch::gate(Pc, s_ana, PROG_ALL, 0))
+					return fail(e, -EIO, "k_gate launch failed");
+				Pc.stripe_s0 = Pc.stripe_s1 = 0;
+			} else if (Launch::inter(Pc, s_ana, Pc.mb_w * Pc.row_num * Pc.n_streams)) {
+				return fail(e, -EIO, "k_inter launch failed");
+			}
+			if (c == C - 1)
+				tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
+		}
+		HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
+		t_main = now_ms();
+
+		// ---- entropy coding on its own stream, concurrent with deblocking ----
+		HIP_TRY(e, hipStreamWaitEvent(s_ent, e->ev_analysis[ei], 0));
+		if (c == 0)
+			tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
+		// Pipelined: as few packets on the entropy stream as possible (see launch_deblock): the size
+		// words are left zeroed and the done flag raised by k_copy_out's last workgroup
+		if (!pipe)
+			HIP_TRY(e, hipMemsetAsync(Pc.stream_size, 0, sizeof(uint32_t) * (Pc.n_streams + 4), s_ent));
+		if (Launch::entropy(Pc, s_ent))
+			return fail(e, -EIO, "entropy launch failed");
+		if (c == C - 1)
+			tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
+		Pc.done_flag = pipe ? f.d_done : nullptr;
+		Pc.done_tag = f.done_tag;
+		if (Launch::copy_out(Pc, s_ent, e->dv_out[f.host_out] + (size_t)(S * c / C) * (C > 1 ? e->stream_out_cap : 0),
+				     e->dv_sizes[slot] + (size_t)c * (S + 2)))
+			return fail(e, -EIO, "k_copy_out launch failed");
+		if (!pipe && c == C - 1) {
+			HIP_TRY(e, hipEventRecord(f.done_ent, s_ent));
+			if (Launch::flag(s_ent, f.d_done, f.done_tag))
+				return fail(e, -EIO, "k_flag launch failed");
+		}
+		t_ent = now_ms();
+
+		if (!pipe || db_late) {
+			const int rc_db = launch_deblock();
+			if (rc_db)
+				return rc_db;
+		}
 	}
 
 	f.active = true;
@@ -1635,11 +1738,11 @@ static int recover(cedar_enc *e, const InFlight &failed)
 	const int n_units = e->ext.n_streams * e->ext.slice_num;
 	(void)n_units;
 	for (int i = 0; i < e->depth; i++) {
-		HIP_TRY(e, hipMemset(e->d_wf_sync[i], 0, sizeof(uint32_t) * 3 * WF_SYNC_WORDS));
+		HIP_TRY(e, hipMemset(e->d_wf_sync[i], 0, sizeof(uint32_t) * MAX_COHORTS * 3 * WF_SYNC_WORDS));
 		*e->fl[i].h_wf_err = 0;
 	}
 	for (int l = 0; l < e->ent_lanes; l++)
-		HIP_TRY(e, hipMemset(e->d_stream_size[l], 0, sizeof(uint32_t) * (e->ext.n_streams + 4)));
+		HIP_TRY(e, hipMemset(e->d_stream_size[l], 0, sizeof(uint32_t) * MAX_COHORTS * (e->ext.n_streams + 4)));
 	for (const ReplayIn &r : later) {
 		const int rc = submit_frame(e, &r);
 		if (rc)
@@ -1681,10 +1784,19 @@ static int collect_frame(cedar_enc *e)
 	e->fl_head = (e->fl_head + 1) % e->depth;
 	e->fl_count--;
 	f.active = false;
-	const uint32_t *sz = e->h_sizes[slot];
-	const uint32_t total = sz[S], flags = sz[S + 1];
+	// sizes per cohort: [streams of the cohort] total, error flags
+	const int C = e->cohorts;
+	uint32_t total = 0, flags = 0;
+	bool too_big = false;
+	for (int c = 0; c < C; c++) {
+		const int n = S * (c + 1) / C - S * c / C;
+		const uint32_t *sz = e->h_sizes[slot] + (size_t)c * (S + 2);
+		total += sz[n];
+		flags |= sz[n + 1];
+		too_big = too_big || sz[n] > (size_t)n * e->stream_out_cap;
+	}
 	const uint32_t wf_err = *f.h_wf_err;
-	if (hip_failed || wf_err || flags || total > e->out_cap) {
+	if (hip_failed || wf_err || flags || too_big) {
 		// this frame is dropped, the session is where it was before it, the frames behind it run again
 		const int rc = recover(e, f);
 		if (rc)
@@ -1695,19 +1807,23 @@ static int collect_frame(cedar_enc *e)
 			return fail(e, -EIO, "wavefront hand-off timed out (flags %u)", wf_err);
 		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
 	}
-	uint32_t off = 0;
-	for (int s = 0; s < S; s++) {
-		e->res_off[s] = off;
-		e->res_size[s] = sz[s];
-		uint8_t *front = e->h_out[f.host_out] + off;
-		if (f.aud) {
-			const std::vector<uint8_t> &a = e->aud_nal[f.aud - 1];
-			memcpy(front, a.data(), a.size());
-			front += a.size();
+	for (int c = 0; c < C; c++) {
+		const int s0 = S * c / C, s1 = S * (c + 1) / C;
+		const uint32_t *sz = e->h_sizes[slot] + (size_t)c * (S + 2);
+		uint32_t off = (uint32_t)((size_t)s0 * (C > 1 ? e->stream_out_cap : 0));
+		for (int s = s0; s < s1; s++) {
+			e->res_off[s] = off;
+			e->res_size[s] = sz[s - s0];
+			uint8_t *front = e->h_out[f.host_out] + off;
+			if (f.aud) {
+				const std::vector<uint8_t> &a = e->aud_nal[f.aud - 1];
+				memcpy(front, a.data(), a.size());
+				front += a.size();
+			}
+			if (f.with_ps[s])
+				memcpy(front, e->sps_pps.data(), e->sps_pps.size());
+			off += sz[s - s0];
 		}
-		if (f.with_ps[s])
-			memcpy(front, e->sps_pps.data(), e->sps_pps.size());
-		off += sz[s];
 	}
 	e->res_host = f.host_out;
 	e->last_total = total;

@@ -208,6 +208,22 @@ def test_many_streams_back_to_back_with_idr_lookahead(ce, monkeypatch, batch_loo
     assert got == want
 
 
+@pytest.mark.parametrize("cohorts,streams", [(2, 5), (3, 18)])
+def test_cohorts_of_streams_give_the_same_bytes(ce, monkeypatch, cohorts, streams):
+    """CEDAR_COHORTS: the streams of a batch go through the stages in groups (the same launches on
+    offset pointers, scratch per cohort). Every stream's bytes must be those of a session of its own."""
+    w, h = 192, 112
+    monkeypatch.setenv("CEDAR_COHORTS", str(cohorts))
+    monkeypatch.setenv("CEDAR_ROW_PIPE", "0")
+    frames = [[ol.gen_frame("B", w, h, f, s << 8) for s in range(streams)] for f in range(7)]
+    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=3, n_streams=streams) as enc:
+        got = _encode_pipelined(enc, frames, streams=streams)
+    for s in range(streams):
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=3))
+        for f in range(7):
+            assert got[f][s] == oe.encode(*frames[f][s]), (s, f)
+
+
 def test_config4_shape_eight_1080p_streams_in_one_session(ce):
     """BASELINE configs[4] shape on one device: 8 lock-step 1920x1080 streams (seed offset
     s<<8); every stream must equal the oracle's encode of that stream alone."""
