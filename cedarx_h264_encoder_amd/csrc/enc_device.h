@@ -169,10 +169,12 @@ DEVI int nz_mask(int v) { return (v | -v) >> 31; }               // v != 0 ? -1 
 DEVI int sel(int m, int a, int b) { return b ^ ((a ^ b) & m); }  // m ? a : b for m in {0,-1}
 
 // cross-lane exchanges inside a 16-lane DPP row; lane = 4*i + j
-DEVI int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); } // quad_perm [1,0,3,2]
-DEVI int dpp_xor3(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xf, 0xf, false); } // quad_perm [3,2,1,0]
-DEVI int dpp_xor4(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); } // row_half_mirror, j restored
-DEVI int dpp_xor12(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); } // row_mirror, j restored
+// (bound_ctrl: none of these patterns reads an invalid lane, and with it set the compiler need not
+// materialise the "old" value -- a v_mov 0 in front of every exchange otherwise)
+DEVI int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); } // quad_perm [1,0,3,2]
+DEVI int dpp_xor3(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xf, 0xf, true); } // quad_perm [3,2,1,0]
+DEVI int dpp_xor4(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true)); } // row_half_mirror, j restored
+DEVI int dpp_xor12(int v) { return dpp_xor3(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true)); } // row_mirror, j restored
 
 // Per-lane constants of the butterflies below (k = position 0..3 along the axis).
 // Selecting with `k == 0 ? .. : k == 1 ? ..` makes hipcc emit exec-mask if/else

@@ -142,10 +142,57 @@ DEVI bool inter_mb(const Params &p, uint32_t i, int &mx, int &my, int &st)
 	return st < p.n_streams;
 }
 
+// LDS traffic of one wave is private to it here: order it with a wave-level fence instead of the
+// workgroup barrier (which would make the four macroblocks of a workgroup wait for each other)
+#define WAVE_LDS_SYNC()                                                        \
+	do {                                                                   \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+		__builtin_amdgcn_wave_barrier();                               \
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
+	} while (0)
+
+typedef uint64_t u64_a4 __attribute__((aligned(4)));
+
+// raster position of a coefficient -> its zig-zag scan index, one nibble each
+DEVI int zigzag_of(int rpos) { return (int)((0xFEA9DB83C7426510ull >> (4 * rpos)) & 15u); }
+
+// transforms of enc_device.h with the lane-constant multiplies as 24-bit multiply-adds (one
+// full-rate instruction each; v_mul_lo_u32 is quarter rate): every operand is far inside 24 bits
+// (|residual| <= 255, |W| <= 9180, |scaled coefficient| < 2^17)
+DEVI int fdct_lanes24(int v, const LaneK &ci, const LaneK &cj)
+{
+	int s = __mul24(cj.s1, v) + dpp_xor3(v);
+	int q = dpp_xor1(s);
+	s = __mul24(cj.fa, s) + __mul24(cj.fb, q);
+	s = __mul24(ci.s1, s) + dpp_xor12(s);
+	q = dpp_xor4(s);
+	return __mul24(ci.fa, s) + __mul24(ci.fb, q);
+}
+
+DEVI int idct_lanes24(int d, const LaneK &ci, const LaneK &cj)
+{
+	int q = dpp_xor1(d);
+	int e = __mul24(cj.ia, d >> cj.sh) + __mul24(cj.ib, q);
+	int f = __mul24(cj.s1, e) + dpp_xor3(e);
+	q = dpp_xor4(f);
+	e = __mul24(ci.ia, f >> ci.sh) + __mul24(ci.ib, q);
+	f = __mul24(ci.s1, e) + dpp_xor12(e);
+	return (f + 32) >> 6;
+}
+
+// quant1 of enc_device.h for |w| < 2^15, mf < 2^14: the product fits the 24-bit multiplier
+DEVI int quant24(int w, int mf, int f, int qbits)
+{
+	const uint32_t a = (uint32_t)iabs(w);
+	int l = (int)((__umul24(a, (uint32_t)mf) + (uint32_t)f) >> qbits);
+	l = l > LEVEL_MAX ? LEVEL_MAX : l;
+	return w < 0 ? -l : l;
+}
+
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
-	// one wave per macroblock, INTER_WAVES macroblocks per workgroup (each wave has its own
-	// slice of every array; the barriers below only ever order a wave with itself)
+	// one wave per macroblock, INTER_WAVES macroblocks per workgroup; each wave has its own
+	// slice of every array and never looks at another wave's
 	__shared__ __attribute__((aligned(16))) uint8_t sa_ref[INTER_WAVES][48 * REF_STRIDE + 64];
 	__shared__ __attribute__((aligned(16))) uint8_t sa_refc[INTER_WAVES][25 * REFC_STRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t sa_cur[INTER_WAVES][256];
@@ -153,14 +200,14 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	__shared__ __attribute__((aligned(16))) int16_t sa_coef[INTER_WAVES][COEF_PER_MB];
 	__shared__ __attribute__((aligned(16))) uint8_t sa_recy[INTER_WAVES][256];
 	__shared__ __attribute__((aligned(16))) uint8_t sa_recc[INTER_WAVES][128];
-	__shared__ int sa_dc[INTER_WAVES][8];
-	__shared__ int sa_cdc[INTER_WAVES][8];
+	__shared__ __attribute__((aligned(8))) uint8_t sa_nnz[INTER_WAVES][NNZ_PER_MB];
 
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows
 	uint8_t *const s_ref = sa_ref[wave], *const s_refc = sa_refc[wave], *const s_cur = sa_cur[wave], *const s_curc = sa_curc[wave];
 	int16_t *const s_coef = sa_coef[wave];
 	uint8_t *const s_recy = sa_recy[wave], *const s_recc = sa_recc[wave];
-	int *const s_dc = sa_dc[wave], *const s_cdc = sa_cdc[wave];
+	uint8_t *const s_nnz = sa_nnz[wave];
 	// XCD-aware workgroup order (see xcd_mb): workgroups sharing an XCD own one contiguous run
 	const uint32_t nb = gridDim.x, hb = blockIdx.x;
 	const uint32_t xcd = hb & 7u, bi = hb >> 3, q = nb >> 3, r = nb & 7u;
@@ -187,80 +234,123 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// records, counts and levels of the dummy macroblock live one past the last stream
 	const size_t mbaddr = valid ? (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx : (size_t)p.dummy_mb;
 
-	// ---- stage tiles through LDS with 16-byte loads ----
+	// ---- stage tiles through LDS with 16-byte loads (offsets inside a plane fit 32 bits) ----
+	const uint32_t cw = (uint32_t)p.cw;
 	if (lane < 16)
-		*(u32x4 *)(s_cur + lane * 16) = *(const u32x4 *)(src_y + (size_t)(y0 + lane) * p.cw + x0);
+		*(u32x4 *)(s_cur + lane * 16) = *(const u32x4 *)(src_y + (uint32_t)(y0 + lane) * cw + (uint32_t)x0);
 	else if (lane < 24)
-		*(u32x4 *)(s_curc + (lane - 16) * 16) =
-			*(const u32x4 *)(src_uv + (size_t)(my * 8 + lane - 16) * p.cw + x0);
-	for (int idx = lane; idx < 48 * 3; idx += 64) {
-		int row = idx / 3, seg = idx - row * 3;
-		int gy = y0 - 16 + row, gx = x0 - 16 + 16 * seg;
-		u32x4 v = u32x4{ 0, 0, 0, 0 };
-		if (gy >= 0 && gy < p.ch && gx >= 0 && gx < p.cw)
-			v = *(const u32x4 *)(ref_y + (size_t)gy * p.cw + gx);
-		*(u32x4 *)(s_ref + row * REF_STRIDE + 16 * seg) = v;
-	}
-	for (int idx = lane; idx < 25 * 4; idx += 64) {
-		int row = idx >> 2, seg = idx & 3;
-		int gy = my * 8 - 8 + row, gx = x0 - 16 + 16 * seg; // byte offset in the CbCr row
-		u32x4 v = u32x4{ 0, 0, 0, 0 };
-		if (gy >= 0 && gy < (p.ch >> 1) && gx >= 0 && gx < p.cw)
-			v = *(const u32x4 *)(ref_uv + (size_t)gy * p.cw + gx);
-		*(u32x4 *)(s_refc + row * REFC_STRIDE + 16 * seg) = v;
-	}
-	if (lane < 16)
-		*(u32x4 *)(s_ref + 48 * REF_STRIDE + (lane & 3) * 16) = u32x4{ 0, 0, 0, 0 };
-	__syncthreads();
-
-	// ---- motion search: lane task = (dy, group of 4 dx); 33 x 9 = 297 tasks ----
-	uint32_t curd[64];
+		*(u32x4 *)(s_curc + (lane - 16) * 16) = *(const u32x4 *)(src_uv + (uint32_t)(my * 8 + lane - 16) * cw + (uint32_t)x0);
+	{
+		// Reference window. Samples outside the picture are never used (a candidate that touches them
+		// is not valid), so the loads are unconditional from clamped coordinates: no branches.
+		// luma: 48 rows x 3 segments of 16 bytes; lane -> (row = lane / 3 + 21 * pass, seg = lane % 3), 63 lanes
+		const int wrow = min(lane, 62) / 3, wseg = min(lane, 62) - 3 * wrow;
+		const uint32_t gx = (uint32_t)min(max(x0 - 16 + 16 * wseg, 0), p.cw - 16);
+		u32x4 v[3];
 #pragma unroll
-	for (int i = 0; i < 64; i++)
-		curd[i] = ((const uint32_t *)s_cur)[i];
-
-	// lane task: dx group g = lane % 9 (fixed for the lane, so its 4 dx costs and their
-	// validity are computed once), dy = 7 * round + lane / 9 - 16; lane 63 idles.
-	const int R = p.search_range;
-	uint32_t best = 0xffffffffu;
-	const int g9 = lane % 9, dsub = lane / 9;
-	const int dx0 = 4 * g9 - 16;
-	uint32_t cost_x[4];
-	bool ok_x[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const int dx = dx0 + k;
-		ok_x[k] = lane < 63 && dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
-		cost_x[k] = (uint32_t)(p.lambda * mv_bits(dx)) << 11 | (uint32_t)(dx + 16);
-	}
-	for (int round = 0; round < 5; round++) {
-		const int dyi_raw = 7 * round + dsub;
-		const bool tvalid = dyi_raw < 33;
-		const int dyi = tvalid ? dyi_raw : 32;
-		const int dy = dyi - 16;
-		const uint8_t *base = s_ref + dyi * REF_STRIDE + 4 * g9;
-		// four independent accumulators (one per 4-sample segment) keep the qsad
-		// pipeline full; each lane's 4 x u16 partial SADs are summed afterwards
-		uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-		for (int r = 0; r < 16; r++) {
-			const uint32_t *rp = (const uint32_t *)(base + r * REF_STRIDE);
-			uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3], w4 = rp[4];
-			a0 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w1 << 32) | w0, curd[4 * r + 0], a0);
-			a1 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w2 << 32) | w1, curd[4 * r + 1], a1);
-			a2 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w3 << 32) | w2, curd[4 * r + 2], a2);
-			a3 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w4 << 32) | w3, curd[4 * r + 3], a3);
+		for (int pass = 0; pass < 3; pass++) {
+			const int gy = min(max(y0 - 16 + wrow + 21 * pass, 0), p.ch - 1);
+			v[pass] = *(const u32x4 *)(ref_y + (uint32_t)gy * cw + gx);
 		}
-		// per-u16 sums cannot carry: a full 16x16 SAD is at most 65280
-		const uint64_t acc = (a0 + a1) + (a2 + a3);
-		const bool yok = tvalid && dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
-		// key = cost << 11 | candidate index, index = (dy+16)*33 + dx+16
-		const uint32_t key_y = ((uint32_t)(p.lambda * mv_bits(dy)) << 11) + (uint32_t)((dy + 16) * 33);
+		// chroma: 25 rows x 4 segments; lane -> (row = lane / 4 + 16 * pass, seg = lane % 4)
+		const int crow = lane >> 2, cseg = lane & 3;
+		const uint32_t cgx = (uint32_t)min(max(x0 - 16 + 16 * cseg, 0), p.cw - 16);
+		u32x4 c[2];
+#pragma unroll
+		for (int pass = 0; pass < 2; pass++) {
+			const int gy = min(max(my * 8 - 8 + crow + 16 * pass, 0), (p.ch >> 1) - 1);
+			c[pass] = *(const u32x4 *)(ref_uv + (uint32_t)gy * cw + cgx);
+		}
+		*(u32x4 *)(s_ref + wrow * REF_STRIDE + 16 * wseg) = v[0];
+		*(u32x4 *)(s_ref + (wrow + 21) * REF_STRIDE + 16 * wseg) = v[1];
+		if (wrow < 6) // rows 42..47 (lane 63 repeats lane 62's store)
+			*(u32x4 *)(s_ref + (wrow + 42) * REF_STRIDE + 16 * wseg) = v[2];
+		*(u32x4 *)(s_refc + crow * REFC_STRIDE + 16 * cseg) = c[0];
+		if (crow < 9) // rows 16..24
+			*(u32x4 *)(s_refc + (crow + 16) * REFC_STRIDE + 16 * cseg) = c[1];
+		// (the last dx group reads one dword past row 47: the 64 bytes of slack behind the window)
+	}
+	WAVE_LDS_SYNC();
+
+	// ---- motion search ----
+	// The current macroblock is the same for every lane: its 64 dwords live in scalar registers and
+	// enter v_qsad_pk_u16_u8 as the scalar operand. A lane owns the 4 horizontal offsets
+	// dx = 4 * g - 16 .. + 3 (g = lane % 9) and 5 consecutive vertical ones dy = d0 - 16 .. + 4
+	// (d0 = min(5 * (lane / 9), 28): the last ranges overlap, which a minimum does not mind). It walks
+	// down the 20 window rows its candidates touch ONCE: a row, fetched as four dword pairs at dword
+	// steps (ds_read2_b32: v_qsad wants an even-aligned register pair and gets one without moves),
+	// serves the up to 5 candidates rows it belongs to. 320 v_qsad and 80 LDS reads per lane, against
+	// 320 and 400 for one (dy, 4 dx) task at a time -- and 450 register moves fewer.
+	uint32_t curs[64];
+	{
+		const uint32_t mine = ((const uint32_t *)s_cur)[lane];
+#pragma unroll
+		for (int i = 0; i < 64; i++)
+			curs[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
+	}
+	const int R = p.search_range;
+	const int g9 = lane % 9, j7 = lane / 9;
+	const int d0 = min(5 * j7, 28);
+	uint64_t acc[5] = { 0, 0, 0, 0, 0 };
+	{
+		// Written as volatile asm: left to itself the scheduler hoists all 20 rows to the top (160
+		// registers, two waves per SIMD instead of four) and strings each accumulator's 64 v_qsad into
+		// one dependent chain. Here the next row is in flight while this one is summed, and
+		// consecutive v_qsad feed different accumulators.
+		const uint32_t la = (uint32_t)(uintptr_t)(s_ref + d0 * REF_STRIDE + 4 * g9); // LDS byte address of the lane's first row
+		uint64_t wa[4], wb[4];
+#define INTER_RD(dst, t, k)                                                                         \
+	asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(la), "n"(12 * (t) + (k)), "n"(12 * (t) + (k) + 1))
+#define INTER_RD4(dst, t) INTER_RD(dst[0], t, 0); INTER_RD(dst[1], t, 1); INTER_RD(dst[2], t, 2); INTER_RD(dst[3], t, 3)
+#define INTER_QS(i, src, t, k)                                                                      \
+	if ((t) - (i) >= 0 && (t) - (i) <= 15)                                                      \
+		asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(src[k]), "s"(curs[4 * ((t) - (i)) + (k)]))
+#define INTER_QS5(src, t, k) INTER_QS(0, src, t, k); INTER_QS(1, src, t, k); INTER_QS(2, src, t, k); INTER_QS(3, src, t, k); INTER_QS(4, src, t, k)
+#define INTER_SUM(src, t) INTER_QS5(src, t, 0); INTER_QS5(src, t, 1); INTER_QS5(src, t, 2); INTER_QS5(src, t, 3)
+// rows t (in cur_) and t + 1 (loaded into nxt_ meanwhile); the waits count LDS reads still in flight
+#define INTER_STEP(cur_, nxt_, t)                                                                   \
+	INTER_RD4(nxt_, (t) + 1);                                                                   \
+	asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                         \
+	INTER_SUM(cur_, t)
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // nothing of the compiler's own is in flight from here on
+		INTER_RD4(wa, 0);
+		INTER_STEP(wa, wb, 0); INTER_STEP(wb, wa, 1); INTER_STEP(wa, wb, 2); INTER_STEP(wb, wa, 3);
+		INTER_STEP(wa, wb, 4); INTER_STEP(wb, wa, 5); INTER_STEP(wa, wb, 6); INTER_STEP(wb, wa, 7);
+		INTER_STEP(wa, wb, 8); INTER_STEP(wb, wa, 9); INTER_STEP(wa, wb, 10); INTER_STEP(wb, wa, 11);
+		INTER_STEP(wa, wb, 12); INTER_STEP(wb, wa, 13); INTER_STEP(wa, wb, 14); INTER_STEP(wb, wa, 15);
+		INTER_STEP(wa, wb, 16); INTER_STEP(wb, wa, 17); INTER_STEP(wa, wb, 18);
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		INTER_SUM(wb, 19);
+#undef INTER_STEP
+#undef INTER_SUM
+#undef INTER_QS5
+#undef INTER_QS
+#undef INTER_RD4
+#undef INTER_RD
+	}
+	// per-u16 sums cannot carry: a full 16x16 SAD is at most 65280
+	uint32_t best = 0xffffffffu;
+	{
+		// key = cost << 11 | candidate index, index = (dy+16)*33 + dx+16; a candidate that is not
+		// allowed gets 2^30 on top per axis (a valid key stays below 2^28), so no selects, no branches
+		const int dx0 = 4 * g9 - 16;
+		uint32_t cost_x[4];
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
-			const uint32_t sad = (uint32_t)(acc >> (16 * k)) & 0xffffu;
-			const uint32_t key = (sad << 11) + key_y + cost_x[k];
-			best = (yok && ok_x[k] && key < best) ? key : best;
+			const int dx = dx0 + k;
+			const bool ok = dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
+			cost_x[k] = ((uint32_t)(p.lambda * mv_bits(dx)) << 11 | (uint32_t)(dx + 16)) + (ok ? 0u : 0x40000000u);
+		}
+#pragma unroll
+		for (int i = 0; i < 5; i++) {
+			const int dy = d0 + i - 16;
+			const bool yok = dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
+			const uint32_t key_y = ((uint32_t)(p.lambda * mv_bits(dy)) << 11) + (uint32_t)((dy + 16) * 33) + (yok ? 0u : 0x40000000u);
+			const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+			best = min(best, ((lo & 0xffffu) << 11) + (key_y + cost_x[0]));
+			best = min(best, ((lo >> 16) << 11) + (key_y + cost_x[1]));
+			best = min(best, ((hi & 0xffffu) << 11) + (key_y + cost_x[2]));
+			best = min(best, ((hi >> 16) << 11) + (key_y + cost_x[3]));
 		}
 	}
 	best = wave_min_u32(best);
@@ -270,9 +360,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// ---- residual, transform, quantisation, reconstruction: one lane per SAMPLE ----
 	// 16-lane group = one 4x4 block, transforms across lanes with DPP (enc_device.h):
 	// 4 passes cover the 16 luma blocks, 2 passes the 8 chroma blocks, all 64 lanes busy.
-	for (int i = lane; i < COEF_PER_MB; i += 64)
-		s_coef[i] = 0;
-	__syncthreads();
+	for (int i = lane; i < COEF_PER_MB * 2 / 16; i += 64)
+		((u32x4 *)s_coef)[i] = u32x4{ 0, 0, 0, 0 };
+	WAVE_LDS_SYNC();
 
 	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / 6;
 	const int gq = lane >> 4, l = lane & 15;
@@ -281,38 +371,36 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
 	const int rpos = 4 * kv + kh;             // coefficient (raster) this lane ends up holding
 	const int pclass = (kv & 1) == (kh & 1) ? (kv & 1) : 2;
-	int zz = 0;
-#pragma unroll
-	for (int z = 0; z < 16; z++)
-		zz = kZigzag[z] == rpos ? z : zz;
+	const int zz = zigzag_of(rpos);
 	const int mf_y = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
 	const int dv_y = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
 	const int mf_c = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
 	const int dv_c = pclass == 0 ? p.dvc[0] : pclass == 1 ? p.dvc[1] : p.dvc[2];
 
+	// (counts go to LDS from every lane of a block -- same value, same address, no branch -- and
+	// leave as three 8-byte stores at the end)
 	uint32_t nz_luma = 0; // bit = coding-order block index
+	const uint8_t *predp = s_ref + (16 + bdy) * REF_STRIDE + 16 + bdx;
 #pragma unroll
 	for (int pass = 0; pass < 4; pass++) {
 		const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
 		const int x = 4 * bx + pj, y = 4 * by + pi;
-		const int pv = s_ref[(16 + bdy + y) * REF_STRIDE + 16 + bdx + x];
+		const int pv = predp[y * REF_STRIDE + x];
 		const int res = (int)s_cur[y * 16 + x] - pv;
-		const int w = fdct_lanes(res, ci, cj);
-		const int level = quant1(w, mf_y, f_inter, p.qbits);
+		const int w = fdct_lanes24(res, ci, cj);
+		const int level = quant24(w, mf_y, f_inter, p.qbits);
 		s_coef[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
-		const int r = idct_lanes((level * dv_y) << p.qshift, ci, cj);
-		s_recy[y * 16 + x] = (uint8_t)clip255(pv + r);
+		const int rr = idct_lanes24(__mul24(level, dv_y) << p.qshift, ci, cj);
+		s_recy[y * 16 + x] = (uint8_t)clip255(pv + rr);
 		const uint64_t bal = __ballot(level != 0);
-		const int nn = __popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
-		if (l == 0)
-			p.nnz[mbaddr * NNZ_PER_MB + bx + 4 * by] = (uint8_t)nn;
+		s_nnz[bx + 4 * by] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 			nz_luma |= ((uint32_t)(bal >> (16 * k)) & 0xffffu) ? (1u << (4 * pass + k)) : 0u;
 	}
 	// chroma: pass = plane, group = block (raster 2x2)
 	const int ix = bdx >> 1, iy = bdy >> 1, fx = (bdx & 1) * 4, fy = (bdy & 1) * 4;
-	int cpv[2], cdq[2];
+	int cpv[2], cdq[2], dcw[2][4];
 	uint32_t nz_cac = 0;
 #pragma unroll
 	for (int c = 0; c < 2; c++) {
@@ -324,61 +412,65 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		const int C = s_refc[wr1 * REFC_STRIDE + 2 * wc + c], D = s_refc[wr1 * REFC_STRIDE + 2 * wc1 + c];
 		cpv[c] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
 		const int res = (int)s_curc[y * 16 + 2 * x + c] - cpv[c];
-		const int w = fdct_lanes(res, ci, cj);
-		if (l == 0)
-			s_dc[4 * c + gq] = w; // lane (0,0) holds the DC coefficient
-		const int level = l == 0 ? 0 : quant1(w, mf_c, f_inter_c, p.qbits_c);
-		if (l != 0)
-			s_coef[COEF_CAC + (4 * c + gq) * 16 + zz] = (int16_t)level;
-		cdq[c] = (level * dv_c) << p.qshift_c;
+		const int w = fdct_lanes24(res, ci, cj);
+		// lane (0,0) of a group holds its DC coefficient: the four of a plane become wave-uniform
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			dcw[c][k] = __builtin_amdgcn_readlane(w, 16 * k);
+		const int level = l == 0 ? 0 : quant24(w, mf_c, f_inter_c, p.qbits_c);
+		s_coef[COEF_CAC + (4 * c + gq) * 16 + zz] = (int16_t)level; // (entry 0 of a block is unused: lane 0 writes its 0 there)
+		cdq[c] = __mul24(level, dv_c) << p.qshift_c;
 		const uint64_t bal = __ballot(level != 0);
-		const int nn = __popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
-		if (l == 0)
-			p.nnz[mbaddr * NNZ_PER_MB + 16 + 4 * c + gq] = (uint8_t)nn;
+		s_nnz[16 + 4 * c + gq] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 		nz_cac |= bal ? 1u : 0u;
 	}
-	__syncthreads();
-	int dc_level_nz = 0;
-	if (lane < 8) { // 2x2 Hadamard of the chroma DCs: lane = (plane, output index)
-		const int c = lane >> 2, blk = lane & 3;
-		const int *dcs = s_dc + 4 * c;
+	// 2x2 Hadamard of the chroma DCs on lanes 0..7 = (plane, output index); the quantised four of a
+	// plane become wave-uniform again for the inverse
+	int lqv;
+	{
+		const int c = (lane >> 2) & 1, blk = lane & 3;
+		const int d0c = c ? dcw[1][0] : dcw[0][0], d1c = c ? dcw[1][1] : dcw[0][1];
+		const int d2c = c ? dcw[1][2] : dcw[0][2], d3c = c ? dcw[1][3] : dcw[0][3];
 		const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
-		const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
-		const int lq = quant1(hd, p.mfc[0], 2 * f_inter_c, p.qbits_c + 1);
-		s_cdc[lane] = lq;
-		s_coef[COEF_CDC + lane] = (int16_t)lq;
-		dc_level_nz = lq != 0;
+		const int hd = d0c + s1 * d1c + s2 * d2c + s1 * s2 * d3c;
+		lqv = quant1(hd, p.mfc[0], 2 * f_inter_c, p.qbits_c + 1);
 	}
-	__syncthreads();
+	if (lane < 8)
+		s_coef[COEF_CDC + lane] = (int16_t)lqv;
+	const uint64_t dcmask = __ballot(lqv != 0) & 0xffull;
+	int lqs[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		lqs[k] = __builtin_amdgcn_readlane(lqv, k);
 #pragma unroll
 	for (int c = 0; c < 2; c++) {
 		const int bx = gq & 1, by = gq >> 1;
 		const int x = 4 * bx + pj, y = 4 * by + pi;
-		const int *ls = s_cdc + 4 * c;
 		const int s1 = (gq & 1) ? -1 : 1, s2 = (gq & 2) ? -1 : 1;
-		const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
+		const int fd = lqs[4 * c] + s1 * lqs[4 * c + 1] + s2 * lqs[4 * c + 2] + s1 * s2 * lqs[4 * c + 3];
 		const int dcr = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
-		const int r = idct_lanes(l == 0 ? dcr : cdq[c], ci, cj);
-		s_recc[y * 16 + 2 * x + c] = (uint8_t)clip255(cpv[c] + r);
+		const int rr = idct_lanes24(l == 0 ? dcr : cdq[c], ci, cj);
+		s_recc[y * 16 + 2 * x + c] = (uint8_t)clip255(cpv[c] + rr);
 	}
 	// coded block pattern
-	const uint64_t dcmask = __ballot(dc_level_nz != 0);
 	int cbp = 0;
 #pragma unroll
-	for (int q = 0; q < 4; q++)
-		cbp |= ((nz_luma >> (4 * q)) & 0xfu) ? (1 << q) : 0;
+	for (int qd = 0; qd < 4; qd++)
+		cbp |= ((nz_luma >> (4 * qd)) & 0xfu) ? (1 << qd) : 0;
 	cbp |= nz_cac ? 0x20 : (dcmask ? 0x10 : 0);
-	__syncthreads();
+	WAVE_LDS_SYNC();
 
 	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
 	if (lane < COEF_PER_MB * 2 / 16)
 		*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)s_coef + lane * 16);
 	if (lane < 16)
-		*(u32x4 *)(rec_y + (size_t)lane * p.cw) = *(const u32x4 *)(s_recy + lane * 16);
+		*(u32x4 *)(rec_y + (uint32_t)lane * cw) = *(const u32x4 *)(s_recy + lane * 16);
 	else if (lane < 24)
-		*(u32x4 *)(rec_uv + (size_t)(lane - 16) * p.cw) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
-	if (lane < 16)
-		p.i4modes[mbaddr * 16 + lane] = 2;
+		*(u32x4 *)(rec_uv + (uint32_t)(lane - 16) * cw) = *(const u32x4 *)(s_recc + (lane - 16) * 16);
+	if (lane < 3)
+		*(uint64_t *)(p.nnz + mbaddr * NNZ_PER_MB + 8 * lane) = *(const uint64_t *)(s_nnz + 8 * lane);
+	if (lane == 4)
+		*(u32x4 *)(p.i4modes + mbaddr * 16) = u32x4{ 0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u };
 	if (lane == 0) {
 		MbInfo m;
 		m.type = MB_P16x16;

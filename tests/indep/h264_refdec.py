@@ -341,6 +341,7 @@ class Decoder:
         self.slice_no = 0
         self.deblock_idc = []      # per slice: (idc, alpha offset, beta offset)
         self.pending = False       # a picture is being decoded (slices seen, not finished)
+        self.max_mb_bits = 0       # the largest macroblock_layer() seen, in bits
         self.next_mb = 0
 
     # ---------------- parameter sets ----------------
@@ -495,7 +496,9 @@ class Decoder:
                     break
             if addr >= n_mb:
                 raise SyntaxError264("macroblock data past the end of the picture")
+            pos0 = b.pos
             self._macroblock(b, addr, is_p)
+            self.max_mb_bits = max(self.max_mb_bits, b.pos - pos0)   # A.3.1: macroblock_layer() <= 3200 bits
             addr += 1
             more = b.more_rbsp_data()
         self.next_mb = addr
