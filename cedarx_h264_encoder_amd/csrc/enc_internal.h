@@ -32,6 +32,7 @@ constexpr int COEF_CAC = 280;
 constexpr int COEF_PER_MB = 408;  // 816 bytes = 51 x 16 B
 
 constexpr int NNZ_PER_MB = 24;    // 16 luma (raster bx+4*by), 4 Cb, 4 Cr
+constexpr int MB_BITS_LIMIT = 3200; // H.264 A.3.1: bits of one macroblock_layer()
 constexpr int SLOT_BYTES = 2048;  // private CAVLC bit buffer of one macroblock
 constexpr int SLOT_WORDS = SLOT_BYTES / 4;
 constexpr int ESC_CHUNK = 32;     // bytes of RBSP per emulation-prevention thread

@@ -367,6 +367,8 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 	p.skip[mbaddr] = (uint8_t)skip;
 	if (b.overflow)
 		atomicOr(&p.stream_size[p.n_streams + 1], 1u);
+	if (total > MB_BITS_LIMIT) // H.264 A.3.1; the session counts or refuses the picture
+		atomicOr(&p.stream_size[p.n_streams + 1], 4u);
 }
 
 // ------------------------------------------------------------------------
@@ -705,6 +707,8 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 		}
 		if (b.overflow || (hl == 0 && nwords + 1 >= SLOT_WORDS))
 			atomicOr(&p.stream_size[p.n_streams + 1], 1u);
+		if (hl == 0 && total > MB_BITS_LIMIT)
+			atomicOr(&p.stream_size[p.n_streams + 1], 4u);
 	}
 }
 

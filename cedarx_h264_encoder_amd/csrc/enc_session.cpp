@@ -784,6 +784,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "chroma_qp_index_offset %d outside -12..12", e->chroma_qp_offset);
 	if (ext.aud != 0 && ext.aud != 1)
 		return fail(e, -EINVAL, "aud must be 0 or 1");
+	if (ext.strict_mb_bits != 0 && ext.strict_mb_bits != 1)
+		return fail(e, -EINVAL, "strict_mb_bits must be 0 or 1");
 	if (mb_h > 512 * ext.slice_count)
 		return fail(e, -EINVAL, "picture too tall for one slice");
 	if (ext.first_frame_index < 0 || ext.first_frame_index % cfg->keyframe_interval)
@@ -1796,7 +1798,12 @@ static int collect_frame(cedar_enc *e)
 		too_big = too_big || sz[n] > (size_t)n * e->stream_out_cap;
 	}
 	const uint32_t wf_err = *f.h_wf_err;
-	if (hip_failed || wf_err || flags || too_big) {
+	// flag 4: a macroblock of more than 3200 bits (H.264 A.3.1). Counted, or -- strict_mb_bits -- refused
+	const bool oversize = (flags & 4u) != 0;
+	flags &= ~4u;
+	if (oversize && !e->ext.strict_mb_bits)
+		e->stats.oversize_frames++;
+	if (hip_failed || wf_err || flags || too_big || (oversize && e->ext.strict_mb_bits)) {
 		// this frame is dropped, the session is where it was before it, the frames behind it run again
 		const int rc = recover(e, f);
 		if (rc)
@@ -1805,6 +1812,8 @@ static int collect_frame(cedar_enc *e)
 			return fail(e, -EIO, "the device reported an error for this frame");
 		if (wf_err)
 			return fail(e, -EIO, "wavefront hand-off timed out (flags %u)", wf_err);
+		if (oversize && !flags && !too_big)
+			return fail(e, -EOVERFLOW, "a macroblock exceeds 3200 bits (H.264 A.3.1): raise the QP");
 		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
 	}
 	for (int c = 0; c < C; c++) {
@@ -1914,7 +1923,7 @@ static int mux_collect_step(cedar_enc *e)
 		}
 		m.out_rc[(size_t)(n % m.cap)] = rc >= 0 ? total : rc;
 	}
-	return rc < 0 && rc != -EIO && rc != -ENOSPC ? rc : 0; // a dropped step is reported per frame
+	return rc < 0 && rc != -EIO && rc != -ENOSPC && rc != -EOVERFLOW ? rc : 0; // a dropped step is reported per frame
 }
 
 static int mux_submit(cedar_enc *e)

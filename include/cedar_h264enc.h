@@ -104,7 +104,11 @@ struct cedar_enc_config_ext {
 				n is delivered once frame n + (G-1)*keyframe_interval has been submitted (or
 				after cedar_enc_flush). cedar_enc_session_depth() says how many frames the
 				caller may have in flight. 0 / 1: off                                    */
-	int reserved[2];
+	int strict_mb_bits;  /* H.264 A.3.1 allows a macroblock 3200 bits; pure noise at QP <= 16 passes that
+				(no I_PCM fallback exists yet). 0: such a picture is emitted as it is and
+				counted (cedar_enc_stats.oversize_frames); 1: it fails with -EOVERFLOW and is
+				dropped like any failed frame                                            */
+	int reserved[1];
 };
 
 typedef struct cedar_enc cedar_enc;
@@ -196,6 +200,7 @@ struct cedar_enc_stats {
 	int      idr_lookahead;                  /* 1: IDR pictures run on streams of their own        */
 	int      depth;                          /* frames in flight this session allows               */
 	int      deblock_streams;                /* deblock streams in use                             */
+	uint64_t oversize_frames;                /* frames with a macroblock above 3200 bits (A.3.1)   */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */

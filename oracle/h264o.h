@@ -46,6 +46,8 @@ typedef struct h264o_config {
 	int fps_num, fps_den; /* both > 0: the SPS carries VUI timing (fixed frame rate fps_num/fps_den)
 	                       * and a bitstream restriction (no reordering, 1 reference frame);
 	                       * the reference writes vui_parameters_present_flag = 0 (cedar.c:933) */
+	int strict_mb_bits;   /* 1: a picture with a macroblock_layer() of more than 3200 bits (H.264 A.3.1) is
+	                       * refused with -EOVERFLOW instead of emitted; 0: emitted and counted */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */
@@ -87,6 +89,7 @@ const h264o_mb *h264o_mbs(const h264o_enc *e);
 const uint8_t *h264o_recon_luma(const h264o_enc *e);
 const uint8_t *h264o_recon_chroma(const h264o_enc *e);
 int h264o_last_frame_type(const h264o_enc *e); /* 1 = IDR, 0 = P */
+int h264o_max_mb_bits(const h264o_enc *e);     /* largest macroblock_layer() of the last frame, in bits */
 
 /* stand-alone pieces exported for known-answer tests */
 int h264o_write_sps(const h264o_config *cfg, uint8_t *out, int cap);

@@ -36,6 +36,8 @@ struct h264o_enc {
 	int cur; /* index of reference_current (cedar.c:117-119) */
 	h264o_mb *mbs;
 	int last_idr;
+	int closed_loop; /* env H264O_CLOSED_LOOP_INTRA=1 (tools/rd_record.py only): intra modes decided on reconstructed neighbours */
+	int max_mb_bits; /* largest macroblock_layer() of the last frame (A.3.1: at most 3200 bits) */
 	uint8_t cbp_code_intra[48], cbp_code_inter[48];
 	uint8_t *rbsp; /* scratch for one slice's RBSP */
 	int rbsp_cap;
@@ -895,7 +897,9 @@ static int sad_block(const uint8_t *a, int sa, const uint8_t *b, int sb, int w, 
 static void intra_decide_mb(h264o_enc *e, int mx, int my, int row0)
 {
 	h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
-	const uint8_t *sy = e->src_y, *suv = e->src_uv;
+	/* (closed_loop: the planes the decision reads are the reconstruction with this macroblock's
+	 * source samples laid in, see h264o_encode -- a measurement of what the open loop costs) */
+	const uint8_t *sy = e->closed_loop ? e->rec_y[e->cur] : e->src_y, *suv = e->closed_loop ? e->rec_uv[e->cur] : e->src_uv;
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
 	int top_mb = my > row0, left_mb = mx > 0;
 	int idx, mode, sum4 = 0, best16 = -1, best16_sad = 0;
@@ -1682,6 +1686,7 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 	e->ch = ALIGN16(cfg->height);
 	e->mb_w = e->cw / 16;
 	e->mb_h = e->ch / 16;
+	e->closed_loop = getenv("H264O_CLOSED_LOOP_INTRA") != NULL && atoi(getenv("H264O_CLOSED_LOOP_INTRA")) != 0;
 	e->src_y = malloc((size_t)e->cw * e->ch);
 	e->src_uv = malloc((size_t)e->cw * e->ch / 2);
 	for (i = 0; i < 2; i++) {
@@ -1733,6 +1738,7 @@ const h264o_mb *h264o_mbs(const h264o_enc *e) { return e->mbs; }
 const uint8_t *h264o_recon_luma(const h264o_enc *e) { return e->rec_y[e->cur ^ 1]; }
 const uint8_t *h264o_recon_chroma(const h264o_enc *e) { return e->rec_uv[e->cur ^ 1]; }
 int h264o_last_frame_type(const h264o_enc *e) { return e->last_idr; }
+int h264o_max_mb_bits(const h264o_enc *e) { return e->max_mb_bits; }
 
 static void pad_source(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma)
 {
@@ -1758,6 +1764,7 @@ static void pad_source(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma)
 
 int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8_t *out, int out_cap)
 {
+	int max_mb_bits = 0, ue_bits_of_run = 0;
 	int idr = e->frame_p_count == 0; /* cedar.c:1047-1050 */
 	int o = 0, s, mx, my, r;
 	int idr_pic_id = (e->frame_count / e->cfg.keyint) & 1;
@@ -1786,7 +1793,23 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 		int r0, r1;
 
 		slice_rows(e, s, &r0, &r1);
-		if (idr) {
+		if (idr && e->closed_loop) {
+			/* NOT the encoder policy (the decision is open loop so that it is
+			 * macroblock-parallel): decide every macroblock on its reconstructed neighbours, in order */
+			for (my = r0; my < r1; my++)
+				for (mx = 0; mx < e->mb_w; mx++) {
+					int y;
+
+					for (y = 0; y < 16; y++)
+						memcpy(e->rec_y[e->cur] + (size_t)(my * 16 + y) * e->cw + mx * 16,
+						       e->src_y + (size_t)(my * 16 + y) * e->cw + mx * 16, 16);
+					for (y = 0; y < 8; y++)
+						memcpy(e->rec_uv[e->cur] + (size_t)(my * 8 + y) * e->cw + mx * 16,
+						       e->src_uv + (size_t)(my * 8 + y) * e->cw + mx * 16, 16);
+					intra_decide_mb(e, mx, my, r0);
+					intra_recon_mb(e, mx, my, r0);
+				}
+		} else if (idr) {
 			for (my = r0; my < r1; my++)
 				for (mx = 0; mx < e->mb_w; mx++)
 					intra_decide_mb(e, mx, my, r0);
@@ -1830,9 +1853,12 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 		for (my = r0; my < r1; my++)
 			for (mx = 0; mx < e->mb_w; mx++) {
 				const h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
+				const uint64_t mb_start = b.pos;
 
 				if (idr) {
 					write_intra_mb(e, &b, mb, mx, my, r0, 0);
+					if ((int)(b.pos - mb_start) > max_mb_bits)
+						max_mb_bits = (int)(b.pos - mb_start);
 					continue;
 				}
 				if (mb->type == H264O_MB_PSKIP) {
@@ -1840,6 +1866,7 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 					continue;
 				}
 				bw_ue(&b, (uint32_t)skip_run);
+				ue_bits_of_run = (int)(b.pos - mb_start);
 				skip_run = 0;
 				{
 					int px, py, skx, sky;
@@ -1853,12 +1880,19 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 						bw_se(&b, 0); /* mb_qp_delta */
 					write_residual(e, &b, mb, mx, my, r0);
 				}
+				/* macroblock_layer() only: mb_skip_run belongs to slice_data() */
+				if ((int)(b.pos - mb_start) - ue_bits_of_run > max_mb_bits)
+					max_mb_bits = (int)(b.pos - mb_start) - ue_bits_of_run;
 			}
 		if (!idr && skip_run)
 			bw_ue(&b, (uint32_t)skip_run);
 		bw_trailing(&b);
 		if (b.overflow)
 			return -ENOSPC;
+		/* H.264 A.3.1: no macroblock_layer() above 3200 bits. No I_PCM fallback exists yet: the picture is
+		 * refused when asked to be strict (state untouched, as for any failed frame), else emitted */
+		if (max_mb_bits > 3200 && e->cfg.strict_mb_bits)
+			return -EOVERFLOW;
 		r = nal_write(out + o, out_cap - o, idr ? 3 : 2, idr ? 5 : 1, e->rbsp, (int)(b.pos >> 3));
 		if (r < 0)
 			return r;
@@ -1866,6 +1900,7 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 	}
 
 	/* cedar.c:1193-1201 */
+	e->max_mb_bits = max_mb_bits;
 	e->last_idr = idr;
 	e->frame_p_count++;
 	if (e->frame_p_count == e->cfg.keyint)

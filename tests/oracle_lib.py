@@ -18,7 +18,8 @@ MB_I4x4, MB_I16x16, MB_P16x16, MB_PSKIP = 0, 1, 2, 3
 class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
-        "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den")]
+        "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
+        "strict_mb_bits")]
 
 
 class MB(ctypes.Structure):
@@ -60,6 +61,7 @@ def lib():
         L.h264o_recon_chroma.restype = vp
         L.h264o_recon_chroma.argtypes = [vp]
         L.h264o_last_frame_type.argtypes = [vp]
+        L.h264o_max_mb_bits.argtypes = [vp]
         L.h264o_write_sps.argtypes = [ctypes.POINTER(Config), vp, ci]
         L.h264o_write_pps.argtypes = [ctypes.POINTER(Config), vp, ci]
         L.h264o_write_aud.argtypes = [ci, vp, ci]
@@ -132,6 +134,10 @@ class OracleEncoder:
         if n < 0:
             raise OSError(-n, os.strerror(-n))
         return self.out[:n].tobytes()
+
+    def max_mb_bits(self):
+        """largest macroblock_layer() of the last frame, in bits (H.264 A.3.1 allows 3200)"""
+        return lib().h264o_max_mb_bits(self.h)
 
     def recon(self):
         y = _view(lib().h264o_recon_luma(self.h), (self.ch, self.cw)).copy()

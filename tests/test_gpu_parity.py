@@ -601,6 +601,45 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
         assert sh.hexdigest() == c["stream_sha1"], c["case"]
 
 
+def test_macroblocks_above_3200_bits_are_counted_or_refused(ce):
+    """H.264 A.3.1: a macroblock_layer() may take 3200 bits. Pure noise at a low QP passes that (measured
+    with the independent decoder: up to QP 16) and there is no I_PCM fallback yet. The path detects
+    it: by default the picture is emitted and counted, with strict_mb_bits it fails with EOVERFLOW and
+    is dropped like any failed frame (GOP state untouched) -- the oracle does the same."""
+    from tests.indep import h264_refdec as rd
+    w, h = 64, 48
+    frames = [ol.gen_frame("C", w, h, f) for f in range(3)] + [ol.gen_frame("A", w, h, 3)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=1))
+    dec = rd.Decoder()
+    with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=1) as enc:
+        for y, uv in frames:
+            au = enc.encode_frame(y, uv)
+            assert au == oe.encode(y, uv)
+            dec.decode(au)
+        assert dec.max_mb_bits > 3200 and oe.max_mb_bits() <= 3200   # the noise frames pass it, the flat last one does not
+        assert enc.stats()["oversize_frames"] == 3
+    os_ = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=1, strict_mb_bits=1))
+    with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=1, strict_mb_bits=1) as enc:
+        for y, uv in frames[:3]:
+            with pytest.raises(ce.EncoderError) as ex:
+                enc.encode_frame(y, uv)
+            assert ex.value.errno == errno.EOVERFLOW
+            with pytest.raises(OSError) as ex2:
+                os_.encode(y, uv)
+            assert ex2.value.errno == errno.EOVERFLOW
+        au = enc.encode_frame(*frames[3])              # still frame 0 of the stream: SPS + PPS + IDR
+        assert au == os_.encode(*frames[3])
+        d2 = rd.Decoder()
+        d2.decode(au)
+        assert d2.max_mb_bits <= 3200 and d2.pictures == 1
+    # at the QPs of the BASELINE configs not even noise comes near the limit
+    dq = rd.Decoder()
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=1, strict_mb_bits=1) as enc:
+        for y, uv in frames[:3]:
+            dq.decode(enc.encode_frame(y, uv))
+    assert 0 < dq.max_mb_bits <= 3200
+
+
 def test_failed_encode_is_retryable_on_the_same_session(ce, monkeypatch):
     """cedar.c:1182-1191 return before the GOP counter and the reference swap (:1193-1201): the caller
     may simply call ENCODE again. Here the failed attempt leaves completion words, progress words and
