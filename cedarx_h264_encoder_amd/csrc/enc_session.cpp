@@ -155,6 +155,7 @@ struct InFlight {
 	std::vector<uint8_t> in_own;
 	std::vector<long> lane_gidx; // [n_streams] global frame index per lock-step lane (-1: idle lane)
 	bool gop_start = false;      // gop_parallel: every lane starts a GOP with this step, whatever the counter says
+	int qp = 0;                  // the picture's QP
 	int lane = 0;          // entropy lane
 	hipStream_t s_db = nullptr, s_ent = nullptr; // the streams that carry this frame's deblocking / entropy coding
 	bool events = true;    // done_main / done_ent were recorded (frames not pipelined)
@@ -211,6 +212,9 @@ struct cedar_enc {
 	std::vector<long> lane_gidx; // [n_streams] global frame index of the next frame, per lane (mux sessions set it per step)
 	bool next_gop_start = false; // gop_parallel: the next submit starts a GOP on every lane
 	uint32_t fault_at = 0;       // tests (CEDAR_FAULT_INJECT_AT)
+	int64_t rc_bits[64] = {};    // rate control: bits of the access unit of frame (index % 64) ...
+	int rc_qp[64] = {};          // ... and the QP it was coded at
+	int64_t rc_target = 0;       // bits per frame (0: fixed QP)
 	int cohorts = 1;             // big batches go through the stages in this many groups of streams (submit_frame)
 	size_t stream_out_cap = 0;   // bytes of output per stream: cohort c packs its streams from (first stream) x this on
 	int cur = 0; // reconstruction buffer being written (cedar.c:117-119)
@@ -550,7 +554,7 @@ void build_sps_pps(cedar_enc *e)
 }
 
 // slice header bits (cedar.c:984-1030)
-SliceHdr build_slice_header(const cedar_enc *e, bool idr, int frame_num, int idr_pic_id, int first_mb)
+SliceHdr build_slice_header(const cedar_enc *e, bool idr, int frame_num, int idr_pic_id, int first_mb, int qp_delta)
 {
 	BitWriter b;
 	b.ue((uint32_t)first_mb);   // reference: always 0 (cedar.c:992-993)
@@ -566,7 +570,7 @@ SliceHdr build_slice_header(const cedar_enc *e, bool idr, int frame_num, int idr
 		b.put(0, 1);
 		b.put(0, 1);
 	}
-	b.se(0);                                  // slice_qp_delta
+	b.se(qp_delta);                           // slice_qp_delta: 0 at fixed QP (cedar.c:1021-1022)
 	b.ue(e->ext.slice_count > 1 ? 2 : 0);     // disable_deblocking_filter_idc
 	b.se(0);
 	b.se(0);
@@ -577,6 +581,63 @@ SliceHdr build_slice_header(const cedar_enc *e, bool idr, int frame_num, int idr
 		v = (v << 1) | ((b.buf[i >> 3] >> (7 - (i & 7))) & 1);
 	h.bits = v;
 	return h;
+}
+
+// everything of Params that follows from the picture's QP (PARA1 in the reference, cedar.c:1165-1168:
+// one fixed QP; with rate control one per picture)
+void set_qp_params(Params &P, int qp, int chroma_qp_offset)
+{
+	P.qp = qp;
+	int qi = qp + chroma_qp_offset;
+	P.qpc = kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi];
+	P.lambda = lambda_of_qp(qp);
+	for (int k = 0; k < 3; k++) {
+		P.mf[k] = kQuantMF[P.qp % 6][k];
+		P.dv[k] = kDequantV[P.qp % 6][k];
+		P.mfc[k] = kQuantMF[P.qpc % 6][k];
+		P.dvc[k] = kDequantV[P.qpc % 6][k];
+		P.tc0_y[k] = kTc0[P.qp][k];
+		P.tc0_c[k] = kTc0[P.qpc][k];
+	}
+	P.qbits = 15 + P.qp / 6;
+	P.qshift = P.qp / 6;
+	P.qbits_c = 15 + P.qpc / 6;
+	P.qshift_c = P.qpc / 6;
+	P.alpha_y = kAlpha[P.qp];
+	P.beta_y = kBeta[P.qp];
+	P.alpha_c = kAlpha[P.qpc];
+	P.beta_c = kBeta[P.qpc];
+}
+
+// ---- frame-level rate control (cedar_enc_config_ext.bitrate; the scalar twin is oracle/h264o_enc.c
+// rc_pick_qp). Integer only: frame n looks at the sizes of frames <= n - 1 - RC_LAG (collected whatever
+// the caller's pipelining: a session keeps at most RC_LAG frames in flight), over the last keyint of
+// them; each is scaled to the configured QP by "6 QP steps halve the bits" (Q16); the new QP is the
+// lowest one at which that model predicts no more than the target.
+constexpr int RC_LAG = CEDAR_ENC_PIPELINE_DEPTH;
+
+int64_t rc_pow2_6_q16(int d) // 2^(d/6) in Q16
+{
+	static const int64_t t[6] = { 65536, 73562, 82570, 92682, 104032, 116772 };
+	const int q = d >= 0 ? d / 6 : -((-d + 5) / 6), r = d - 6 * q;
+	return q >= 0 ? t[r] << q : t[r] >> -q;
+}
+
+int rc_pick_qp(int qp0, int64_t target, const int64_t *bits, const int *qps, long n, int keyint)
+{
+	const long known = n - RC_LAG;
+	if (known <= 0 || target <= 0)
+		return qp0;
+	const long w = known < keyint ? known : keyint;
+	int64_t sum = 0;
+	for (long i = known - w; i < known; i++)
+		sum += (bits[i & 63] * rc_pow2_6_q16(qps[i & 63] - qp0)) >> 16;
+	const int64_t avg = sum / w;
+	int d = -46;
+	while (d < 46 && rc_pow2_6_q16(d) * target < (avg << 16))
+		d++;
+	const int qp = qp0 + d;
+	return qp < 1 ? 1 : qp > 47 ? 47 : qp;
 }
 
 void fill_static_params(cedar_enc *e)
@@ -600,27 +661,8 @@ void fill_static_params(cedar_enc *e)
 	slice_rows(P.mb_h, P.slice_count, P.slice_first + P.slice_num - 1, &q0, &q1);
 	P.row_first = r0;
 	P.row_num = q1 - r0;
-	P.qp = c.qp;
-	int qi = c.qp + e->chroma_qp_offset;
-	P.qpc = kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi];
 	P.search_range = e->ext.search_range;
-	P.lambda = lambda_of_qp(c.qp);
-	for (int k = 0; k < 3; k++) {
-		P.mf[k] = kQuantMF[P.qp % 6][k];
-		P.dv[k] = kDequantV[P.qp % 6][k];
-		P.mfc[k] = kQuantMF[P.qpc % 6][k];
-		P.dvc[k] = kDequantV[P.qpc % 6][k];
-		P.tc0_y[k] = kTc0[P.qp][k];
-		P.tc0_c[k] = kTc0[P.qpc][k];
-	}
-	P.qbits = 15 + P.qp / 6;
-	P.qshift = P.qp / 6;
-	P.qbits_c = 15 + P.qpc / 6;
-	P.qshift_c = P.qpc / 6;
-	P.alpha_y = kAlpha[P.qp];
-	P.beta_y = kBeta[P.qp];
-	P.alpha_c = kAlpha[P.qpc];
-	P.beta_c = kBeta[P.qpc];
+	set_qp_params(P, c.qp, e->chroma_qp_offset);
 }
 
 double now_ms()
@@ -786,6 +828,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "aud must be 0 or 1");
 	if (ext.strict_mb_bits != 0 && ext.strict_mb_bits != 1)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0 or 1");
+	if (ext.bitrate < 0 || (ext.bitrate > 0 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count)))
+		return fail(e, -EINVAL, "rate control wants one stream, whole pictures, no GOP lanes");
 	if (mb_h > 512 * ext.slice_count)
 		return fail(e, -EINVAL, "picture too tall for one slice");
 	if (ext.first_frame_index < 0 || ext.first_frame_index % cfg->keyframe_interval)
@@ -1205,6 +1249,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		e->fault_at = env ? (uint32_t)atoi(env) : 0;
 	}
 
+	e->rc_target = ext.bitrate > 0 ? (int64_t)ext.bitrate * (ext.fps_num > 0 ? ext.fps_den : 1) / (ext.fps_num > 0 ? ext.fps_num : 30) : 0;
 	build_sps_pps(e);
 	e->frame_count = 0; // cedar.c:815-816
 	e->frame_p_count = 0;
@@ -1381,6 +1426,10 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	f.done_tag = seq;
 	Params P = e->P;
 	P.is_idr = idr;
+	if (e->rc_target > 0)
+		set_qp_params(P, rc_pick_qp(e->cfg.qp, e->rc_target, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyframe_interval),
+			      e->chroma_qp_offset);
+	f.qp = P.qp;
 	if (e->fault_at && seq != e->fault_at) // tests: lose the hand-off of one chosen submit only
 		P.fault_inject = 0;
 	P.rec_y = e->d_rec_y[e->cur];
@@ -1510,7 +1559,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		for (int k = 0; k < e->ext.slice_num; k++) {
 			int r0, r1;
 			slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
-			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, (int)(gop & 1), r0 * P.mb_w);
+			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, (int)(gop & 1), r0 * P.mb_w, P.qp - e->cfg.qp);
 		}
 		// cedar.c:1058-1061: SPS + PPS in front of the stream's first picture (the IDR picture of GOP 0)
 		f.with_ps[s] = idr && (gop == 0 || e->ext.repeat_headers) && e->ext.slice_first == 0;
@@ -1836,6 +1885,9 @@ static int collect_frame(cedar_enc *e)
 	}
 	e->res_host = f.host_out;
 	e->last_total = total;
+	e->rc_bits[f.before.frame_count & 63] = (int64_t)total * 8;
+	e->rc_qp[f.before.frame_count & 63] = f.qp;
+	e->stats.frame_qp = f.qp;
 	if (e->profiling) {
 		static const char *const stage_name[CEDAR_ENC_STAGE_COUNT] = { "input", "intra_decide", "intra_recon", "inter", "deblock", "entropy" };
 		const bool timeline = e->ev_base && getenv("CEDAR_TRACE_TIMELINE");

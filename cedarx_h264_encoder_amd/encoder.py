@@ -42,7 +42,7 @@ class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-        "gop_parallel", "strict_mb_bits")] + [("reserved", ctypes.c_int * 1)]
+        "gop_parallel", "strict_mb_bits", "bitrate")]
 
 
 class _Stats(ctypes.Structure):
@@ -50,7 +50,7 @@ class _Stats(ctypes.Structure):
                 ("ms", ctypes.c_double * 6), ("encode_wall_ms", ctypes.c_double),
                 ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int),
                 ("frames_pipelined", ctypes.c_int), ("idr_lookahead", ctypes.c_int), ("depth", ctypes.c_int),
-                ("deblock_streams", ctypes.c_int), ("oversize_frames", ctypes.c_uint64)]
+                ("deblock_streams", ctypes.c_int), ("oversize_frames", ctypes.c_uint64), ("frame_qp", ctypes.c_int)]
 
 
 _lib = None
@@ -165,6 +165,7 @@ class EncoderConfig:
     first_frame_index: int = 0  # global index of this session's first frame (a multiple of keyframe_interval)
     gop_parallel: int = 0       # G > 1: G consecutive closed GOPs of every stream are encoded side by side
     strict_mb_bits: int = 0     # 1: a picture with a macroblock above 3200 bits fails with EOVERFLOW
+    bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
 
 
 class CedarEncoder:
@@ -193,7 +194,7 @@ class CedarEncoder:
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-                  "gop_parallel", "strict_mb_bits"):
+                  "gop_parallel", "strict_mb_bits", "bitrate"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")
@@ -277,7 +278,7 @@ class CedarEncoder:
         return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms, "wf_split": s.wf_split,
                 "deblock_planes_split": bool(s.deblock_planes_split),
                 "frames_pipelined": bool(s.frames_pipelined), "idr_lookahead": bool(s.idr_lookahead),
-                "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames,
+                "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames, "frame_qp": s.frame_qp,
                 "ms": {n: s.ms[i] for i, n in enumerate(STAGES)},
                 "launches": {n: s.launches[i] for i, n in enumerate(STAGES)}}
 

@@ -108,7 +108,14 @@ struct cedar_enc_config_ext {
 				(no I_PCM fallback exists yet). 0: such a picture is emitted as it is and
 				counted (cedar_enc_stats.oversize_frames); 1: it fails with -EOVERFLOW and is
 				dropped like any failed frame                                            */
-	int reserved[1];
+	int bitrate;         /* > 0: frame-level rate control towards this many bits per second (at fps_num /
+				fps_den, 30 frames/s when unset). The VE has rate-control registers the
+				reference never programs (cedar_regs.h:43-53); here every
+				picture gets one QP, carried by slice_qp_delta, from a law that only looks at
+				frames at least CEDAR_ENC_PIPELINE_DEPTH + 1 back -- so the bytes do not
+				depend on how many frames the caller keeps in flight. qp is the starting
+				point. One stream, all slices, no gop_parallel. 0: fixed QP, as the reference
+				(cedar.c:1165-1168)                                                      */
 };
 
 typedef struct cedar_enc cedar_enc;
@@ -201,6 +208,7 @@ struct cedar_enc_stats {
 	int      depth;                          /* frames in flight this session allows               */
 	int      deblock_streams;                /* deblock streams in use                             */
 	uint64_t oversize_frames;                /* frames with a macroblock above 3200 bits (A.3.1)   */
+	int      frame_qp;                       /* slice QP of the frame collected last (rate control) */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */

@@ -46,6 +46,9 @@ typedef struct h264o_config {
 	int fps_num, fps_den; /* both > 0: the SPS carries VUI timing (fixed frame rate fps_num/fps_den)
 	                       * and a bitstream restriction (no reordering, 1 reference frame);
 	                       * the reference writes vui_parameters_present_flag = 0 (cedar.c:933) */
+	int bitrate;          /* > 0: frame-level rate control towards this many bits per second (frame rate
+	                       * fps_num/fps_den, 30 when unset): the slice QP follows h264o_rc_pick_qp;
+	                       * 0: fixed QP, as the reference (cedar.c:1165-1168 PARA1 = qp) */
 	int strict_mb_bits;   /* 1: a picture with a macroblock_layer() of more than 3200 bits (H.264 A.3.1) is
 	                       * refused with -EOVERFLOW instead of emitted; 0: emitted and counted */
 } h264o_config;
@@ -89,6 +92,7 @@ const h264o_mb *h264o_mbs(const h264o_enc *e);
 const uint8_t *h264o_recon_luma(const h264o_enc *e);
 const uint8_t *h264o_recon_chroma(const h264o_enc *e);
 int h264o_last_frame_type(const h264o_enc *e); /* 1 = IDR, 0 = P */
+int h264o_frame_qp(const h264o_enc *e);        /* slice QP of the last frame (rate control) */
 int h264o_max_mb_bits(const h264o_enc *e);     /* largest macroblock_layer() of the last frame, in bits */
 
 /* stand-alone pieces exported for known-answer tests */

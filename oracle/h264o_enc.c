@@ -36,6 +36,9 @@ struct h264o_enc {
 	int cur; /* index of reference_current (cedar.c:117-119) */
 	h264o_mb *mbs;
 	int last_idr;
+	int qp;          /* slice QP of the frame being coded: cfg.qp, or what the rate control picks */
+	int64_t rc_bits[64]; /* rate control history, index = frame number % 64: bits of the access unit ... */
+	int rc_qp[64];       /* ... and the QP it was coded at */
 	int closed_loop; /* env H264O_CLOSED_LOOP_INTRA=1 (tools/rd_record.py only): intra modes decided on reconstructed neighbours */
 	int max_mb_bits; /* largest macroblock_layer() of the last frame (A.3.1: at most 3200 bits) */
 	uint8_t cbp_code_intra[48], cbp_code_inter[48];
@@ -254,8 +257,17 @@ int h264o_write_pps(const h264o_config *cfg, uint8_t *out, int cap)
 	return nal_write(out, cap, 3, 8, tmp, (int)(b.pos >> 3));
 }
 
+static void slice_header_bits_qp(const h264o_config *c, bitw *b, int idr,
+				 int frame_num, int idr_pic_id, int first_mb, int qp_delta);
+
 static void slice_header_bits(const h264o_config *c, bitw *b, int idr,
 			      int frame_num, int idr_pic_id, int first_mb)
+{
+	slice_header_bits_qp(c, b, idr, frame_num, idr_pic_id, first_mb, 0);
+}
+
+static void slice_header_bits_qp(const h264o_config *c, bitw *b, int idr,
+				 int frame_num, int idr_pic_id, int first_mb, int qp_delta)
 {
 	bw_ue(b, (uint32_t)first_mb);
 	bw_ue(b, idr ? 2 : 0); /* slice_type I=2, P=0 (cedar.c:994-997) */
@@ -270,7 +282,7 @@ static void slice_header_bits(const h264o_config *c, bitw *b, int idr,
 		bw_put(b, 0, 1); /* ref_pic_list_modification_flag_l0 */
 		bw_put(b, 0, 1); /* adaptive_ref_pic_marking_mode_flag */
 	}
-	bw_se(b, 0); /* slice_qp_delta */
+	bw_se(b, qp_delta); /* slice_qp_delta: 0 at fixed QP (cedar.c:1021-1022) */
 	/* disable_deblocking_filter_idc: 0 single slice (cedar.c:1024-1025);
 	 * 2 when the picture has several slices so they stay independent */
 	bw_ue(b, c->slice_count > 1 ? 2 : 0);
@@ -757,7 +769,7 @@ static void blk4_avail(const h264o_enc *e, int mx, int my, int row0, int idx,
 
 static int chroma_qp_of(const h264o_enc *e)
 {
-	int q = e->cfg.qp + e->cfg.chroma_qp_offset;
+	int q = e->qp + e->cfg.chroma_qp_offset;
 
 	return h264o_chroma_qp[q < 0 ? 0 : q > 51 ? 51 : q];
 }
@@ -858,7 +870,7 @@ static void chroma_residual(h264o_enc *e, h264o_mb *mb, int mx, int my,
 static int luma_block_16(const h264o_enc *e, const int16_t res[16], int16_t lv[16],
 			 uint8_t *rec, int stride, int intra)
 {
-	int qp = e->cfg.qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
+	int qp = e->qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
 	int f = (1 << qbits) / (intra ? 3 : 6);
 	int16_t w[16];
 	int d[16], i, n = 0;
@@ -943,7 +955,7 @@ static void intra_decide_mb(h264o_enc *e, int mx, int my, int row0)
 		}
 	}
 	mb->i16_mode = (int8_t)best16;
-	mb->type = (sum4 + 32 * h264o_lambda[e->cfg.qp] < best16_sad) ? H264O_MB_I4x4 : H264O_MB_I16x16;
+	mb->type = (sum4 + 32 * h264o_lambda[e->qp] < best16_sad) ? H264O_MB_I4x4 : H264O_MB_I16x16;
 
 	bestc = -1;
 	for (mode = 0; mode < 4; mode++) {
@@ -979,7 +991,7 @@ static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0)
 	uint8_t *ry = e->rec_y[e->cur], *ruv = e->rec_uv[e->cur];
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
 	int top_mb = my > row0, left_mb = mx > 0;
-	int qp = e->cfg.qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
+	int qp = e->qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
 	int idx, i, c;
 	uint8_t predc[2][64];
 
@@ -1142,7 +1154,7 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 	const uint8_t *refy = e->rec_y[e->cur ^ 1], *refuv = e->rec_uv[e->cur ^ 1];
 	uint8_t *ry = e->rec_y[e->cur];
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
-	int R = e->cfg.search_range, lam = h264o_lambda[e->cfg.qp];
+	int R = e->cfg.search_range, lam = h264o_lambda[e->qp];
 	int dx, dy, idx, c;
 	long best_key = -1;
 	int bdx = 0, bdy = 0;
@@ -1362,7 +1374,7 @@ static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 	const h264o_mb *q = &e->mbs[my * e->mb_w + mx];
 	uint8_t *ry = e->rec_y[e->cur], *ruv = e->rec_uv[e->cur];
 	int stride = e->cw;
-	int qp = e->cfg.qp;
+	int qp = e->qp;
 	int qpc = chroma_qp_of(e);
 	int alpha_y = h264o_alpha[qp], beta_y = h264o_beta[qp];
 	int alpha_c = h264o_alpha[qpc], beta_c = h264o_beta[qpc];
@@ -1739,6 +1751,44 @@ const uint8_t *h264o_recon_luma(const h264o_enc *e) { return e->rec_y[e->cur ^ 1
 const uint8_t *h264o_recon_chroma(const h264o_enc *e) { return e->rec_uv[e->cur ^ 1]; }
 int h264o_last_frame_type(const h264o_enc *e) { return e->last_idr; }
 int h264o_max_mb_bits(const h264o_enc *e) { return e->max_mb_bits; }
+int h264o_frame_qp(const h264o_enc *e) { return e->qp; }
+
+/* ---- frame-level rate control (the VE has RC registers the driver never programs, cedar_regs.h:43-53;
+ * SURVEY 8(f)-4). One QP per picture, carried by slice_qp_delta. The law, integer only:
+ *   - frame n may use the sizes of frames <= n - 1 - 16 only (a session keeps up to 16 frames in
+ *     flight: whatever the caller's pipelining, those frames have been collected), over a window of
+ *     the last keyint of them;
+ *   - every known frame is scaled to what it would have cost at the configured QP, by the model
+ *     "6 QP steps halve the bits": bits * 2^((qp_i - qp0) / 6), in Q16;
+ *   - the new QP is qp0 + d with d the smallest step for which 2^(d/6) * target >= that average:
+ *     the lowest QP at which the model predicts no more than the target, clamped to 1..47 (cedar.c:771).
+ * 2^(d/6) in Q16 for d = 6q + r: */
+static int64_t rc_pow2_6_q16(int d)
+{
+	static const int64_t t[6] = { 65536, 73562, 82570, 92682, 104032, 116772 };
+	int q = d >= 0 ? d / 6 : -((-d + 5) / 6), r = d - 6 * q;
+
+	return q >= 0 ? t[r] << q : t[r] >> -q;
+}
+
+#define RC_LAG 16
+static int rc_pick_qp(int qp0, int64_t target, const int64_t *bits, const int *qps, long n, int keyint)
+{
+	long known = n - RC_LAG, w, i;
+	int64_t sum = 0, avg;
+	int d = -46, qp;
+
+	if (known <= 0 || target <= 0)
+		return qp0;
+	w = known < keyint ? known : keyint;
+	for (i = known - w; i < known; i++)
+		sum += (bits[i & 63] * rc_pow2_6_q16(qps[i & 63] - qp0)) >> 16;
+	avg = sum / w;
+	while (d < 46 && rc_pow2_6_q16(d) * target < (avg << 16))
+		d++;
+	qp = qp0 + d;
+	return qp < 1 ? 1 : qp > 47 ? 47 : qp;
+}
 
 static void pad_source(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma)
 {
@@ -1786,6 +1836,14 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 		if (r < 0)
 			return r;
 		o += r;
+	}
+
+	e->qp = e->cfg.qp;
+	if (e->cfg.bitrate > 0) {
+		const int64_t fn = e->cfg.fps_num > 0 && e->cfg.fps_den > 0 ? e->cfg.fps_num : 30;
+		const int64_t fd = e->cfg.fps_num > 0 && e->cfg.fps_den > 0 ? e->cfg.fps_den : 1;
+
+		e->qp = rc_pick_qp(e->cfg.qp, (int64_t)e->cfg.bitrate * fd / fn, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyint);
 	}
 
 	/* analysis + reconstruction */
@@ -1849,7 +1907,7 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 
 		slice_rows(e, s, &r0, &r1);
 		bw_init(&b, e->rbsp, e->rbsp_cap);
-		slice_header_bits(&e->cfg, &b, idr, e->frame_p_count, idr_pic_id, r0 * e->mb_w);
+		slice_header_bits_qp(&e->cfg, &b, idr, e->frame_p_count, idr_pic_id, r0 * e->mb_w, e->qp - e->cfg.qp);
 		for (my = r0; my < r1; my++)
 			for (mx = 0; mx < e->mb_w; mx++) {
 				const h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
@@ -1899,6 +1957,8 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 		o += r;
 	}
 
+	e->rc_bits[e->frame_count & 63] = (int64_t)o * 8;
+	e->rc_qp[e->frame_count & 63] = e->qp;
 	/* cedar.c:1193-1201 */
 	e->max_mb_bits = max_mb_bits;
 	e->last_idr = idr;

@@ -19,7 +19,7 @@ class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
         "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
-        "strict_mb_bits")]
+        "bitrate", "strict_mb_bits")]
 
 
 class MB(ctypes.Structure):
@@ -62,6 +62,7 @@ def lib():
         L.h264o_recon_chroma.argtypes = [vp]
         L.h264o_last_frame_type.argtypes = [vp]
         L.h264o_max_mb_bits.argtypes = [vp]
+        L.h264o_frame_qp.argtypes = [vp]
         L.h264o_write_sps.argtypes = [ctypes.POINTER(Config), vp, ci]
         L.h264o_write_pps.argtypes = [ctypes.POINTER(Config), vp, ci]
         L.h264o_write_aud.argtypes = [ci, vp, ci]
@@ -134,6 +135,10 @@ class OracleEncoder:
         if n < 0:
             raise OSError(-n, os.strerror(-n))
         return self.out[:n].tobytes()
+
+    def frame_qp(self):
+        """slice QP of the last frame (cfg.qp unless rate control is on)"""
+        return lib().h264o_frame_qp(self.h)
 
     def max_mb_bits(self):
         """largest macroblock_layer() of the last frame, in bits (H.264 A.3.1 allows 3200)"""

@@ -601,6 +601,29 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
         assert sh.hexdigest() == c["stream_sha1"], c["case"]
 
 
+@pytest.mark.parametrize("w,h,target", [(320, 240, 500000), (854, 480, 2500000)])
+def test_rate_control_follows_the_oracle_at_any_depth(ce, w, h, target):
+    """bitrate > 0: the picture QP comes from sizes of frames 17 and more back (collected by then
+    whatever the pipelining), so the synchronous loop, the full ring and the scalar oracle pick the
+    same QPs and emit the same bytes."""
+    n = 48
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25, bitrate=target))
+    want, qps = [], []
+    for y, uv in frames:
+        want.append(oe.encode(y, uv))
+        qps.append(oe.frame_qp())
+    assert len(set(qps)) > 1
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target) as enc:
+        got = _encode_pipelined(enc, frames)
+        assert enc.stats()["frame_qp"] == qps[-1]
+    assert got == want
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target) as enc:
+        assert [enc.encode_frame(y, uv) for y, uv in frames[:24]] == want[:24]
+    with pytest.raises(ce.EncoderError):     # one QP per launch: one stream, whole pictures
+        ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, n_streams=2)
+
+
 def test_macroblocks_above_3200_bits_are_counted_or_refused(ce):
     """H.264 A.3.1: a macroblock_layer() may take 3200 bits. Pure noise at a low QP passes that (measured
     with the independent decoder: up to QP 16) and there is no I_PCM fallback yet. The path detects

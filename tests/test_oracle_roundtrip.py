@@ -115,3 +115,33 @@ def test_fuzzed_round_trips():
                        capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
     assert "120 cases, decode == recon" in r.stdout
+
+
+def test_rate_control_reaches_the_target_and_stays_decodable():
+    """cedar_enc_config_ext.bitrate / h264o_config.bitrate: one QP per picture (slice_qp_delta) from an
+    integer law that only looks 17 and more frames back. After the start-up the stream runs within
+    one QP step (12 %) below the target; every picture still decodes to the encoder's reconstruction,
+    with the independent decoder too (it follows slice_qp_delta)."""
+    import numpy as np
+    from tests.indep import h264_refdec as rd
+    w, h, n = 192, 112, 110
+    for target in (150000, 600000):
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25, bitrate=target))
+        dec, pdec = ol.OracleDecoder(), rd.Decoder()
+        sizes, qps = [], []
+        for f in range(n):
+            au = oe.encode(*ol.gen_frame("B", w, h, f))
+            sizes.append(len(au))
+            qps.append(oe.frame_qp())
+            assert dec.decode(au) == 1
+            ry, ruv = oe.recon()
+            dy, duv = dec.picture()
+            assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
+            if f % 9 == 0 or f < 3:
+                pic = pdec.decode(au)[0]
+                assert pic.luma_bytes() == ry.tobytes() and pic.nv12_chroma_bytes() == ruv.tobytes()
+            else:
+                pdec.decode(au)
+        assert qps[:17] == [30] * 17 and len(set(qps)) > 1       # nothing is known before frame 17
+        rate = sum(sizes[60:110]) * 8 * 30 / 50.0               # two whole GOPs
+        assert 0.80 * target <= rate <= 1.02 * target, (target, rate, qps[::10])
