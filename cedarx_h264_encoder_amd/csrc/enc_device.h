@@ -228,6 +228,24 @@ DEVI int idct_lanes(int d, const LaneK &ci, const LaneK &cj)
 	return (f + 32) >> 6;
 }
 
+// Every spin of the hand-off protocols is bounded in WALL time: s_memrealtime counts at 100 MHz
+// whatever the shader clock does, so a wait is "lost" after WAIT_LIMIT_TICKS of real time and not
+// after an iteration count that a busy or throttled GPU stretches (several sessions or processes
+// polling on one device starve each other's producers for a while; that is slow, not lost). Looked
+// at every 256th iteration; the first look starts the clock.
+constexpr uint64_t WAIT_LIMIT_TICKS = 300000000ull; // 3 s
+DEVI bool wait_expired(uint32_t spins, uint64_t &t0)
+{
+	if ((spins & 255u) != 255u)
+		return false;
+	const uint64_t now = __builtin_amdgcn_s_memrealtime();
+	if (t0 == 0) {
+		t0 = now | 1u;
+		return false;
+	}
+	return now - t0 > WAIT_LIMIT_TICKS;
+}
+
 DEVI int mv_bits(int d)
 {
 	int a = iabs(d);

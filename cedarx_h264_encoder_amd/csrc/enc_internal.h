@@ -125,6 +125,8 @@ struct Params {
 	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
 	int64_t dummy_mb;                // ... and the macroblock record they fill: one past the session's last stream
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code
+	uint32_t *abort_all;             // device word of the session: set by the first wait that ran out, so that the waits of
+	                                 // the frames queued behind give up at once instead of one time-out after the other
 	// Frame pipelining keeps the deblock stream to ONE packet per frame (every packet queued behind a
 	// resident kernel costs its hardware pipe ~20 us): the last workgroup of the deblock launch
 	// zeroes the sync words of regions 1-2 for the slot's next use (db_self_reset) and stores

@@ -519,6 +519,7 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 			pending = band < ((r1 - r0 + 3) >> 2) && 2 * (r0 + 4 * band) < need_d;
 		}
 		uint32_t spins = 0;
+		uint64_t t0 = 0;
 		while (true) {
 			if (pending) {
 				const uint32_t v = __hip_atomic_load(&p.prev_db[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -526,9 +527,11 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 			}
 			if (!__any(pending))
 				break;
-			if (++spins > (1u << 20)) {
-				if (lane == 0)
+			if (wait_expired(++spins, t0) || __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // wall time, not iterations
+				if (lane == 0) {
 					__hip_atomic_store(p.wf_err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 				return;
 			}
 			__builtin_amdgcn_s_sleep(32);

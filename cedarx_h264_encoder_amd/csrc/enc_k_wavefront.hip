@@ -51,8 +51,9 @@ DEVI void xstore64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_
 DEVI uint32_t xwait(const uint32_t *word, uint32_t *abort_word, uint32_t *err_word, uint32_t need)
 {
 	uint32_t v = xload32(word), spins = 0;
+	uint64_t t0 = 0;
 	while (v < need) {
-		if (++spins > (1u << 21) || xload32(abort_word)) {
+		if (wait_expired(++spins, t0) || xload32(abort_word)) {
 			xstore32(abort_word, 1u);
 			__hip_atomic_store(err_word, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			return 0x7fffffffu;
@@ -199,6 +200,7 @@ struct WaitCtx {
 DEVI void lds_wait_ge(const int *word, int need, const WaitCtx &w)
 {
 	// bounded like every spin here: a lost partner ends in -EIO at collect, not in a hung grid
+	uint64_t t0 = 0;
 	for (int spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spins++) {
 		// back off after ~50 us: the partner is usually a few hundred cycles away, but with frames
 		// pipelined a whole workgroup can wait for a millisecond for its frame's analysis
@@ -206,7 +208,7 @@ DEVI void lds_wait_ge(const int *word, int need, const WaitCtx &w)
 			__builtin_amdgcn_s_sleep(0);
 			continue;
 		}
-		if (spins > (1 << 22)) {
+		if (wait_expired((uint32_t)spins, t0)) {
 			__hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__hip_atomic_store(w.abort_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			xstore32(w.abort_x, 1u);
@@ -528,6 +530,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				w2 = band + 1 < nbands && band + 1 < PROG_BANDS ? w0 + 1 : w0;
 			}
 			uint32_t spins = 0;
+			uint64_t t0 = 0;
 			while (true) {
 				const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -538,8 +541,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					inter_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
 					break;
 				}
-				if (++spins > (1u << 20)) {
+				// (a 3 us sleep per look: the clock is read every 256th, i.e. every ~0.8 ms)
+				if (wait_expired(++spins, t0) || __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
 					__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					inter_seen = 0x7fffffffu;
 					break;
 				}

@@ -246,6 +246,7 @@ struct cedar_enc {
 	hipStream_t s_ent2 = nullptr; // lane 1 (an alias of the spare stream s_db[2]); lane 0 is s_ent
 	uint8_t *d_out[CEDAR_ENC_PIPELINE_DEPTH] = {}; // compact bytestreams, one per frame in flight
 	uint8_t *d_pred4 = nullptr;
+	uint32_t *d_abort_all = nullptr; // Params::abort_all
 	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint64_t *d_wf_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint8_t *d_dummy_rec = nullptr;  // 24 rows: what idle k_inter waves reconstruct into
@@ -348,7 +349,7 @@ void free_all(cedar_enc *e)
 		F(e->d_slot[l]); F(e->d_mb_bits[l]); F(e->d_skip[l]); F(e->d_bit_off[l]); F(e->d_run[l]); F(e->d_unit_bits[l]);
 		F(e->d_rbsp[l]); F(e->d_esc[l]); F(e->d_nal_off[l]); F(e->d_nal_size[l]); F(e->d_stream_size[l]);
 	}
-	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab);
+	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab); F(e->d_abort_all);
 	if (e->mux) {
 		F(e->mux->d_store_y); F(e->mux->d_store_uv);
 		delete e->mux;
@@ -950,6 +951,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (int i = 0; i < e->depth; i++)
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
+	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
 	{
 		// workgroups per unit for the wavefront kernels: one CU is instruction-bound by a
 		// single unit's wavefront, so few units are spread over more CUs
@@ -1230,6 +1232,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.hdr = nullptr; // per frame: the frame's own pinned header words
 	P.prefix_len = nullptr;
 	P.pred4_tab = e->d_pred4;
+	P.abort_all = e->d_abort_all;
 	P.wf_sync = e->d_wf_sync[0];
 	P.wf_hbuf = e->d_wf_hbuf[0];
 	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES;
@@ -1794,6 +1797,7 @@ static int recover(cedar_enc *e, const InFlight &failed)
 	}
 	for (int l = 0; l < e->ent_lanes; l++)
 		HIP_TRY(e, hipMemset(e->d_stream_size[l], 0, sizeof(uint32_t) * MAX_COHORTS * (e->ext.n_streams + 4)));
+	HIP_TRY(e, hipMemset(e->d_abort_all, 0, sizeof(uint32_t)));
 	for (const ReplayIn &r : later) {
 		const int rc = submit_frame(e, &r);
 		if (rc)

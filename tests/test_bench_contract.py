@@ -62,3 +62,22 @@ def test_bench_two_ranks_shard_streams():
     # whole-job value: both ranks' macroblocks over the slowest rank's time
     assert abs(j["value"] - 2 * 8160 * 25 / (j["ms_per_step"] * 25e-3)) < 1e-3 * j["value"]
     assert "no collective" in j["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_slices_across_ranks_concatenate():
+    """BASELINE configs[3] harness: rank k codes slice k of one picture, the host concatenates the slice
+    NALs; the run itself checks that the concatenation IS the one-session stream. Two ranks on the one
+    card of this box over gloo; on the 8-GPU node the same code runs one rank per GPU."""
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--slices-across-gpus", "--width", "1280", "--height", "720",
+           "--steps", "12", "--warmup", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["slices_concatenate_to_one_session_stream"] is True
+    assert abs(j["value"] - 3600 * 12 / (j["ms_per_step"] * 12e-3)) < 1e-3 * j["value"]   # ONE picture per step
+    assert "slices x2" in j["config"]["parallelism"] and j["config"]["idr_in_timed_region"] == 1

@@ -122,6 +122,25 @@ def test_1080p_gop_bit_exact_and_decodable(ce):
         assert dec.crop_size() == (w, h)
 
 
+def test_1080p_crosses_a_gop_boundary_of_25_frames(ce):
+    """BASELINE configs[2] as it is benchmarked (QP 24, keyint 25, the full ring in flight): the 27
+    access units around the first GOP boundary against the scalar oracle, every one decodable."""
+    w, h, n = 1920, 1080, 27
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=24, keyint=25))
+    dec = ol.OracleDecoder()
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25) as enc:
+        got = _encode_pipelined(enc, frames)
+        ry, ruv = enc.debug_read("recon_y"), enc.debug_read("recon_uv")
+    for f in range(n):
+        assert got[f] == oe.encode(*frames[f]), f
+        assert dec.decode(got[f]) == 1
+    kinds = [got[25][i + 4] & 0x1f for i in range(len(got[25]) - 4) if got[25][i:i + 4] == b"\0\0\0\1"]
+    assert kinds == [5]                       # the second IDR picture: no parameter sets again (cedar.c:1058-1061)
+    dy, duv = dec.picture()
+    assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
+
+
 def test_4k_four_slices_decodable_and_matches_oracle_first_frames(ce):
     """BASELINE configs[3] structure on one device: 3840x2160 in 4 slices (34/34/34/33 rows)."""
     w, h = 3840, 2160
