@@ -17,7 +17,7 @@ struct MbInfo {
 	int8_t i16_mode;     // 0 V 1 H 2 DC 3 Plane
 	int8_t chroma_mode;  // 0 DC 1 H 2 V 3 Plane
 	int8_t cbp;          // bits 0-3 luma 8x8, bits 4-5 chroma
-	int16_t mvx, mvy;    // full-pel
+	int16_t mvx, mvy;    // quarter samples
 };
 
 // Quantised levels of one macroblock, int16, zig-zag order inside a block:

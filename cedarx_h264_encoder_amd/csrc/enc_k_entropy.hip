@@ -348,8 +348,8 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 			p.mbi[mbaddr].type = MB_PSKIP; // nobody else reads .type of a P macroblock concurrently
 		} else {
 			bw_ue(b, 0); // P_L0_16x16
-			bw_se(b, 4 * (mi.mvx - px));
-			bw_se(b, 4 * (mi.mvy - py));
+			bw_se(b, mi.mvx - px); // vectors are kept in quarter samples
+			bw_se(b, mi.mvy - py);
 			bw_ue(b, kCbpCodeInter[mi.cbp & 0x3f]);
 			if (mi.cbp & 0x3f)
 				bw_se(b, 0);
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 				p.mbi[mbaddr].type = MB_PSKIP; // nobody else reads .type of a P macroblock concurrently
 			} else {
 				lw_ue(b, 0); // P_L0_16x16
-				lw_se(b, 4 * (mi.mvx - px));
-				lw_se(b, 4 * (mi.mvy - py));
+				lw_se(b, mi.mvx - px); // vectors are kept in quarter samples
+				lw_se(b, mi.mvy - py);
 				lw_ue(b, kCbpCodeInter[cbp]);
 				if (cbp)
 					lw_se(b, 0);

@@ -477,8 +477,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		m.i16_mode = 0;
 		m.chroma_mode = 0;
 		m.cbp = (int8_t)cbp;
-		m.mvx = (int16_t)bdx;
-		m.mvy = (int16_t)bdy;
+		m.mvx = (int16_t)(4 * bdx); // quarter samples
+		m.mvy = (int16_t)(4 * bdy);
 		p.mbi[mbaddr] = m;
 	}
 }

@@ -175,6 +175,13 @@ DEVI void filt_chroma_s2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &
 	q0 = sel(m, nq0, q0);
 }
 
+// packed { int16 mvx, mvy } words: 1 if a component differs by 4 quarter samples or more
+DEVI int mv_far(int a, int b)
+{
+	const int dx = (int)(int16_t)a - (int)(int16_t)b, dy = (a >> 16) - (b >> 16);
+	return (int)((uint32_t)(3 - iabs(dx)) >> 31) | (int)((uint32_t)(3 - iabs(dy)) >> 31);
+}
+
 constexpr int DB2_PAIRS = WF_WAVES / 2;
 constexpr int DB2_XRING = 16; // macroblocks of bottom rows a band keeps for the band below (power of two)
 
@@ -651,7 +658,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				} else {
 					const int k = l >> 2, ks = (l & 7) >> 1;
 					int bv[4], bh[4];
-					const int mvd_l = nz_mask(mvc ^ mvl) & 1, mvd_t = nz_mask(mvc ^ mvt) & 1;
+					// vectors are in quarter samples: bS 1 from a difference of a whole sample on (8.7.2.1)
+					const int mvd_l = mv_far(mvc, mvl), mvd_t = mv_far(mvc, mvt);
 					const int nzv0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
 					bv[0] = (2 * nzv0 + ((1 - nzv0) & mvd_l)) & -(int)left_edge;
 					const int nzh0 = (int)(((nz_cur >> k) | (nz_top >> (12 + k))) & 1u);

@@ -610,8 +610,8 @@ void set_qp_params(Params &P, int qp, int chroma_qp_offset)
 	P.beta_c = kBeta[P.qpc];
 }
 
-// ---- frame-level rate control (cedar_enc_config_ext.bitrate; the scalar twin is oracle/h264o_enc.c
-// rc_pick_qp). Integer only: frame n looks at the sizes of frames <= n - 1 - RC_LAG (collected whatever
+// ---- frame-level rate control (cedar_enc_config_ext.bitrate; the tests hold a scalar
+// twin of this law against it). Integer only: frame n looks at the sizes of frames <= n - 1 - RC_LAG (collected whatever
 // the caller's pipelining: a session keeps at most RC_LAG frames in flight), over the last keyint of
 // them; each is scaled to the configured QP by "6 QP steps halve the bits" (Q16); the new QP is the
 // lowest one at which that model predicts no more than the target.

@@ -219,7 +219,7 @@ int cedar_enc_reset_stats(cedar_enc *enc);
 /* test hook: copy an internal device array of the last encoded frame to host.
  * Returns bytes copied or negative errno. */
 enum cedar_enc_debug_buf {
-	CEDAR_ENC_DBG_MBINFO = 0, /* struct { int8 type,i16,chroma,cbp; int16 mvx,mvy; } per MB */
+	CEDAR_ENC_DBG_MBINFO = 0, /* struct { int8 type,i16,chroma,cbp; int16 mvx,mvy (quarter samples); } per MB */
 	CEDAR_ENC_DBG_I4MODES,    /* int8[16] per MB, coding-order index                       */
 	CEDAR_ENC_DBG_NNZ,        /* uint8[24] per MB                                          */
 	CEDAR_ENC_DBG_COEF,       /* int16[408] per MB: luma[16][16] dc16[16] cdc[2][4] cac[2][4][16] */

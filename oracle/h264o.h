@@ -46,6 +46,9 @@ typedef struct h264o_config {
 	int fps_num, fps_den; /* both > 0: the SPS carries VUI timing (fixed frame rate fps_num/fps_den)
 	                       * and a bitstream restriction (no reordering, 1 reference frame);
 	                       * the reference writes vui_parameters_present_flag = 0 (cedar.c:933) */
+	int subpel;           /* motion vector precision: 0 whole samples (default), 1 half, 2 quarter -- a
+	                       * refinement around the best whole-sample vector (the VE keeps sub-pel planes,
+	                       * cedar.c:520, cedar_regs.h:71-72; what it does with them is not in the driver) */
 	int bitrate;          /* > 0: frame-level rate control towards this many bits per second (frame rate
 	                       * fps_num/fps_den, 30 when unset): the slice QP follows h264o_rc_pick_qp;
 	                       * 0: fixed QP, as the reference (cedar.c:1165-1168 PARA1 = qp) */
@@ -60,7 +63,7 @@ typedef struct h264o_mb {
 	int8_t  chroma_mode;  /* 0 DC 1 H 2 V 3 Plane                            */
 	int8_t  cbp;          /* bits 0-3 luma 8x8, bits 4-5 chroma (0,1,2)      */
 	int8_t  i4_modes[16]; /* by coding-order block index                     */
-	int16_t mvx, mvy;     /* full-pel                                        */
+	int16_t mvx, mvy;     /* quarter samples                                 */
 	uint8_t nnz[24];      /* total_coeff: 16 luma (raster bx+4*by), 4 Cb, 4 Cr */
 	int16_t luma[16][16]; /* levels, zig-zag order, coding-order block index */
 	int16_t dc16[16];     /* Intra16x16 DC levels, zig-zag                   */

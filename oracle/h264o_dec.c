@@ -955,6 +955,51 @@ static void pred_mv(const h264o_dec *d, int mx, int my, int slice, int addr, int
 	*py = med3(ay, by, cy);
 }
 
+
+/* clause 8.4.2.2.1: the sample at integer position (x, y) + quarter fractions (fx, fy) of the reference
+ * picture; positions outside the picture read the nearest edge sample */
+static int dec_ref(const h264o_dec *d, int x, int y)
+{
+	return d->ref_y[clip3(0, d->ch - 1, y) * d->cw + clip3(0, d->cw - 1, x)];
+}
+
+static int dec_tap(int a, int b, int c, int dd, int e, int f) { return a - 5 * b + 20 * c + 20 * dd - 5 * e + f; }
+
+static int dec_b1(const h264o_dec *d, int x, int y)
+{
+	return dec_tap(dec_ref(d, x - 2, y), dec_ref(d, x - 1, y), dec_ref(d, x, y), dec_ref(d, x + 1, y), dec_ref(d, x + 2, y), dec_ref(d, x + 3, y));
+}
+
+static int dec_h1(const h264o_dec *d, int x, int y)
+{
+	return dec_tap(dec_ref(d, x, y - 2), dec_ref(d, x, y - 1), dec_ref(d, x, y), dec_ref(d, x, y + 1), dec_ref(d, x, y + 2), dec_ref(d, x, y + 3));
+}
+
+static int dec_luma_sample(const h264o_dec *d, int x, int y, int fx, int fy)
+{
+	int g = dec_ref(d, x, y), b, h, s, m, j;
+
+	if (!fx && !fy)
+		return g;
+	b = clip3(0, 255, (dec_b1(d, x, y) + 16) >> 5);
+	h = clip3(0, 255, (dec_h1(d, x, y) + 16) >> 5);
+	if (!fy)
+		return fx == 2 ? b : fx == 1 ? (g + b + 1) >> 1 : (dec_ref(d, x + 1, y) + b + 1) >> 1;
+	if (!fx)
+		return fy == 2 ? h : fy == 1 ? (g + h + 1) >> 1 : (dec_ref(d, x, y + 1) + h + 1) >> 1;
+	s = clip3(0, 255, (dec_b1(d, x, y + 1) + 16) >> 5);
+	m = clip3(0, 255, (dec_h1(d, x + 1, y) + 16) >> 5);
+	j = clip3(0, 255, (dec_tap(dec_b1(d, x, y - 2), dec_b1(d, x, y - 1), dec_b1(d, x, y), dec_b1(d, x, y + 1),
+				   dec_b1(d, x, y + 2), dec_b1(d, x, y + 3)) + 512) >> 10);
+	if (fx == 2 && fy == 2)
+		return j;
+	if (fx == 2)
+		return fy == 1 ? (b + j + 1) >> 1 : (s + j + 1) >> 1;
+	if (fy == 2)
+		return fx == 1 ? (h + j + 1) >> 1 : (m + j + 1) >> 1;
+	return ((fy == 1 ? b : s) + (fx == 1 ? h : m) + 1) >> 1;
+}
+
 static int decode_inter_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr, int skip)
 {
 	int px, py, cbp = 0, x, y, c;
@@ -985,16 +1030,11 @@ static int decode_inter_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr
 			m->qp = (int8_t)((m->qp + dq + 52) % 52);
 		}
 	}
-	if ((m->mvx & 3) || (m->mvy & 3))
-		return fail(d, "fractional luma vectors unsupported by the test decoder");
-	/* luma: full-pel copy with picture-edge clamping (8.4.2.2.1) */
+	/* luma: quarter-sample interpolation with picture-edge clamping (8.4.2.2.1) */
 	for (y = 0; y < 16; y++)
-		for (x = 0; x < 16; x++) {
-			int sx = clip3(0, d->cw - 1, mx * 16 + x + (m->mvx >> 2));
-			int sy = clip3(0, d->ch - 1, my * 16 + y + (m->mvy >> 2));
-
-			d->cur_y[(my * 16 + y) * d->cw + mx * 16 + x] = d->ref_y[sy * d->cw + sx];
-		}
+		for (x = 0; x < 16; x++)
+			d->cur_y[(my * 16 + y) * d->cw + mx * 16 + x] =
+				(uint8_t)dec_luma_sample(d, mx * 16 + x + (m->mvx >> 2), my * 16 + y + (m->mvy >> 2), m->mvx & 3, m->mvy & 3);
 	/* chroma: 1/8-sample bilinear (8.4.2.2.2) */
 	for (c = 0; c < 2; c++)
 		for (y = 0; y < 8; y++)

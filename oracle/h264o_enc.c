@@ -1148,6 +1148,81 @@ static int mv_bits(int d)
 	return 2 * (bitlen32((uint32_t)(8 * a)) - 1) + 1;
 }
 
+/* ---- fractional-sample luma prediction, clause 8.4.2.2.1 (the caller keeps every tap inside the
+ * picture, so no clamping here) ---- */
+static int tap6(int a, int b, int c, int d, int e_, int f)
+{
+	return a - 5 * b + 20 * c + 20 * d - 5 * e_ + f;
+}
+
+static int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+static int luma_sample_q(const uint8_t *r, int stride, int x, int y, int fx, int fy)
+{
+#define G_(dx, dy) ((int)r[(y + (dy)) * stride + x + (dx)])
+#define B1(dx, dy) tap6(G_((dx) - 2, dy), G_((dx) - 1, dy), G_(dx, dy), G_((dx) + 1, dy), G_((dx) + 2, dy), G_((dx) + 3, dy))
+#define H1(dx, dy) tap6(G_(dx, (dy) - 2), G_(dx, (dy) - 1), G_(dx, dy), G_(dx, (dy) + 1), G_(dx, (dy) + 2), G_(dx, (dy) + 3))
+	int g = G_(0, 0), b, h, s, m, j;
+
+	if (!fx && !fy)
+		return g;
+	if (!fy) {
+		b = clip8((B1(0, 0) + 16) >> 5);
+		return fx == 2 ? b : fx == 1 ? (g + b + 1) >> 1 : (G_(1, 0) + b + 1) >> 1;
+	}
+	if (!fx) {
+		h = clip8((H1(0, 0) + 16) >> 5);
+		return fy == 2 ? h : fy == 1 ? (g + h + 1) >> 1 : (G_(0, 1) + h + 1) >> 1;
+	}
+	b = clip8((B1(0, 0) + 16) >> 5);
+	h = clip8((H1(0, 0) + 16) >> 5);
+	s = clip8((B1(0, 1) + 16) >> 5);
+	m = clip8((H1(1, 0) + 16) >> 5);
+	j = clip8((tap6(B1(0, -2), B1(0, -1), B1(0, 0), B1(0, 1), B1(0, 2), B1(0, 3)) + 512) >> 10);
+	if (fx == 2 && fy == 2)
+		return j;
+	if (fx == 2)
+		return fy == 1 ? (b + j + 1) >> 1 : (s + j + 1) >> 1;
+	if (fy == 2)
+		return fx == 1 ? (h + j + 1) >> 1 : (m + j + 1) >> 1;
+	return ((fy == 1 ? b : s) + (fx == 1 ? h : m) + 1) >> 1;
+#undef G_
+#undef B1
+#undef H1
+}
+
+/* bits of se(v) for a vector component in quarter samples (== mv_bits(d) for v = 4 d) */
+static int mv_bits_q(int v)
+{
+	int a = v < 0 ? -v : v, n = 0;
+
+	if (!a)
+		return 1;
+	for (a *= 2; a > 1; a >>= 1)
+		n++;
+	return 2 * n + 1;
+}
+
+/* May the 16x16 block at quarter-sample vector (qx, qy) be predicted from?  Every sample a tap reads
+ * lies inside the picture and the slice's band of rows (slices stay independent of each other), and
+ * inside the +-16 window around the macroblock that the search works in. */
+static int subpel_ok(const h264o_enc *e, int x0, int y0, int row0, int row1, int qx, int qy)
+{
+	int R4 = 4 * e->cfg.search_range;
+	int ix = qx >> 2, iy = qy >> 2, fx = qx & 3, fy = qy & 3;
+	int X = x0 + ix, Y = y0 + iy;
+
+	if (qx < -R4 || qx > R4 || qy < -R4 || qy > R4)
+		return 0;
+	if (X < 0 || X + 16 > e->cw || Y < row0 * 16 || Y + 16 > row1 * 16)
+		return 0;
+	if (fx && (X - 2 < 0 || X + 18 >= e->cw || ix < -14 || ix > 13))
+		return 0;
+	if (fy && (Y - 2 < row0 * 16 || Y + 18 >= row1 * 16 || iy < -14 || iy > 13))
+		return 0;
+	return 1;
+}
+
 static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 {
 	h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
@@ -1155,7 +1230,7 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 	uint8_t *ry = e->rec_y[e->cur];
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
 	int R = e->cfg.search_range, lam = h264o_lambda[e->qp];
-	int dx, dy, idx, c;
+	int dx, dy, idx, c, qx, qy;
 	long best_key = -1;
 	int bdx = 0, bdy = 0;
 	uint8_t predc[2][64];
@@ -1180,9 +1255,45 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 			}
 		}
 	}
+	qx = 4 * bdx;
+	qy = 4 * bdy;
+	/* Sub-sample refinement (cfg.subpel): the 8 half-sample neighbours of the best whole-sample vector,
+	 * then the 8 quarter-sample neighbours of the winner. Cost as above, SAD of the interpolated
+	 * prediction + lambda * bits of the vector; a candidate replaces the incumbent only when strictly
+	 * cheaper, candidates in raster order (dy, then dx). */
+	{
+		long best = best_key >> 11; /* SAD + lambda * bits of the incumbent */
+		int stage;
+
+		for (stage = 1; stage <= e->cfg.subpel && stage <= 2; stage++) {
+			int step = stage == 1 ? 2 : 1, cx = qx, cy = qy, sy, sx;
+
+			for (sy = -step; sy <= step; sy += step)
+				for (sx = -step; sx <= step; sx += step) {
+					int vx = cx + sx, vy = cy + sy, x, y;
+					long cost;
+
+					if ((!sx && !sy) || !subpel_ok(e, x0, y0, row0, row1, vx, vy))
+						continue;
+					cost = lam * (mv_bits_q(vx) + mv_bits_q(vy));
+					for (y = 0; y < 16; y++)
+						for (x = 0; x < 16; x++) {
+							int d = e->src_y[(y0 + y) * stride + x0 + x] -
+								luma_sample_q(refy, stride, x0 + (vx >> 2) + x, y0 + (vy >> 2) + y, vx & 3, vy & 3);
+
+							cost += d < 0 ? -d : d;
+						}
+					if (cost < best) {
+						best = cost;
+						qx = vx;
+						qy = vy;
+					}
+				}
+		}
+	}
 	mb->type = H264O_MB_P16x16;
-	mb->mvx = (int16_t)bdx;
-	mb->mvy = (int16_t)bdy;
+	mb->mvx = (int16_t)qx; /* quarter samples */
+	mb->mvy = (int16_t)qy;
 	mb->i16_mode = 0;
 	mb->chroma_mode = 0;
 	memset(mb->i4_modes, 2, sizeof(mb->i4_modes));
@@ -1197,7 +1308,7 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 
 		for (y = 0; y < 4; y++)
 			for (x = 0; x < 4; x++) {
-				int p = refy[(y0 + bdy + 4 * by + y) * stride + x0 + bdx + 4 * bx + x];
+				int p = luma_sample_q(refy, stride, x0 + (qx >> 2) + 4 * bx + x, y0 + (qy >> 2) + 4 * by + y, qx & 3, qy & 3);
 
 				res[4 * y + x] = (int16_t)(e->src_y[(y0 + 4 * by + y) * stride + x0 + 4 * bx + x] - p);
 				dst[y * stride + x] = (uint8_t)p;
@@ -1208,9 +1319,9 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 			mb->cbp |= (int8_t)(1 << (idx >> 2));
 	}
 	/* chroma motion compensation (8.4.2.2.2): mvC = luma mv in 1/8 chroma
-	 * samples; full-pel luma vectors give fractions 0 or 4 */
+	 * samples; whole-sample luma vectors give fractions 0 or 4 */
 	{
-		int mvcx = 4 * bdx, mvcy = 4 * bdy;
+		int mvcx = qx, mvcy = qy;
 		int ix = mvcx >> 3, iy = mvcy >> 3, fx = mvcx & 7, fy = mvcy & 7;
 		int x, y;
 
@@ -1292,7 +1403,7 @@ static int bs_of(const h264o_mb *p, int pbx, int pby, const h264o_mb *q, int qbx
 		return mb_edge ? 4 : 3;
 	if (p->nnz[pbx + 4 * pby] || q->nnz[qbx + 4 * qby])
 		return 2;
-	if (p->mvx != q->mvx || p->mvy != q->mvy)
+	if (abs(p->mvx - q->mvx) >= 4 || abs(p->mvy - q->mvy) >= 4) /* a whole sample or more (8.7.2.1) */
 		return 1; /* full-pel vectors: any difference is >= 4 quarter samples */
 	return 0;
 }
@@ -1680,6 +1791,8 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		return NULL;
 	if (cfg->keyint <= 0 || cfg->keyint >= 32)
 		return NULL;
+	if (cfg->subpel < 0 || cfg->subpel > 2)
+		return NULL;
 	if (cfg->search_range < 0 || cfg->search_range > 16)
 		return NULL;
 	if (cfg->slice_count < 1 || cfg->slice_count > ALIGN16(cfg->height) / 16)
@@ -1931,8 +2044,8 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 
 					mv_pred(e, mx, my, r0, &px, &py, &skx, &sky);
 					bw_ue(&b, 0); /* mb_type P_L0_16x16 */
-					bw_se(&b, 4 * (mb->mvx - px));
-					bw_se(&b, 4 * (mb->mvy - py));
+					bw_se(&b, mb->mvx - px); /* vectors are kept in quarter samples */
+					bw_se(&b, mb->mvy - py);
 					bw_ue(&b, e->cbp_code_inter[mb->cbp & 0x3f]);
 					if (mb->cbp & 0x3f)
 						bw_se(&b, 0); /* mb_qp_delta */
