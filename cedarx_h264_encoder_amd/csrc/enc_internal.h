@@ -66,6 +66,7 @@ struct Params {
 	int32_t row_first, row_num; // MB rows covered by those slices
 	// policy
 	int32_t qp, qpc, search_range, lambda;
+	int32_t subpel;             // motion vector precision: 0 whole samples, 1 half, 2 quarter
 	int32_t is_idr;
 	// quantiser, luma (index = position class 0 even/even, 1 odd/odd, 2 mixed)
 	int32_t mf[3], dv[3], qbits, qshift;

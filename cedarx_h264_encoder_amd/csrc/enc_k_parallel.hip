@@ -189,6 +189,42 @@ DEVI int quant24(int w, int mf, int f, int qbits)
 	return w < 0 ? -l : l;
 }
 
+// ---- sub-sample refinement (Params::subpel; clause 8.4.2.2.1) ----
+// Around the best whole-sample vector the half-sample planes of the reference are built once in LDS:
+//   b  half a sample to the right of G      h  half a sample below G      j  both
+// (b1 = the unrounded 6-tap row sums that j is filtered from). Every fractional prediction is one of
+// G / b / h / j or the rounded mean of two of them (the standard's a..s table), so a candidate is
+// two (plane, +0/+1 column, +0/+1 row) picks, kSubTab below; its SAD is one v_sad_u8 per lane
+// (16 rows x 4 segments of 4 samples = 64 lanes) and a wave sum.
+#define SP_STRIDE 20 // bytes per row of the b / h / j planes; plane sample (u, v), u, v >= -1, at [(v + 1) * 20 + u + 1]
+#define SP_B1_STRIDE 18 // int16 per row of b1; (u, v), u >= -1, v >= -3, at [(v + 3) * 18 + u + 1]
+struct SubPick { int8_t pa, ua, va, pb, ub, vb; }; // planes: 0 G, 1 b, 2 h, 3 j
+// index = 4 * fy + fx
+__device__ constexpr SubPick kSubTab[16] = {
+	{ 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 1, 0, 0 }, { 1, 0, 0, 1, 0, 0 }, { 0, 1, 0, 1, 0, 0 }, // G   a   b   c
+	{ 0, 0, 0, 2, 0, 0 }, { 1, 0, 0, 2, 0, 0 }, { 1, 0, 0, 3, 0, 0 }, { 1, 0, 0, 2, 1, 0 }, // d   e   f   g
+	{ 2, 0, 0, 2, 0, 0 }, { 2, 0, 0, 3, 0, 0 }, { 3, 0, 0, 3, 0, 0 }, { 2, 1, 0, 3, 0, 0 }, // h   i   j   k
+	{ 0, 0, 1, 2, 0, 0 }, { 1, 0, 1, 2, 0, 0 }, { 1, 0, 1, 3, 0, 0 }, { 1, 0, 1, 2, 1, 0 }, // n   p   q   r
+};
+
+// bits of se(v), v a vector component in quarter samples (mv_bits(d) for v = 4 d)
+DEVI int mv_bits_q(int v)
+{
+	const int a = iabs(v);
+	return a == 0 ? 1 : 2 * (31 - __clz(2 * a)) + 1;
+}
+
+// four bytes from a byte address in LDS that need not be aligned: two aligned dwords and a funnel shift
+DEVI uint32_t lds_bytes4(const uint8_t *base, int off)
+{
+	const uint32_t *w = (const uint32_t *)(base + (off & ~3));
+	return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)off & 3u);
+}
+
+// rounded mean of four byte pairs: (a + b + 1) >> 1 per byte
+DEVI uint32_t avg_bytes4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
+
+template <int SUBPEL>
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
 	// one wave per macroblock, INTER_WAVES macroblocks per workgroup; each wave has its own
@@ -201,6 +237,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	__shared__ __attribute__((aligned(16))) uint8_t sa_recy[INTER_WAVES][256];
 	__shared__ __attribute__((aligned(16))) uint8_t sa_recc[INTER_WAVES][128];
 	__shared__ __attribute__((aligned(8))) uint8_t sa_nnz[INTER_WAVES][NNZ_PER_MB];
+	// half-sample planes b, h, j (18 rows each, 4 bytes of slack for the funnel-shift reads)
+	__shared__ __attribute__((aligned(16))) uint8_t sa_sub[SUBPEL ? INTER_WAVES : 1][SUBPEL ? 3 * 18 * SP_STRIDE + 16 : 16];
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows
@@ -356,6 +394,97 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	best = wave_min_u32(best);
 	const int bidx = (int)(best & 2047u);
 	const int bdy = bidx / 33 - 16, bdx = bidx - (bidx / 33) * 33 - 16;
+	int qx = 4 * bdx, qy = 4 * bdy; // the vector in quarter samples
+	uint8_t *const s_sub = sa_sub[SUBPEL ? wave : 0];
+	if (SUBPEL && p.subpel > 0) {
+		// window coordinates of the best whole-sample block; plane sample (u, v) = window (wx0 + u, wy0 + v)
+		const int wx0 = 16 + bdx, wy0 = 16 + bdy;
+		int16_t *const s_b1 = (int16_t *)s_coef; // 22 rows x 18: the levels' place is free until the transform
+		uint8_t *const s_pb = s_sub, *const s_ph = s_sub + 18 * SP_STRIDE, *const s_pj = s_sub + 36 * SP_STRIDE;
+		// b1 (u in [-1, 15], v in [-3, 18]) and b = clip((b1 + 16) >> 5) for v in [-1, 16]. Addresses are
+		// clamped into the window: a clamped tap is a wrong tap, but only candidates that subpel_ok
+		// refuses read it.
+		for (int i = lane; i < 22 * 17; i += 64) {
+			const int v = i / 17 - 3, u = i - (v + 3) * 17 - 1;
+			const uint8_t *r = s_ref + min(max(wy0 + v, 0), 47) * REF_STRIDE + min(max(wx0 + u - 2, 0), 42);
+			const int t = (int)r[0] - 5 * (int)r[1] + 20 * (int)r[2] + 20 * (int)r[3] - 5 * (int)r[4] + (int)r[5];
+			s_b1[(v + 3) * SP_B1_STRIDE + u + 1] = (int16_t)t;
+			if (v >= -1 && v <= 16)
+				s_pb[(v + 1) * SP_STRIDE + u + 1] = (uint8_t)clip255((t + 16) >> 5);
+		}
+		// h (u in [-1, 16], v in [-1, 15])
+		for (int i = lane; i < 17 * 18; i += 64) {
+			const int v = i / 18 - 1, u = i - (v + 1) * 18 - 1;
+			const uint8_t *r = s_ref + min(max(wy0 + v - 2, 0), 42) * REF_STRIDE + min(max(wx0 + u, 0), 47);
+			const int t = (int)r[0] - 5 * (int)r[REF_STRIDE] + 20 * (int)r[2 * REF_STRIDE] + 20 * (int)r[3 * REF_STRIDE] -
+				      5 * (int)r[4 * REF_STRIDE] + (int)r[5 * REF_STRIDE];
+			s_ph[(v + 1) * SP_STRIDE + u + 1] = (uint8_t)clip255((t + 16) >> 5);
+		}
+		WAVE_LDS_SYNC();
+		// j (u, v in [-1, 15]) from six b1 of a column
+		for (int i = lane; i < 17 * 17; i += 64) {
+			const int v = i / 17 - 1, u = i - (v + 1) * 17 - 1;
+			const int16_t *c = s_b1 + (v + 1) * SP_B1_STRIDE + u + 1; // row v - 2
+			const int t = (int)c[0] - 5 * (int)c[SP_B1_STRIDE] + 20 * (int)c[2 * SP_B1_STRIDE] + 20 * (int)c[3 * SP_B1_STRIDE] -
+				      5 * (int)c[4 * SP_B1_STRIDE] + (int)c[5 * SP_B1_STRIDE];
+			s_pj[(v + 1) * SP_STRIDE + u + 1] = (uint8_t)clip255((t + 512) >> 10);
+		}
+		WAVE_LDS_SYNC();
+		// candidates: lane = (row r = lane / 4, segment c = lane % 4) of the block
+		const int sr = lane >> 2, sc = lane & 3;
+		const uint32_t cur4 = ((const uint32_t *)s_cur)[lane]; // row sr, samples 4 sc .. 4 sc + 3
+		auto pred4 = [&](int vx, int vy) -> uint32_t { // the 4 predicted samples of this lane for vector (vx, vy)
+			const int ox = (vx >> 2) - bdx, oy = (vy >> 2) - bdy; // -1 or 0
+			const SubPick k = kSubTab[4 * (vy & 3) + (vx & 3)];
+			auto fetch = [&](int pl, int du, int dv) -> uint32_t {
+				const int u = 4 * sc + ox + du, v = sr + oy + dv;
+				if (pl == 0) // (never below the window's first byte: a refused candidate may point there)
+					return lds_bytes4(s_ref, max((wy0 + v) * REF_STRIDE + wx0 + u, 0));
+				return lds_bytes4(s_sub, (pl - 1) * 18 * SP_STRIDE + (v + 1) * SP_STRIDE + u + 1);
+			};
+			return avg_bytes4(fetch(k.pa, k.ua, k.va), fetch(k.pb, k.ub, k.vb));
+		};
+		auto allowed = [&](int vx, int vy) -> bool { // see subpel_ok of the scalar twin
+			const int ix = vx >> 2, iy = vy >> 2, fx = vx & 3, fy = vy & 3;
+			const int X = x0 + ix, Y = y0 + iy;
+			bool ok = vx >= -4 * R && vx <= 4 * R && vy >= -4 * R && vy <= 4 * R;
+			ok = ok && X >= 0 && X + 16 <= p.cw && Y >= band_y0 && Y + 16 <= band_y1;
+			ok = ok && (!fx || (X - 2 >= 0 && X + 18 < p.cw && ix >= -14 && ix <= 13));
+			ok = ok && (!fy || (Y - 2 >= band_y0 && Y + 18 < band_y1 && iy >= -14 && iy <= 13));
+			return ok;
+		};
+		uint32_t bestj = best >> 11; // SAD + lambda * bits of the incumbent
+		for (int stage = 1; stage <= p.subpel && stage <= 2; stage++) {
+			const int step = stage == 1 ? 2 : 1, cx = qx, cy = qy;
+			uint32_t key = bestj << 4; // incumbent: index 0, wins ties
+#pragma unroll
+			for (int pr = 0; pr < 4; pr++) { // two candidates per wave sum (a lane's SAD is < 2^16 / 64)
+				uint32_t packed = 0;
+#pragma unroll
+				for (int hh = 0; hh < 2; hh++) {
+					const int n = 2 * pr + hh, ci = n < 4 ? n : n + 1; // 3x3 raster without the centre
+					const int vx = cx + (ci % 3 - 1) * step, vy = cy + (ci / 3 - 1) * step;
+					packed |= __builtin_amdgcn_sad_u8(pred4(vx, vy), cur4, 0u) << (16 * hh);
+				}
+				const uint32_t tot = (uint32_t)wave_sum_i32((int)packed);
+#pragma unroll
+				for (int hh = 0; hh < 2; hh++) {
+					const int n = 2 * pr + hh, ci = n < 4 ? n : n + 1;
+					const int vx = cx + (ci % 3 - 1) * step, vy = cy + (ci / 3 - 1) * step;
+					const uint32_t j = ((tot >> (16 * hh)) & 0xffffu) + (uint32_t)(p.lambda * (mv_bits_q(vx) + mv_bits_q(vy)));
+					const uint32_t k2 = (j << 4) | (uint32_t)(n + 1);
+					key = (allowed(vx, vy) && k2 < key) ? k2 : key;
+				}
+			}
+			const int win = (int)(key & 15u);
+			if (win) {
+				const int n = win - 1, ci = n < 4 ? n : n + 1;
+				qx = cx + (ci % 3 - 1) * step;
+				qy = cy + (ci / 3 - 1) * step;
+				bestj = key >> 4;
+			}
+		}
+	}
 
 	// ---- residual, transform, quantisation, reconstruction: one lane per SAMPLE ----
 	// 16-lane group = one 4x4 block, transforms across lanes with DPP (enc_device.h):
@@ -381,11 +510,26 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// leave as three 8-byte stores at the end)
 	uint32_t nz_luma = 0; // bit = coding-order block index
 	const uint8_t *predp = s_ref + (16 + bdy) * REF_STRIDE + 16 + bdx;
+	// fractional vector: the prediction is the rounded mean of two plane samples (kSubTab)
+	const bool frac = SUBPEL && ((qx | qy) & 3) != 0;
+	const uint8_t *pa_base = predp, *pb_base = predp;
+	int pa_stride = REF_STRIDE, pb_stride = REF_STRIDE;
+	if (frac) {
+		const SubPick k = kSubTab[4 * (qy & 3) + (qx & 3)];
+		const int ox = (qx >> 2) - bdx, oy = (qy >> 2) - bdy;
+		pa_base = k.pa ? s_sub + (k.pa - 1) * 18 * SP_STRIDE + (oy + k.va + 1) * SP_STRIDE + ox + k.ua + 1
+			       : predp + (oy + k.va) * REF_STRIDE + ox + k.ua;
+		pb_base = k.pb ? s_sub + (k.pb - 1) * 18 * SP_STRIDE + (oy + k.vb + 1) * SP_STRIDE + ox + k.ub + 1
+			       : predp + (oy + k.vb) * REF_STRIDE + ox + k.ub;
+		pa_stride = k.pa ? SP_STRIDE : REF_STRIDE;
+		pb_stride = k.pb ? SP_STRIDE : REF_STRIDE;
+	}
 #pragma unroll
 	for (int pass = 0; pass < 4; pass++) {
 		const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
 		const int x = 4 * bx + pj, y = 4 * by + pi;
-		const int pv = predp[y * REF_STRIDE + x];
+		const int pv = frac ? ((int)pa_base[y * pa_stride + x] + (int)pb_base[y * pb_stride + x] + 1) >> 1
+				    : (int)predp[y * REF_STRIDE + x];
 		const int res = (int)s_cur[y * 16 + x] - pv;
 		const int w = fdct_lanes24(res, ci, cj);
 		const int level = quant24(w, mf_y, f_inter, p.qbits);
@@ -399,7 +543,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 			nz_luma |= ((uint32_t)(bal >> (16 * k)) & 0xffffu) ? (1u << (4 * pass + k)) : 0u;
 	}
 	// chroma: pass = plane, group = block (raster 2x2)
-	const int ix = bdx >> 1, iy = bdy >> 1, fx = (bdx & 1) * 4, fy = (bdy & 1) * 4;
+	// vector in 1/8 chroma samples = the luma vector in quarter samples (8.4.1.4)
+	const int ix = qx >> 3, iy = qy >> 3, fx = qx & 7, fy = qy & 7;
 	int cpv[2], cdq[2], dcw[2][4];
 	uint32_t nz_cac = 0;
 #pragma unroll
@@ -477,15 +622,19 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		m.i16_mode = 0;
 		m.chroma_mode = 0;
 		m.cbp = (int8_t)cbp;
-		m.mvx = (int16_t)(4 * bdx); // quarter samples
-		m.mvy = (int16_t)(4 * bdy);
+		m.mvx = (int16_t)qx; // quarter samples
+		m.mvy = (int16_t)qy;
 		p.mbi[mbaddr] = m;
 	}
 }
 
 int Launch::inter(const Params &p, void *stream, int n_mbs)
 {
-	hipLaunchKernelGGL(k_inter, dim3((n_mbs + INTER_WAVES - 1) / INTER_WAVES), dim3(64 * INTER_WAVES), 0, (hipStream_t)stream, p);
+	const dim3 grid((n_mbs + INTER_WAVES - 1) / INTER_WAVES), block(64 * INTER_WAVES);
+	if (p.subpel > 0) // the refinement's planes take LDS: a kernel of its own, so the whole-sample one keeps its occupancy
+		hipLaunchKernelGGL(k_inter<1>, grid, block, 0, (hipStream_t)stream, p);
+	else
+		hipLaunchKernelGGL(k_inter<0>, grid, block, 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 

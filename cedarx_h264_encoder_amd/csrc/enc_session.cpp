@@ -663,6 +663,7 @@ void fill_static_params(cedar_enc *e)
 	P.row_first = r0;
 	P.row_num = q1 - r0;
 	P.search_range = e->ext.search_range;
+	P.subpel = e->ext.subpel;
 	set_qp_params(P, c.qp, e->chroma_qp_offset);
 }
 
@@ -827,6 +828,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "chroma_qp_index_offset %d outside -12..12", e->chroma_qp_offset);
 	if (ext.aud != 0 && ext.aud != 1)
 		return fail(e, -EINVAL, "aud must be 0 or 1");
+	if (ext.subpel < 0 || ext.subpel > 2)
+		return fail(e, -EINVAL, "subpel %d outside 0..2", ext.subpel);
 	if (ext.strict_mb_bits != 0 && ext.strict_mb_bits != 1)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0 or 1");
 	if (ext.bitrate < 0 || (ext.bitrate > 0 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count)))

@@ -42,7 +42,7 @@ class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-        "gop_parallel", "strict_mb_bits", "bitrate")]
+        "gop_parallel", "strict_mb_bits", "subpel", "bitrate")]
 
 
 class _Stats(ctypes.Structure):
@@ -165,6 +165,7 @@ class EncoderConfig:
     first_frame_index: int = 0  # global index of this session's first frame (a multiple of keyframe_interval)
     gop_parallel: int = 0       # G > 1: G consecutive closed GOPs of every stream are encoded side by side
     strict_mb_bits: int = 0     # 1: a picture with a macroblock above 3200 bits fails with EOVERFLOW
+    subpel: int = 0             # motion vectors: 0 whole samples, 1 half, 2 quarter
     bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
 
 
@@ -194,7 +195,7 @@ class CedarEncoder:
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-                  "gop_parallel", "strict_mb_bits", "bitrate"):
+                  "gop_parallel", "strict_mb_bits", "subpel", "bitrate"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")

@@ -108,6 +108,11 @@ struct cedar_enc_config_ext {
 				(no I_PCM fallback exists yet). 0: such a picture is emitted as it is and
 				counted (cedar_enc_stats.oversize_frames); 1: it fails with -EOVERFLOW and is
 				dropped like any failed frame                                            */
+	int subpel;          /* motion vector precision: 0 whole samples (default; what round 1 shipped), 1 half,
+				2 quarter samples -- a refinement of the 8 half- and then 8 quarter-sample
+				neighbours of the best whole-sample vector, 6-tap interpolation of H.264
+				8.4.2.2.1 (the VE keeps "sub-pel" planes per reference frame, cedar.c:520,
+				cedar_regs.h:71-72; what the silicon does with them is not in the driver)  */
 	int bitrate;         /* > 0: frame-level rate control towards this many bits per second (at fps_num /
 				fps_den, 30 frames/s when unset). The VE has rate-control registers the
 				reference never programs (cedar_regs.h:43-53); here every

@@ -620,6 +620,47 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
         assert sh.hexdigest() == c["stream_sha1"], c["case"]
 
 
+def _drifting_texture(w, h, f, vx=1.25, vy=0.5):
+    """a smooth texture that moves by a fraction of a sample per frame: what sub-sample vectors are for"""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    u, v = x + vx * f, y + vy * f
+    lum = 128 + 60 * np.sin(u / 5.0) * np.cos(v / 7.0) + 30 * np.sin((u + v) / 3.0)
+    yy = np.clip(np.round(lum), 0, 255).astype(np.uint8).reshape(-1)
+    cy, cx = np.mgrid[0:h // 2, 0:w // 2].astype(np.float64)
+    uv = np.empty((h // 2, w), np.uint8)
+    uv[:, 0::2] = np.clip(np.round(128 + 40 * np.sin((cx * 2 + vx * f) / 9.0)), 0, 255).astype(np.uint8)
+    uv[:, 1::2] = np.clip(np.round(128 + 40 * np.cos((cy * 2 + vy * f) / 11.0)), 0, 255).astype(np.uint8)
+    return yy, uv.reshape(-1)
+
+
+@pytest.mark.parametrize("w,h,qp,subpel,slices,search", [(96, 80, 26, 1, 1, 0), (96, 80, 26, 2, 1, 0), (320, 240, 30, 2, 3, 0),
+                                                         (70, 50, 20, 2, 1, 5), (640, 368, 24, 2, 1, 0), (1920, 1080, 24, 2, 1, 0)])
+def test_sub_sample_motion_vectors_equal_the_oracle(ce, w, h, qp, subpel, slices, search):
+    """subpel = 1 / 2: half- and quarter-sample refinement around the best whole-sample vector (6-tap
+    planes built per macroblock in LDS). Decisions, levels, reconstruction and bytes equal the scalar
+    twin's; fractional vectors really occur; the independent decoder interpolates the same pictures."""
+    from tests.indep import h264_refdec as rd
+    n = 4 if w < 1000 else 2
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=25, subpel=subpel, slice_count=slices, search_range=search or 16))
+    dec = rd.Decoder() if w <= 320 else None
+    fr = 0
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=25, subpel=subpel, slice_count=slices, search_range=search) as ge:
+        for f in range(n):
+            y, uv = _drifting_texture(w, h, f) if f < 3 else ol.gen_frame("B", w, h, f)
+            ref = oe.encode(y, uv)
+            got = ge.encode_frame(y, uv)
+            _compare_state(oe, ge)
+            assert got == ref, "frame %d: bytestream differs" % f
+            mb = ge.debug_read("mbinfo")
+            fr += int((((mb["mvx"] | mb["mvy"]) & 3) != 0).sum())
+            if dec:
+                pic, = dec.decode(got)
+                assert pic.luma_bytes() == ge.debug_read("recon_y").tobytes()
+    assert fr > 0
+    if dec:
+        assert dec.cover["mc_luma_fractional"] > 0
+
+
 @pytest.mark.parametrize("w,h,target", [(320, 240, 500000), (854, 480, 2500000)])
 def test_rate_control_follows_the_oracle_at_any_depth(ce, w, h, target):
     """bitrate > 0: the picture QP comes from sizes of frames 17 and more back (collected by then
