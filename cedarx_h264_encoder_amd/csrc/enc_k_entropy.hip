@@ -716,7 +716,8 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 template <bool IS_MAX>
 DEVI int block_scan_incl(int v, int *s_tmp)
 {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// (any block size up to 1024 threads: the waves that do not exist contribute the identity)
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (int)(blockDim.x >> 6);
 #pragma unroll
 	for (int off = 1; off < 64; off <<= 1) {
 		int o = __shfl_up(v, off, 64);
@@ -728,7 +729,7 @@ DEVI int block_scan_incl(int v, int *s_tmp)
 		s_tmp[wave] = v;
 	__syncthreads();
 	if (wave == 0) {
-		int t = lane < 16 ? s_tmp[lane] : (IS_MAX ? -0x7fffffff : 0);
+		int t = lane < nwaves ? s_tmp[lane] : (IS_MAX ? -0x7fffffff : 0);
 #pragma unroll
 		for (int off = 1; off < 16; off <<= 1) {
 			int o = __shfl_up(t, off, 64);
@@ -747,9 +748,16 @@ DEVI int block_scan_incl(int v, int *s_tmp)
 }
 
 // ------------------------------------------------------------------------
-// k_scan: one 1024-thread block per unit. Entry e of bit_off / run_before:
+// k_scan: one SCAN_THREADS-thread block per unit. Entry e of bit_off / run_before:
 //   e in [0, n): macroblock e of the unit; e == n: slice trailer.
 // ------------------------------------------------------------------------
+// The two per-unit scan kernels take their workgroup size from the launch: 1024 threads for a few
+// units (fewest loop trips: the single stream's entropy chain is latency), 256 for a batch. 1024
+// threads are 16 waves, which only an idle CU can take: beside a batch's k_inter, whose small
+// workgroups refill every CU as fast as they drain, a launch of 32 such blocks waited ~0.6 ms for
+// room to do 20 us of work (profiles/r02_s32: k_scan 675 us average). Four waves slip in anywhere.
+#define SCAN_THREADS ((int)blockDim.x)
+
 __global__ __launch_bounds__(1024) void k_scan(Params p)
 {
 	__shared__ int s_tmp[32];
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(1024) void k_scan(Params p)
 		s_carry_sum = p.hdr[unit].nbits;
 	}
 	__syncthreads();
-	for (int base = 0; base <= n; base += 1024) {
+	for (int base = 0; base <= n; base += SCAN_THREADS) {
 		const int e = base + threadIdx.x;
 		const bool mb = e < n, trailer = e == n;
 		const int sk = mb ? p.skip[mb0 + e] : 0;
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(1024) void k_scan(Params p)
 		if (trailer)
 			p.unit_bits[unit] = (uint32_t)(csum + incl);
 		__syncthreads();
-		if (threadIdx.x == 1023) {
+		if (threadIdx.x == SCAN_THREADS - 1) {
 			s_carry_max = m;
 			s_carry_sum = csum + incl;
 		}
@@ -968,7 +976,7 @@ __global__ __launch_bounds__(1024) void k_esc_scan(Params p)
 		if (threadIdx.x == 0)
 			s_carry = 0;
 		__syncthreads();
-		for (int base = 0; base < chunks; base += 1024) {
+		for (int base = 0; base < chunks; base += SCAN_THREADS) {
 			const int c = base + threadIdx.x;
 			const int v = c < chunks ? (int)cnt[c] : 0;
 			const int incl = block_scan_incl<false>(v, s_tmp);
@@ -976,7 +984,7 @@ __global__ __launch_bounds__(1024) void k_esc_scan(Params p)
 			if (c < chunks)
 				cnt[c] = (uint32_t)(carry + incl - v);
 			__syncthreads();
-			if (threadIdx.x == 1023)
+			if (threadIdx.x == SCAN_THREADS - 1)
 				s_carry = carry + incl;
 			__syncthreads();
 		}
@@ -1052,11 +1060,11 @@ int Launch::entropy(const Params &p, void *stream)
 		hipLaunchKernelGGL(k_cavlc2, dim3((mbs + 1) / 2, p.n_streams), dim3(64), 0, s, p);
 	else
 		hipLaunchKernelGGL(k_cavlc, dim3((mbs + 63) / 64, p.n_streams), dim3(64), 0, s, p);
-	hipLaunchKernelGGL(k_scan, dim3(n_units), dim3(1024), 0, s, p);
+	hipLaunchKernelGGL(k_scan, dim3(n_units), dim3(n_units > 8 ? 256 : 1024), 0, s, p);
 	hipLaunchKernelGGL(k_zero, dim3((p.rbsp_cap / 16 + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_pack, dim3((p.unit_mb_cap + 2 + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_esc_count, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
-	hipLaunchKernelGGL(k_esc_scan, dim3(n_units), dim3(1024), 0, s, p);
+	hipLaunchKernelGGL(k_esc_scan, dim3(n_units), dim3(n_units > 8 ? 256 : 1024), 0, s, p);
 	hipLaunchKernelGGL(k_esc_write, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
 	return (int)hipGetLastError();
 }

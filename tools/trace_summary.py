@@ -5,7 +5,8 @@
 
 Prints, for the session's kernels (cedar::*, config-time probes left out):
   * per kernel: launches, average / min / max duration, share of the busy time;
-  * the steady-state window (the last 60 % of the dispatches): wall span, the union of
+  * the steady-state window (second half of the longest uninterrupted run of dispatches = the
+    measured session's timed region): wall span, the union of
     all kernel intervals ("GPU busy"), the idle gaps between them and, per hardware
     queue, the busy time -- i.e. which kernel or which launch gap owns a step.
 The full trace is large; this text is what gets committed under profiles/.
@@ -35,8 +36,19 @@ def main():
     print("%-44s %8s %10s %10s %10s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "share"))
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         print("%-44s %8d %10.1f %10.1f %10.1f %6.1f%%" % (n[:44], len(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
-    # steady state: the last 60 % of the dispatches
-    ss = rows[int(len(rows) * 0.4):]
+    # bench.py runs several sessions (a throw-away one to warm the runtime, the measured one, one with
+    # frames back to back for the work times): they are separated by milliseconds of set-up. Steady
+    # state = the second half of the longest run of dispatches without a 1.5 ms hole.
+    runs, cur = [], [rows[0]]
+    for prev, r in zip(rows, rows[1:]):
+        if r[0] - max(prev[1], cur[-1][1]) > 1500000:
+            runs.append(cur)
+            cur = []
+        cur.append(r)
+    runs.append(cur)
+    ss = max(runs, key=len)
+    print("sessions seen: %d (dispatches %s); the longest is summarised" % (len(runs), [len(x) for x in runs]))
+    ss = ss[len(ss) // 2:]
     t0, t1 = ss[0][0], max(e for _, e, _, _ in ss)
     span = (t1 - t0) / 1e3
     busy, cur_s, cur_e = 0.0, None, None
