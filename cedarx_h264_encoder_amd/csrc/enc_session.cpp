@@ -156,6 +156,7 @@ struct InFlight {
 	std::vector<long> lane_gidx; // [n_streams] global frame index per lock-step lane (-1: idle lane)
 	bool gop_start = false;      // gop_parallel: every lane starts a GOP with this step, whatever the counter says
 	int qp = 0;                  // the picture's QP
+	int qp_bump = 0;             // ... of which this much because an earlier attempt had a macroblock above 3200 bits
 	int lane = 0;          // entropy lane
 	hipStream_t s_db = nullptr, s_ent = nullptr; // the streams that carry this frame's deblocking / entropy coding
 	bool events = true;    // done_main / done_ent were recorded (frames not pipelined)
@@ -830,8 +831,10 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "aud must be 0 or 1");
 	if (ext.subpel < 0 || ext.subpel > 2)
 		return fail(e, -EINVAL, "subpel %d outside 0..2", ext.subpel);
-	if (ext.strict_mb_bits != 0 && ext.strict_mb_bits != 1)
-		return fail(e, -EINVAL, "strict_mb_bits must be 0 or 1");
+	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
+		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
+	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
+		return fail(e, -EINVAL, "requantising oversize pictures wants one stream, whole pictures, no GOP lanes (one QP per launch)");
 	if (ext.bitrate < 0 || (ext.bitrate > 0 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count)))
 		return fail(e, -EINVAL, "rate control wants one stream, whole pictures, no GOP lanes");
 	if (mb_h > 512 * ext.slice_count)
@@ -1403,6 +1406,7 @@ struct ReplayIn {
 	std::vector<uint8_t> own;
 	std::vector<long> gidx;
 	bool gop_start;
+	int qp_bump = 0;
 };
 
 static int submit_frame(cedar_enc *e, const ReplayIn *replay)
@@ -1432,8 +1436,10 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	f.done_tag = seq;
 	Params P = e->P;
 	P.is_idr = idr;
-	if (e->rc_target > 0)
-		set_qp_params(P, rc_pick_qp(e->cfg.qp, e->rc_target, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyframe_interval),
+	f.qp_bump = replay ? replay->qp_bump : 0;
+	if (e->rc_target > 0 || f.qp_bump)
+		set_qp_params(P, (e->rc_target > 0 ? rc_pick_qp(e->cfg.qp, e->rc_target, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyframe_interval)
+						   : e->cfg.qp) + f.qp_bump,
 			      e->chroma_qp_offset);
 	f.qp = P.qp;
 	if (e->fault_at && seq != e->fault_at) // tests: lose the hand-off of one chosen submit only
@@ -1772,10 +1778,12 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 // (h264enc.c:189-192). With frames in flight "the next frame" has already been submitted on top
 // of the broken one: drain the device, put the GOP / reference state back to what it was before
 // the failed frame, and encode the frames behind it again from the inputs the session still holds.
-static int recover(cedar_enc *e, const InFlight &failed)
+static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again = nullptr)
 {
 	hipDeviceSynchronize();
 	std::vector<ReplayIn> later;
+	if (again) // the failed frame itself goes first (requantised, see collect_frame)
+		later.push_back(*again);
 	for (int k = 0; k < e->fl_count; k++) {
 		InFlight &g = e->fl[(e->fl_head + k) % e->depth];
 		later.push_back(ReplayIn{ g.in_used, g.in_own, g.lane_gidx, g.gop_start });
@@ -1859,6 +1867,18 @@ static int collect_frame(cedar_enc *e)
 	flags &= ~4u;
 	if (oversize && !e->ext.strict_mb_bits)
 		e->stats.oversize_frames++;
+	if (oversize && e->ext.strict_mb_bits == 2 && !hip_failed && !wf_err && !flags && !too_big && f.qp + 6 <= 51) {
+		// The hard cap: the picture is coded again 6 QP steps coarser (slice_qp_delta), as often as it
+		// takes -- the frames submitted behind it run again on the new reconstruction. Noise at a very
+		// low QP is what gets here; everything else never does.
+		ReplayIn again{ f.in_used, f.in_own, f.lane_gidx, f.gop_start, f.qp_bump + 6 };
+		const InFlight snapshot = f;
+		const int rc = recover(e, snapshot, &again);
+		if (rc)
+			return rc;
+		e->stats.requantised_frames++;
+		return collect_frame(e);
+	}
 	if (hip_failed || wf_err || flags || too_big || (oversize && e->ext.strict_mb_bits)) {
 		// this frame is dropped, the session is where it was before it, the frames behind it run again
 		const int rc = recover(e, f);

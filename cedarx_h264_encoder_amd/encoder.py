@@ -50,7 +50,8 @@ class _Stats(ctypes.Structure):
                 ("ms", ctypes.c_double * 6), ("encode_wall_ms", ctypes.c_double),
                 ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int),
                 ("frames_pipelined", ctypes.c_int), ("idr_lookahead", ctypes.c_int), ("depth", ctypes.c_int),
-                ("deblock_streams", ctypes.c_int), ("oversize_frames", ctypes.c_uint64), ("frame_qp", ctypes.c_int)]
+                ("deblock_streams", ctypes.c_int), ("oversize_frames", ctypes.c_uint64), ("frame_qp", ctypes.c_int),
+                ("requantised_frames", ctypes.c_uint64)]
 
 
 _lib = None
@@ -164,7 +165,7 @@ class EncoderConfig:
     fps_den: int = 0
     first_frame_index: int = 0  # global index of this session's first frame (a multiple of keyframe_interval)
     gop_parallel: int = 0       # G > 1: G consecutive closed GOPs of every stream are encoded side by side
-    strict_mb_bits: int = 0     # 1: a picture with a macroblock above 3200 bits fails with EOVERFLOW
+    strict_mb_bits: int = 0     # a picture with a macroblock above 3200 bits: 0 counted, 1 EOVERFLOW, 2 coded again at QP + 6
     subpel: int = 0             # motion vectors: 0 whole samples, 1 half, 2 quarter
     bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
 
@@ -279,7 +280,7 @@ class CedarEncoder:
         return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms, "wf_split": s.wf_split,
                 "deblock_planes_split": bool(s.deblock_planes_split),
                 "frames_pipelined": bool(s.frames_pipelined), "idr_lookahead": bool(s.idr_lookahead),
-                "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames, "frame_qp": s.frame_qp,
+                "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames, "frame_qp": s.frame_qp, "requantised_frames": s.requantised_frames,
                 "ms": {n: s.ms[i] for i, n in enumerate(STAGES)},
                 "launches": {n: s.launches[i] for i, n in enumerate(STAGES)}}
 

@@ -104,10 +104,13 @@ struct cedar_enc_config_ext {
 				n is delivered once frame n + (G-1)*keyframe_interval has been submitted (or
 				after cedar_enc_flush). cedar_enc_session_depth() says how many frames the
 				caller may have in flight. 0 / 1: off                                    */
-	int strict_mb_bits;  /* H.264 A.3.1 allows a macroblock 3200 bits; pure noise at QP <= 16 passes that
-				(no I_PCM fallback exists yet). 0: such a picture is emitted as it is and
-				counted (cedar_enc_stats.oversize_frames); 1: it fails with -EOVERFLOW and is
-				dropped like any failed frame                                            */
+	int strict_mb_bits;  /* H.264 A.3.1 allows a macroblock 3200 bits; pure noise at QP <= 16 passes that.
+				0: such a picture is emitted as it is and counted
+				   (cedar_enc_stats.oversize_frames);
+				1: it fails with -EOVERFLOW and is dropped like any failed frame;
+				2: it is coded again 6 QP steps coarser (slice_qp_delta), as often as it takes,
+				   so no emitted macroblock ever exceeds the limit
+				   (cedar_enc_stats.requantised_frames; one stream, whole pictures)       */
 	int subpel;          /* motion vector precision: 0 whole samples (default; what round 1 shipped), 1 half,
 				2 quarter samples -- a refinement of the 8 half- and then 8 quarter-sample
 				neighbours of the best whole-sample vector, 6-tap interpolation of H.264
@@ -214,6 +217,7 @@ struct cedar_enc_stats {
 	int      deblock_streams;                /* deblock streams in use                             */
 	uint64_t oversize_frames;                /* frames with a macroblock above 3200 bits (A.3.1)   */
 	int      frame_qp;                       /* slice QP of the frame collected last (rate control) */
+	uint64_t requantised_frames;             /* re-encodes because of a macroblock above 3200 bits  */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */

@@ -52,8 +52,9 @@ typedef struct h264o_config {
 	int bitrate;          /* > 0: frame-level rate control towards this many bits per second (frame rate
 	                       * fps_num/fps_den, 30 when unset): the slice QP follows h264o_rc_pick_qp;
 	                       * 0: fixed QP, as the reference (cedar.c:1165-1168 PARA1 = qp) */
-	int strict_mb_bits;   /* 1: a picture with a macroblock_layer() of more than 3200 bits (H.264 A.3.1) is
-	                       * refused with -EOVERFLOW instead of emitted; 0: emitted and counted */
+	int strict_mb_bits;   /* a picture with a macroblock_layer() of more than 3200 bits (H.264 A.3.1): 0 emitted
+	                       * and counted; 1 refused with -EOVERFLOW; 2 coded again 6 QP steps coarser (slice_qp_delta)
+	                       * until every macroblock fits, -EOVERFLOW if QP 51 does not do it */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */

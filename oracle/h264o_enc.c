@@ -1929,7 +1929,7 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 {
 	int max_mb_bits = 0, ue_bits_of_run = 0;
 	int idr = e->frame_p_count == 0; /* cedar.c:1047-1050 */
-	int o = 0, s, mx, my, r;
+	int o = 0, o_hdr, s, mx, my, r;
 	int idr_pic_id = (e->frame_count / e->cfg.keyint) & 1;
 
 	pad_source(e, luma, chroma);
@@ -1958,6 +1958,10 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 
 		e->qp = rc_pick_qp(e->cfg.qp, (int64_t)e->cfg.bitrate * fd / fn, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyint);
 	}
+	o_hdr = o;
+again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is coded again, 6 QP steps coarser */
+	o = o_hdr;
+	max_mb_bits = 0;
 
 	/* analysis + reconstruction */
 	for (s = 0; s < e->cfg.slice_count; s++) {
@@ -2062,6 +2066,10 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 			return -ENOSPC;
 		/* H.264 A.3.1: no macroblock_layer() above 3200 bits. No I_PCM fallback exists yet: the picture is
 		 * refused when asked to be strict (state untouched, as for any failed frame), else emitted */
+		if (max_mb_bits > 3200 && e->cfg.strict_mb_bits == 2 && e->qp + 6 <= 51) {
+			e->qp += 6; /* nothing of the session's state has been committed yet: just code it again */
+			goto again;
+		}
 		if (max_mb_bits > 3200 && e->cfg.strict_mb_bits)
 			return -EOVERFLOW;
 		r = nal_write(out + o, out_cap - o, idr ? 3 : 2, idr ? 5 : 1, e->rbsp, (int)(b.pos >> 3));

@@ -723,6 +723,34 @@ def test_macroblocks_above_3200_bits_are_counted_or_refused(ce):
     assert 0 < dq.max_mb_bits <= 3200
 
 
+@pytest.mark.parametrize("qp,keyint", [(1, 25), (12, 3)])
+def test_oversize_pictures_are_requantised_until_every_macroblock_fits(ce, qp, keyint):
+    """strict_mb_bits = 2, the hard cap: a picture with a macroblock above 3200 bits is coded again 6 QP
+    steps coarser (slice_qp_delta), with the frames in flight behind it re-encoded on the new
+    reconstruction. Same QPs and bytes as the scalar twin, synchronous or with the ring full; the
+    independent decoder finds no macroblock above the limit and the session's own reconstruction."""
+    from tests.indep import h264_refdec as rd
+    w, h, n = 64, 48, 7
+    frames = [ol.gen_frame("CB"[f % 5 == 4], w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, strict_mb_bits=2))
+    want, qps = [], []
+    for y, uv in frames:
+        want.append(oe.encode(y, uv))
+        qps.append(oe.frame_qp())
+    assert max(qps) > qp
+    dec = rd.Decoder()
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
+        for f, (y, uv) in enumerate(frames):
+            au = enc.encode_frame(y, uv)
+            assert au == want[f], f
+            assert enc.stats()["frame_qp"] == qps[f]
+            pic, = dec.decode(au)
+            assert pic.luma_bytes() == enc.debug_read("recon_y").tobytes()
+        assert enc.stats()["requantised_frames"] > 0 and dec.max_mb_bits <= 3200
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
+        assert _encode_pipelined(enc, frames) == want
+
+
 def test_failed_encode_is_retryable_on_the_same_session(ce, monkeypatch):
     """cedar.c:1182-1191 return before the GOP counter and the reference swap (:1193-1201): the caller
     may simply call ENCODE again. Here the failed attempt leaves completion words, progress words and
