@@ -156,3 +156,44 @@ def test_hip_cli_usage_and_config_error(tmp_path):
     assert r.returncode == 255 and b"Usage:" in r.stdout
     r = subprocess.run([HIPCLI, "-", "321", "240", str(tmp_path / "o.264")], input=b"", capture_output=True)
     assert r.returncode != 0 and b"CEDAR_IOCTL_CONFIG failed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_hip_cli_skips_exactly_the_failed_frame(tmp_path):
+    """h264enc.c:189-192: a failed ENCODE is reported, that frame is not written, the loop goes on and
+    the driver's GOP counter and reference frames are as before it (cedar.c:1182-1201). The pipelined
+    pump does the same with frames in flight: the file is the oracle's encode of the input WITHOUT the
+    failed frame, the process ends with 0 like the reference."""
+    w, h, frames, bad = 640, 368, 12, 4
+    raw = _raw("B", w, h, frames)
+    out = tmp_path / "out.264"
+    env = dict(os.environ, H264ENC_QP="26", H264ENC_KEYINT="5", CEDAR_FAULT_INJECT="1", CEDAR_FAULT_INJECT_AT=str(bad + 1))
+    r = subprocess.run([HIPCLI, "-", str(w), str(h), str(out)], input=raw, capture_output=True, env=env, timeout=200)
+    assert r.returncode == 0
+    assert b"CEDAR_IOCTL_ENCODE failed" in r.stderr and r.stderr.count(b"failed") == 1
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=26, keyint=5))
+    want = b"".join(enc.encode(*ol.gen_frame("B", w, h, f)) for f in range(frames) if f != bad)
+    assert out.read_bytes() == want
+    _decode_all(want, frames - 1)
+
+
+@pytest.mark.gpu
+def test_hip_cli_gop_parallel_subpel_and_first_frame(tmp_path):
+    """H264ENC_GOP_PARALLEL (G closed GOPs side by side, flushed at EOF), H264ENC_SUBPEL and
+    H264ENC_FIRST_FRAME (a GOP shard) through the command line: the bytes of the plain run / the oracle."""
+    w, h, frames, K = 320, 240, 23, 4
+    raw = _raw("B", w, h, frames)
+    enc = ol.OracleEncoder(ol.default_config(w, h, qp=28, keyint=K, subpel=2))
+    aus = [enc.encode(*ol.gen_frame("B", w, h, f)) for f in range(frames)]
+    out = tmp_path / "gop.264"
+    env = dict(os.environ, H264ENC_QP="28", H264ENC_KEYINT=str(K), H264ENC_SUBPEL="2", H264ENC_GOP_PARALLEL="3")
+    r = subprocess.run([HIPCLI, "-", str(w), str(h), str(out)], input=raw + b"\1" * 999, capture_output=True, env=env, timeout=200)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert out.read_bytes() == b"".join(aus)
+    # the shard that starts at GOP 2: frames 8.. of the same input, no parameter sets (they go with frame 0)
+    out2 = tmp_path / "shard.264"
+    env2 = dict(os.environ, H264ENC_QP="28", H264ENC_KEYINT=str(K), H264ENC_SUBPEL="2", H264ENC_FIRST_FRAME=str(2 * K))
+    fsz = w * h * 3 // 2
+    r = subprocess.run([HIPCLI, "-", str(w), str(h), str(out2)], input=raw[2 * K * fsz:4 * K * fsz], capture_output=True, env=env2, timeout=200)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert out2.read_bytes() == b"".join(aus[2 * K:4 * K])
