@@ -907,7 +907,7 @@ def test_gop_parallel_two_streams_and_collect_before_input_is_there(ce):
         assert [g[s] for g in got] == want[s], s
 
 
-@pytest.mark.parametrize("mode", ["plain", "narrow", "wide"])
+@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2"])
 def test_fuzz_sweep_against_oracle(mode):
     """tools/fuzz_parity.py with a fixed seed: random geometry (every other picture 1-3 macroblocks
     wide or high in "narrow"), QP, GOP length, slices, streams (up to 33 in "wide"), search range,
@@ -920,6 +920,8 @@ def test_fuzz_sweep_against_oracle(mode):
         env["FUZZ_NARROW"] = "1"
     if mode == "wide":
         env["FUZZ_WIDE"] = "1"
+    if mode == "r2":   # round 2's options on top: sub-sample vectors, the macroblock bit cap, rate control, GOP lanes
+        env["FUZZ_R2"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "40"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=root)

@@ -42,6 +42,19 @@ for case in range(n_cases):
     if os.environ.get("FUZZ_BIG"):
         n, S = min(n, 5), min(S, 2)
     depth_draw = int(rng.randint(1, 17))
+    G = 0
+    if os.environ.get("FUZZ_R2"):   # round 2's options: sub-sample vectors, the macroblock bit cap, rate control, GOP lanes
+        kw.update(subpel=int(rng.choice([0, 1, 2, 2])))
+        pick = int(rng.randint(0, 4))
+        if S == 1 and pick == 1:
+            kw.update(strict_mb_bits=2)
+        elif S == 1 and pick == 2:
+            n = int(rng.randint(19, 30))
+            kw.update(bitrate=int(rng.choice([1, 4, 20])) * w * h)
+        elif pick == 3 and S <= 3:
+            G = int(rng.randint(2, 5))
+            n = int(rng.randint(3, 3 * keyint * G + 3))
+            kw.pop("repeat_headers", None)
     if case < first_case:
         continue
     print("case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s n %d depth<=%d" % (case, w, h, qp, keyint, slices, S, pat, kw, n, depth_draw), flush=True)
@@ -53,7 +66,7 @@ for case in range(n_cases):
         okw["chroma_qp_offset"] = okw.pop("chroma_qp_offset_minus4") + 4
     oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **okw)) for _ in range(S)]
     want = [[oes[s].encode(*frames[f][s]) for s in range(S)] for f in range(n)]
-    if os.environ.get("FUZZ_WIDE") and slices >= 2 and S == 1 and case % 3 == 0:
+    if os.environ.get("FUZZ_WIDE") and slices >= 2 and S == 1 and case % 3 == 0 and not ({"strict_mb_bits", "bitrate"} & set(kw)):
         # the slices of one picture on two sessions ("two GPUs"): the concatenation is the whole
         a = int(rng.randint(1, slices))
         parts = [ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices,
@@ -74,14 +87,17 @@ for case in range(n_cases):
             sys.exit("MISMATCH (sharded slices %d+%d) seed %d case %d: %dx%d qp %d keyint %d slices %d pattern %s %s" % (
                 a, slices - a, seed, case, w, h, qp, keyint, slices, pat, kw))
         continue
-    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, n_streams=S, **kw) as enc:
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, n_streams=S, gop_parallel=G, **kw) as enc:
         depth, got, q = min(enc.pipeline_depth, depth_draw), [], 0
+        if G:
+            depth = enc.pipeline_depth
         for fr in frames:
             if q == depth:
                 enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
             for s in range(S):
                 enc.set_input(fr[s][0], fr[s][1], stream=s)
             enc.submit(); q += 1
+        enc.flush()
         while q:
             enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
     if got != want:
