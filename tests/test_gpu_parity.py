@@ -885,6 +885,55 @@ def test_gop_parallel_session_equals_the_serial_stream(ce, w, h, K, G, n, device
     assert not bad, "first differing frames: %s" % bad[:8]
 
 
+@pytest.mark.parametrize("at", [1, 3, 6])
+def test_gop_parallel_failed_step_drops_one_frame_per_lane_and_nothing_drifts(ce, monkeypatch, at):
+    """A lock-step step that fails takes one frame of every GOP lane with it (each reported by its own
+    collect); the steps behind it are coded again on the state from before it, and every lane starts
+    its next GOP on time. What is delivered must decode, picture for picture, to something close to
+    its source: a reference that drifted would show at once."""
+    from tests.indep import h264_refdec as rd
+    w, h, K, G, n = 320, 240, 4, 3, 30
+    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
+    monkeypatch.setenv("CEDAR_FAULT_INJECT", "1")
+    monkeypatch.setenv("CEDAR_FAULT_INJECT_AT", str(at))     # the at-th lock-step step
+    got, failed = {}, []
+    with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=K, gop_parallel=G) as enc:
+        depth, q, nxt = enc.pipeline_depth, 0, 0
+
+        def take():
+            nonlocal nxt
+            try:
+                enc.collect()
+                got[nxt] = enc.output()
+            except ce.EncoderError as ex:
+                assert ex.errno == errno.EIO
+                failed.append(nxt)
+            nxt += 1
+        for f in range(n):
+            if q == depth:
+                take()
+                q -= 1
+            enc.set_input(*frames[f])
+            enc.submit()
+            q += 1
+        enc.flush()
+        while q:
+            take()
+            q -= 1
+    grp, t = (at - 1) // K, (at - 1) % K              # the step's group of G GOPs and its position inside them
+    assert failed == [(grp * G + g) * K + t for g in range(G)]
+    dec = rd.Decoder()
+    for f in sorted(got):
+        pic, = dec.decode(got[f])
+        y = np.frombuffer(pic.luma_bytes(), np.uint8).reshape(240, 320).astype(np.float64)
+        mse = ((y - frames[f][0].reshape(h, w)) ** 2).mean()
+        assert mse < 40, (f, mse)                      # ~35 dB at QP 26; a wrong reference gives hundreds
+    kinds = {f: [got[f][i + 4] & 0x1f for i in range(len(got[f]) - 4) if got[f][i:i + 4] == b"\0\0\0\1"] for f in got}
+    for f in got:                                      # every GOP starts with an IDR picture: its first delivered frame
+        first_of_gop = min(x for x in got if x // K == f // K)
+        assert (5 in kinds[f]) == (f == first_of_gop), (f, kinds[f])
+
+
 def test_gop_parallel_two_streams_and_collect_before_input_is_there(ce):
     w, h, K, G, n = 320, 240, 4, 3, 19
     frames = [[ol.gen_frame("B", w, h, f, s << 8) for s in range(2)] for f in range(n)]
