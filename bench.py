@@ -12,6 +12,8 @@ streams (configs[4]: independent streams shard with no collective), so scaling i
 weak and `value` is total macroblocks of all ranks / max-over-ranks time.
 `--slices-across-gpus` is configs[3] instead: rank k encodes slice k of ONE picture
 (3840x2160 by default), the host concatenates the slice NALs; strong scaling.
+`--gops-across-gpus` shards ONE stream by closed GOPs: GOP g on rank
+g mod N, a step = one GOP per rank, the byte ranges concatenate to the serial stream.
 
 Inputs are resident in HBM before the timed region (device-input entry point of
 the C-ABI); the Annex-B bytes land in pinned host memory inside it.
@@ -92,6 +94,8 @@ def parse():
                     help="also report ONE stream with this many closed GOPs side by side (0 = skip)")
     ap.add_argument("--slices-across-gpus", action="store_true",
                     help="configs[3]: rank k encodes slice k of one picture (default 3840x2160), no collective")
+    ap.add_argument("--gops-across-gpus", action="store_true",
+                    help="ONE stream, GOP g on rank g mod N (cedar_enc_set_frame_index), no collective; a step = one GOP per rank")
     a = ap.parse_args()
     if not a.width:
         a.width, a.height = (3840, 2160) if a.slices_across_gpus else (1920, 1080)
@@ -117,7 +121,8 @@ def run_rank(args, rank, world, local_rank):
     def make_inputs(S):
         ins = []
         for s in range(S):
-            gs = (0 if args.slices_across_gpus else rank * S) + s  # global stream id: seed offset s<<8
+            # global stream id: seed offset s<<8; one picture / one stream sharded: the same on every rank
+            gs = (0 if (args.slices_across_gpus or args.gops_across_gpus) else rank * S) + s
             fr = []
             for f in range(args.frames):
                 y, uv = ce.gen_pattern("B", W, H, f, gs << 8)
@@ -257,6 +262,8 @@ def run_rank(args, rank, world, local_rank):
             dt = time.perf_counter() - t0
         return n, dt
 
+    if args.gops_across_gpus:
+        return run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, barrier, allmax, mbs_per_frame)
     S = args.streams
     sweep = [int(x) for x in str(args.batched_streams).split(",") if x.strip() and int(x) > 0 and int(x) != S]
     gsweep = [int(x) for x in str(args.gop_parallel).split(",") if x.strip() and int(x) > 1]
@@ -462,6 +469,86 @@ def run_rank(args, rank, world, local_rank):
         "batched": batched,
     }
     return out
+
+
+def run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, barrier, allmax, mbs_per_frame):
+    """ONE stream sharded by closed GOPs: rank r codes GOPs r, r + N, ... (`cedar_enc_set_frame_index`
+    moves its session on), the host would concatenate the byte ranges in GOP order. A step is one GOP per
+    rank; the run gathers the first GOPs of every rank and checks the concatenation against ONE session
+    coding the same frames serially (outside the timed region; the data path has no collective)."""
+    W, H, K = args.width, args.height, args.keyint
+    inputs = make_inputs(1)[0]
+    nf = len(inputs)
+
+    def gop(enc, g, keep=None):
+        enc.set_frame_index(g * K)
+        depth, q, nb = enc.pipeline_depth, 0, 0
+        for t in range(K):
+            if q == depth:
+                nb += enc.collect()
+                q -= 1
+                if keep is not None:
+                    keep.append(enc.output(0))
+            y, uv = inputs[(g * K + t) % nf]
+            enc.set_device_input(0, y.data_ptr(), uv.data_ptr())
+            enc.submit()
+            q += 1
+        while q:
+            nb += enc.collect()
+            q -= 1
+            if keep is not None:
+                keep.append(enc.output(0))
+        return nb
+
+    enc = ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=K, device=local_rank)
+    mine = []
+    for k in range(max(1, args.warmup // K) + 1):          # untimed: this rank's first GOPs (kept for the check)
+        gop(enc, k * world + rank, mine if k < 2 else None)
+    first = (max(1, args.warmup // K) + 1) * world
+    barrier()
+    t0 = time.perf_counter()
+    nbytes = 0
+    for k in range(args.steps):
+        nbytes += gop(enc, first + k * world + rank)
+    barrier()
+    dt = allmax(time.perf_counter() - t0)
+    enc.close()
+    ok = None
+    parts = [None] * world
+    if world > 1:
+        dist.all_gather_object(parts, mine)
+    else:
+        parts = [mine]
+    if rank == 0:
+        with ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=K, device=local_rank) as one:
+            serial = []
+            for f in range(2 * world * K):
+                y, uv = inputs[f % nf]
+                one.set_device_input(0, y.data_ptr(), uv.data_ptr())
+                one.encode()
+                serial.append(one.output(0))
+        shards = []
+        for k in range(2):
+            for r in range(world):
+                shards += parts[r][k * K:(k + 1) * K]
+        ok = shards == serial
+        if not ok:
+            raise SystemExit("GOP shards from %d ranks do not concatenate to the serial stream" % world)
+    if rank != 0:
+        return None
+    frames = args.steps * world * K
+    value = frames * mbs_per_frame / dt
+    return {"metric": "macroblocks/s @ fixed QP, 1080p nv12" if (W, H) == (1920, 1080) else "macroblocks/s @ fixed QP, %dx%d nv12" % (W, H),
+            "value": value, "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%dx%d nv12 I+P keyint %d QP %d, pattern-B, ONE stream sharded by closed GOPs: GOP g on GPU g mod %d "
+                                   "(SURVEY 8(e) row 2; a step = one GOP of %d frames per GPU; no collective)" % (W, H, K, args.qp, world, K),
+                       "parallelism": "closed GOPs x%d of one stream, no collective" % world,
+                       "frames_per_step": world * K, "macroblocks_per_frame": mbs_per_frame,
+                       "gop_shards_concatenate_to_the_serial_stream": ok,
+                       "realtime_4k30_multiple": value / 972000.0},
+            "roofline": None, "cpu_baseline": None}
 
 
 def main():

@@ -1522,11 +1522,14 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		f.in_used[s] = in_ptr(s, false);
 		f.in_used[S + s] = in_ptr(s, true);
 	}
-	// (a plain session counts its frames itself, replayed or not; GOP lanes keep the frame they were given)
-	if (!e->mux)
+	// (a plain session counts its frames itself; a replayed frame comes with its index, which recover()
+	// has moved up by the frame that was dropped; GOP lanes keep the frame they were given)
+	if (replay)
+		f.lane_gidx = replay->gidx;
+	else if (!e->mux)
 		f.lane_gidx.assign((size_t)S, (long)e->ext.first_frame_index + e->frame_count);
 	else
-		f.lane_gidx = replay ? replay->gidx : e->lane_gidx;
+		f.lane_gidx = e->lane_gidx;
 	if (replay)
 		e->in_tab_valid[ds] = false; // the table of this slot, if any, describes another frame
 	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
@@ -1784,9 +1787,17 @@ static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again =
 	std::vector<ReplayIn> later;
 	if (again) // the failed frame itself goes first (requantised, see collect_frame)
 		later.push_back(*again);
+	// a plain session's frames behind a dropped one move up by one frame index -- up to the next frame
+	// that was given its index explicitly (cedar_enc_set_frame_index: it starts a GOP where it is)
+	long shift = (again || e->mux) ? 0 : 1;
 	for (int k = 0; k < e->fl_count; k++) {
 		InFlight &g = e->fl[(e->fl_head + k) % e->depth];
-		later.push_back(ReplayIn{ g.in_used, g.in_own, g.lane_gidx, g.gop_start });
+		if (g.gop_start && !e->mux)
+			shift = 0;
+		std::vector<long> gidx = g.lane_gidx;
+		for (long &v : gidx)
+			v = v < 0 ? v : v - shift;
+		later.push_back(ReplayIn{ g.in_used, g.in_own, gidx, g.gop_start });
 		g.active = false;
 	}
 	const GopState &b = failed.before;
@@ -2096,6 +2107,20 @@ extern "C" int cedar_enc_collect(cedar_enc *e)
 	if (!e || !e->configured)
 		return -EINVAL;
 	return e->mux ? mux_collect(e) : collect_frame(e);
+}
+
+extern "C" int cedar_enc_set_frame_index(cedar_enc *e, int index)
+{
+	if (!e || !e->configured)
+		return -EINVAL;
+	if (e->mux)
+		return fail(e, -EINVAL, "gop_parallel sessions number their frames themselves");
+	if (index < 0 || index % e->cfg.keyframe_interval)
+		return fail(e, -EINVAL, "frame %d is not the start of a GOP (keyframe interval %d)", index, e->cfg.keyframe_interval);
+	// frames already in flight keep the index they were submitted under (InFlight::lane_gidx)
+	e->ext.first_frame_index = index - e->frame_count;
+	e->next_gop_start = true; // cedar.c:1047-1050: the next picture is an IDR picture (recorded with the frame: a replay keeps it)
+	return 0;
 }
 
 extern "C" int cedar_enc_flush(cedar_enc *e)

@@ -110,6 +110,7 @@ def load_library():
     L.cedar_enc_submit.argtypes = [vp]
     L.cedar_enc_collect.argtypes = [vp]
     L.cedar_enc_flush.argtypes = [vp]
+    L.cedar_enc_set_frame_index.argtypes = [vp, ci]
     L.cedar_enc_close.argtypes = [vp]
     L.cedar_enc_close.restype = None
     L.cedar_enc_stream_output.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ci)]
@@ -244,6 +245,10 @@ class CedarEncoder:
 
     def collect(self):
         return self._check(self._L.cedar_enc_collect(self._h), "collect")
+
+    def set_frame_index(self, index):
+        """the next frame submitted is frame `index` of the stream and starts a GOP (GOP shards)"""
+        return self._check(self._L.cedar_enc_set_frame_index(self._h, index), "set_frame_index")
 
     def flush(self):
         """gop_parallel sessions: no more frames will come, deliver what is buffered."""

@@ -188,6 +188,11 @@ int cedar_enc_pipeline_depth(void);                  /* the compile-time maximum
 int cedar_enc_session_depth(const cedar_enc *enc);   /* this session's; -EINVAL before CONFIG */
 int cedar_enc_submit(cedar_enc *enc);
 int cedar_enc_collect(cedar_enc *enc);
+/* The next frame submitted is frame `index` of the stream (a multiple of keyframe_interval) and starts
+ * a GOP: a session that codes GOPs r, r + N, r + 2N, ... of a stream sharded over N GPUs moves on with
+ * this instead of being configured again (first_frame_index is where it starts). idr_pic_id and the
+ * SPS / PPS cadence follow the index (cedar.c:1001, :1047, :1058-1061). Not for gop_parallel sessions. */
+int cedar_enc_set_frame_index(cedar_enc *enc, int index);
 /* gop_parallel sessions: no more frames will come; the GOPs buffered so far are encoded with the
  * missing lanes idle, and cedar_enc_collect delivers what is left. collect returns -EAGAIN when
  * the next frame in order needs more input (or a flush) first. A no-op for other sessions. */

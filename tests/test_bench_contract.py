@@ -81,3 +81,19 @@ def test_bench_slices_across_ranks_concatenate():
     assert j["config"]["slices_concatenate_to_one_session_stream"] is True
     assert abs(j["value"] - 3600 * 12 / (j["ms_per_step"] * 12e-3)) < 1e-3 * j["value"]   # ONE picture per step
     assert "slices x2" in j["config"]["parallelism"] and j["config"]["idr_in_timed_region"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_gop_shards_across_ranks_concatenate():
+    """SURVEY 8(e) row 2 as a harness: ONE stream, GOP g on rank g mod N; the run checks that the shards'
+    bytes, in GOP order, are the serial stream. Two ranks on the one card of this box over gloo."""
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gops-across-gpus", "--width", "640", "--height", "368",
+           "--keyint", "5", "--steps", "4", "--warmup", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["gop_shards_concatenate_to_the_serial_stream"] is True
+    assert abs(j["value"] - 2 * 5 * 4 * 920 / (j["ms_per_step"] * 4e-3)) < 1e-3 * j["value"]
