@@ -318,7 +318,7 @@ def run_rank(args, rank, world, local_rank):
         gdt = allmax(gdt)
         v = world * mbs_per_frame * n / gdt
         gop_par.append({"gops_side_by_side": G, "frames": n, "value": v, "ms_per_frame": gdt / n * 1e3,
-                        "latency_frames": (G - 1) * K + 1,
+                        "latency_frames": 2 * (G - 1) * K + 9,   # gop_low_latency = 0: the next group's IDR step hides
                         "pipeline_frac_of_hbm_peak": v * 1136.64 / 1e9 / HBM_PEAK_GBS})
     work_ms = measure_work(S, inputs) if profile else None
 

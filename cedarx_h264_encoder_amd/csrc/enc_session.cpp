@@ -183,6 +183,8 @@ struct InFlight {
 struct GopMux {
 	int G = 1, K = 1, S = 1;          // lanes per stream, GOP length, the caller's streams
 	int cap = 0;                      // frames the rings hold
+	int user_depth = 0;               // frames the caller may have in flight
+	bool ahead = false;               // user_depth includes a second (G-1) K of look-ahead
 	long n_sub = 0, n_col = 0;        // user frames submitted / collected
 	long q_sub = 0, q_col = 0;        // lock-step steps submitted / collected
 	bool flushed = false;
@@ -829,6 +831,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "chroma_qp_index_offset %d outside -12..12", e->chroma_qp_offset);
 	if (ext.aud != 0 && ext.aud != 1)
 		return fail(e, -EINVAL, "aud must be 0 or 1");
+	if (ext.gop_low_latency != 0 && ext.gop_low_latency != 1)
+		return fail(e, -EINVAL, "gop_low_latency must be 0 or 1");
 	if (ext.subpel < 0 || ext.subpel > 2)
 		return fail(e, -EINVAL, "subpel %d outside 0..2", ext.subpel);
 	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
@@ -1274,7 +1278,13 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		m->G = G;
 		m->K = cfg->keyframe_interval;
 		m->S = S_user;
-		m->cap = G * m->K + e->depth + 1;
+		// frames the caller may have in flight: (G-1) K is the least (frame n needs frame n + (G-1) K in),
+		// + the session's ring; with `ahead` another (G-1) K + 8, so that the IDR step of the NEXT group of
+		// GOPs has its input while this group's last steps still run and hides beside them (the session's
+		// IDR look-ahead; measured below) -- at the price of twice the latency
+		m->ahead = !ext.gop_low_latency;
+		m->user_depth = (G - 1) * m->K + e->depth + (m->ahead ? (G - 1) * m->K + 8 : 0);
+		m->cap = m->user_depth + m->K + 1;
 		m->in_ring.assign((size_t)m->cap * 2 * S_user, nullptr);
 		m->out_ring.resize((size_t)m->cap * S_user);
 		m->out_rc.assign((size_t)m->cap, INT32_MIN);
@@ -1344,7 +1354,7 @@ extern "C" int cedar_enc_session_depth(const cedar_enc *e)
 	if (!e || !e->configured)
 		return -EINVAL;
 	// gop_parallel: frame n needs frame n + (G-1)*K submitted before it can be delivered
-	return e->mux ? (e->mux->G - 1) * e->mux->K + e->depth : e->depth;
+	return e->mux ? e->mux->user_depth : e->depth;
 }
 
 // Cohort c of a big batch: the same kernels on the streams [S*c/C, S*(c+1)/C) -- every per-stream and

@@ -60,6 +60,7 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.fps_num = env_int("H264ENC_FPS_NUM", 0);
 	ext.fps_den = env_int("H264ENC_FPS_DEN", ext.fps_num > 0 ? 1 : 0);
 	ext.gop_parallel = env_int("H264ENC_GOP_PARALLEL", 0);
+	ext.gop_low_latency = env_int("H264ENC_GOP_LOW_LATENCY", 0);
 	ext.first_frame_index = env_int("H264ENC_FIRST_FRAME", 0);
 	ext.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	ext.bitrate = env_int("H264ENC_BITRATE", 0);

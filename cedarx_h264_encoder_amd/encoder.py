@@ -42,7 +42,7 @@ class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-        "gop_parallel", "strict_mb_bits", "subpel", "bitrate")]
+        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate")]
 
 
 class _Stats(ctypes.Structure):
@@ -168,6 +168,7 @@ class EncoderConfig:
     gop_parallel: int = 0       # G > 1: G consecutive closed GOPs of every stream are encoded side by side
     strict_mb_bits: int = 0     # a picture with a macroblock above 3200 bits: 0 counted, 1 EOVERFLOW, 2 coded again at QP + 6
     subpel: int = 0             # motion vectors: 0 whole samples, 1 half, 2 quarter
+    gop_low_latency: int = 0    # gop_parallel: 1 = half the latency, every group's IDR step exposed
     bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
 
 
@@ -197,7 +198,7 @@ class CedarEncoder:
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-                  "gop_parallel", "strict_mb_bits", "subpel", "bitrate"):
+                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")

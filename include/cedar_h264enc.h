@@ -116,6 +116,12 @@ struct cedar_enc_config_ext {
 				neighbours of the best whole-sample vector, 6-tap interpolation of H.264
 				8.4.2.2.1 (the VE keeps "sub-pel" planes per reference frame, cedar.c:520,
 				cedar_regs.h:71-72; what the silicon does with them is not in the driver)  */
+	int gop_low_latency; /* gop_parallel sessions. 0 (default): the caller may run 2 (G-1) keyframe_interval
+				+ ring + 8 frames ahead, which puts the input of the NEXT group's IDR step in
+				the session's hands while this group's last steps run: the IDR pictures hide
+				beside them (8 lanes of 1080p: 84 -> 97 M macroblocks/s). 1: (G-1)
+				keyframe_interval + ring only -- half the latency and buffering, every group's
+				IDR step exposed. Same bytes either way                                    */
 	int bitrate;         /* > 0: frame-level rate control towards this many bits per second (at fps_num /
 				fps_den, 30 frames/s when unset). The VE has rate-control registers the
 				reference never programs (cedar_regs.h:43-53); here every

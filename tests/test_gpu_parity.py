@@ -878,11 +878,12 @@ def test_gop_parallel_session_equals_the_serial_stream(ce, w, h, K, G, n, device
     frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
     oe = ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=K))
     want = [oe.encode(y, uv) for y, uv in frames]
-    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=K, gop_parallel=G) as enc:
-        assert enc.pipeline_depth >= (G - 1) * K + 2
-        got = _encode_gop_parallel(enc, frames, device=device)
-    bad = [i for i in range(n) if got[i] != want[i]]
-    assert not bad, "first differing frames: %s" % bad[:8]
+    for low in (0, 1):   # with and without the second (G-1) K frames of look-ahead: the same bytes
+        with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=K, gop_parallel=G, gop_low_latency=low) as enc:
+            assert enc.pipeline_depth >= (2 - low) * (G - 1) * K + 2
+            got = _encode_gop_parallel(enc, frames, device=device)
+        bad = [i for i in range(n) if got[i] != want[i]]
+        assert not bad, "first differing frames: %s" % bad[:8]
 
 
 @pytest.mark.parametrize("at", [1, 3, 6])
