@@ -80,6 +80,9 @@ int main(int argc, char **argv)
 	cfg.aud = env_int("H264ENC_AUD", 0);
 	cfg.fps_num = env_int("H264ENC_FPS_NUM", 0);
 	cfg.fps_den = env_int("H264ENC_FPS_DEN", cfg.fps_num > 0 ? 1 : 0);
+	cfg.subpel = env_int("H264ENC_SUBPEL", 0);
+	cfg.bitrate = env_int("H264ENC_BITRATE", 0);
+	cfg.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	enc = h264o_open(&cfg, &err);
 	if (!enc) {
 		fprintf(stderr, "%s(): config failed: %s\n", __func__, strerror(-err));
