@@ -676,7 +676,8 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 			}
 			if (!__any(pending))
 				break;
-			if (wait_expired(++spins, t0) || __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // wall time, not iterations
+			// (the session's abort word is looked at every 64th spin: a second load per look would stretch the hand-off)
+			if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { // wall time, not iterations
 				if (lane == 0) {
 					__hip_atomic_store(p.wf_err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -549,7 +549,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					break;
 				}
 				// (a 3 us sleep per look: the clock is read every 256th, i.e. every ~0.8 ms)
-				if (wait_expired(++spins, t0) || __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+				if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
 					__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					inter_seen = 0x7fffffffu;
