@@ -83,6 +83,7 @@ int main(int argc, char **argv)
 	cfg.subpel = env_int("H264ENC_SUBPEL", 0);
 	cfg.bitrate = env_int("H264ENC_BITRATE", 0);
 	cfg.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
+	cfg.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
 	enc = h264o_open(&cfg, &err);
 	if (!enc) {
 		fprintf(stderr, "%s(): config failed: %s\n", __func__, strerror(-err));

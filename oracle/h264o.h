@@ -55,6 +55,10 @@ typedef struct h264o_config {
 	int strict_mb_bits;   /* a picture with a macroblock_layer() of more than 3200 bits (H.264 A.3.1): 0 emitted
 	                       * and counted; 1 refused with -EOVERFLOW; 2 coded again 6 QP steps coarser (slice_qp_delta)
 	                       * until every macroblock fits, -EOVERFLOW if QP 51 does not do it */
+	int intra_refresh;    /* N >= 3: cyclic intra refresh (the VE has a register for it, cedar_regs.h:43
+	                       * CYCLICINTRAREFRESH, that the driver never writes) -- in the t-th P picture after an IDR
+	                       * the macroblocks with (x + 2*y + t) % N == 0 are coded Intra16x16 (DC), and the PPS sets
+	                       * constrained_intra_pred_flag so that they do not lean on inter samples; 0: off */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */

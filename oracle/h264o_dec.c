@@ -40,7 +40,7 @@ struct h264o_dec {
 	uint32_t vui_ticks, vui_scale; /* 0: no timing in the SPS */
 	int vui_reorder, n_aud;
 	int log2_max_frame_num, poc_type;
-	int init_qp, chroma_qp_offset, deblock_ctrl;
+	int init_qp, chroma_qp_offset, deblock_ctrl, constrained_intra;
 	uint8_t *cur_y, *cur_uv, *ref_y, *ref_uv;
 	dmb *mbs;
 	int *slice_idc, *slice_a, *slice_b; /* per slice deblock params */
@@ -298,8 +298,7 @@ static int parse_pps(h264o_dec *d, br *b)
 	br_se(b);
 	d->chroma_qp_offset = br_se(b);
 	d->deblock_ctrl = (int)br_u(b, 1);
-	if (br_u(b, 1))
-		return fail(d, "constrained intra pred unsupported");
+	d->constrained_intra = (int)br_u(b, 1);
 	if (br_u(b, 1))
 		return fail(d, "redundant pictures unsupported");
 	if (b->err)
@@ -434,6 +433,19 @@ static const dmb *mb_at(const h264o_dec *d, int mx, int my, int cur_slice, int c
 	if (addr >= cur_addr || d->mbs[addr].slice != cur_slice)
 		return NULL;
 	return &d->mbs[addr];
+}
+
+/* the neighbour as INTRA PREDICTION sees it (8.3.1.2, 8.3.3, 8.3.4): with constrained_intra_pred_flag
+ * a macroblock coded in Inter prediction mode counts as not available; the same rule decides
+ * dcPredModePredictedFlag (8.3.1.1). CAVLC's nC keeps looking at the real neighbour (9.2.1: the
+ * exception there is for data partitioning only). */
+static const dmb *mb_at_intra(const h264o_dec *d, int mx, int my, int cur_slice, int cur_addr)
+{
+	const dmb *n = mb_at(d, mx, my, cur_slice, cur_addr);
+
+	if (n && d->constrained_intra && n->type >= H264O_MB_P16x16)
+		return NULL;
+	return n;
 }
 
 static int nc_of(const h264o_dec *d, const dmb *cur, const dmb *A, const dmb *B,
@@ -772,13 +784,17 @@ static int decode_residual_and_recon(h264o_dec *d, br *b, dmb *m, int mx, int my
 				scale4x4(lv, qp, 0, c4);
 			}
 			if (m->type == H264O_MB_I4x4) {
-				int top = by > 0 || B, left = bx > 0 || A, tr;
+				const dmb *Ai = mb_at_intra(d, mx - 1, my, m->slice, addr), *Bi = mb_at_intra(d, mx, my - 1, m->slice, addr);
+				int top = by > 0 || Bi, left = bx > 0 || Ai, tr;
 				static const uint8_t tri[16] = { 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 1, 0, 1, 0, 1, 0 };
 
 				if (by == 0)
-					tr = bx < 3 ? B != NULL : mb_at(d, mx + 1, my - 1, m->slice, addr) != NULL;
+					tr = bx < 3 ? Bi != NULL : mb_at_intra(d, mx + 1, my - 1, m->slice, addr) != NULL;
 				else
 					tr = tri[idx];
+				/* modes 4..6 read the corner sample: of macroblock D for block 0 */
+				if (idx == 0 && m->i4[0] >= 4 && m->i4[0] <= 6 && !mb_at_intra(d, mx - 1, my - 1, m->slice, addr))
+					return fail(d, "Intra4x4 mode needs an unavailable corner");
 				intra4x4(d->cur_y, d->cw, mx * 16 + 4 * bx, my * 16 + 4 * by, m->i4[bx + 4 * by],
 					 top, left, tr);
 			}
@@ -836,7 +852,8 @@ static int decode_residual_and_recon(h264o_dec *d, br *b, dmb *m, int mx, int my
 
 static int decode_intra_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr, int mbt)
 {
-	const dmb *A = mb_at(d, mx - 1, my, m->slice, addr), *B = mb_at(d, mx, my - 1, m->slice, addr);
+	/* everything in this function is intra prediction: the constrained view of the neighbours */
+	const dmb *A = mb_at_intra(d, mx - 1, my, m->slice, addr), *B = mb_at_intra(d, mx, my - 1, m->slice, addr);
 	int cbp, cmode, c;
 	int16_t dc16[16];
 
@@ -897,13 +914,15 @@ static int decode_intra_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr
 			m->qp = (int8_t)((m->qp + dq + 52) % 52);
 		}
 		/* luma prediction for the whole MB */
-		if (((t & 3) == 0 && !B) || ((t & 3) == 1 && !A) || ((t & 3) == 3 && !(A && B)))
+		if (((t & 3) == 0 && !B) || ((t & 3) == 1 && !A) ||
+		    ((t & 3) == 3 && !(A && B && mb_at_intra(d, mx - 1, my - 1, m->slice, addr))))
 			return fail(d, "Intra16x16 mode needs an unavailable neighbour");
 		intra_big(d->cur_y + my * 16 * d->cw + mx * 16, d->cw, 1, 16, t & 3, B != NULL, A != NULL);
 	} else {
 		return fail(d, "I_PCM unsupported");
 	}
-	if (cmode > 3 || (cmode == 1 && !A) || (cmode == 2 && !B) || (cmode == 3 && !(A && B)))
+	if (cmode > 3 || (cmode == 1 && !A) || (cmode == 2 && !B) ||
+	    (cmode == 3 && !(A && B && mb_at_intra(d, mx - 1, my - 1, m->slice, addr))))
 		return fail(d, "bad intra_chroma_pred_mode");
 	/* chroma prediction: syntax 0 DC 1 H 2 V 3 Plane -> intra_big 2,1,0,3 */
 	for (c = 0; c < 2; c++)

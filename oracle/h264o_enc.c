@@ -220,7 +220,7 @@ static void pps_rbsp(const h264o_config *c, bitw *b)
 	bw_se(b, c->qp - 26); /* pic_init_qs_minus26 */
 	bw_se(b, c->chroma_qp_offset);
 	bw_put(b, 1, 1); /* deblocking_filter_control_present_flag */
-	bw_put(b, 0, 1); /* constrained_intra_pred_flag */
+	bw_put(b, c->intra_refresh > 0, 1); /* constrained_intra_pred_flag: refresh macroblocks must not lean on inter samples */
 	bw_put(b, 0, 1); /* redundant_pic_cnt_present_flag */
 	bw_trailing(b);
 }
@@ -985,12 +985,14 @@ static void intra_decide_mb(h264o_enc *e, int mx, int my, int row0)
 	mb->mvx = mb->mvy = 0;
 }
 
-static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0)
+/* isolated: a refresh macroblock of a P picture -- under constrained_intra_pred its (inter) neighbours
+ * do not exist for intra prediction */
+static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0, int isolated)
 {
 	h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
 	uint8_t *ry = e->rec_y[e->cur], *ruv = e->rec_uv[e->cur];
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
-	int top_mb = my > row0, left_mb = mx > 0;
+	int top_mb = !isolated && my > row0, left_mb = !isolated && mx > 0;
 	int qp = e->qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
 	int idx, i, c;
 	uint8_t predc[2][64];
@@ -1353,10 +1355,27 @@ static int median3(int a, int b, int c)
 	return c < mn ? mn : c > mx ? mx : c;
 }
 
+static int mb_is_intra(const h264o_mb *m)
+{
+	return m->type == H264O_MB_I4x4 || m->type == H264O_MB_I16x16;
+}
+
+/* Cyclic intra refresh (cfg.intra_refresh = N): in the t-th P picture after an IDR the macroblocks with
+ * (x + 2*y + t) % N == 0 are coded intra, so N consecutive P pictures renew every macroblock. With
+ * N >= 3 neither the left nor the upper neighbour of a refresh macroblock is one itself: under
+ * constrained_intra_pred both are "not available" and the prediction is the constant 128. */
+static int refresh_mb(const h264o_enc *e, int mx, int my)
+{
+	return e->cfg.intra_refresh > 0 && e->frame_p_count > 0 &&
+	       (mx + 2 * my + e->frame_p_count) % e->cfg.intra_refresh == 0;
+}
+
+/* An intra neighbour (refresh macroblocks) is available with refIdx -1 and a zero vector. */
 static void mv_pred(const h264o_enc *e, int mx, int my, int row0, int *px, int *py, int *skx, int *sky)
 {
 	const h264o_mb *A = NULL, *B = NULL, *C = NULL;
 	int ax = 0, ay = 0, bx = 0, by = 0, cx = 0, cy = 0, n;
+	int ra, rb, rc;
 
 	if (mx > 0)
 		A = &e->mbs[my * e->mb_w + mx - 1];
@@ -1367,21 +1386,24 @@ static void mv_pred(const h264o_enc *e, int mx, int my, int row0, int *px, int *
 		else if (mx > 0)
 			C = &e->mbs[(my - 1) * e->mb_w + mx - 1]; /* D replaces C */
 	}
-	if (A) { ax = A->mvx; ay = A->mvy; }
-	if (B) { bx = B->mvx; by = B->mvy; }
-	if (C) { cx = C->mvx; cy = C->mvy; }
-	n = (A != NULL) + (B != NULL) + (C != NULL);
+	ra = A && !mb_is_intra(A);
+	rb = B && !mb_is_intra(B);
+	rc = C && !mb_is_intra(C);
+	if (ra) { ax = A->mvx; ay = A->mvy; }
+	if (rb) { bx = B->mvx; by = B->mvy; }
+	if (rc) { cx = C->mvx; cy = C->mvy; }
+	n = ra + rb + rc; /* neighbours with refIdx 0 */
 	if (!B && !C && A) {
 		*px = ax; *py = ay;
 	} else if (n == 1) {
-		*px = A ? ax : B ? bx : cx;
-		*py = A ? ay : B ? by : cy;
+		*px = ra ? ax : rb ? bx : cx;
+		*py = ra ? ay : rb ? by : cy;
 	} else {
 		*px = median3(ax, bx, cx);
 		*py = median3(ay, by, cy);
 	}
 	/* P_Skip inference (8.4.1.1) */
-	if (!A || !B || (ax == 0 && ay == 0) || (bx == 0 && by == 0)) {
+	if (!A || !B || (ra && ax == 0 && ay == 0) || (rb && bx == 0 && by == 0)) {
 		*skx = 0; *sky = 0;
 	} else {
 		*skx = *px; *sky = *py;
@@ -1390,11 +1412,6 @@ static void mv_pred(const h264o_enc *e, int mx, int my, int row0, int *px, int *
 
 /* ------------------------------------------------------------------ */
 /* deblocking filter (clause 8.7), macroblock raster order, in place   */
-
-static int mb_is_intra(const h264o_mb *m)
-{
-	return m->type == H264O_MB_I4x4 || m->type == H264O_MB_I16x16;
-}
 
 /* boundary strength between 4x4 luma blocks (pbx,pby) of MB p and (qbx,qby) of MB q */
 static int bs_of(const h264o_mb *p, int pbx, int pby, const h264o_mb *q, int qbx, int qby, int mb_edge)
@@ -1793,6 +1810,8 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		return NULL;
 	if (cfg->subpel < 0 || cfg->subpel > 2)
 		return NULL;
+	if (cfg->intra_refresh < 0 || (cfg->intra_refresh > 0 && cfg->intra_refresh < 3) || cfg->intra_refresh > 65535)
+		return NULL;
 	if (cfg->search_range < 0 || cfg->search_range > 16)
 		return NULL;
 	if (cfg->slice_count < 1 || cfg->slice_count > ALIGN16(cfg->height) / 16)
@@ -1982,7 +2001,7 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 						memcpy(e->rec_uv[e->cur] + (size_t)(my * 8 + y) * e->cw + mx * 16,
 						       e->src_uv + (size_t)(my * 8 + y) * e->cw + mx * 16, 16);
 					intra_decide_mb(e, mx, my, r0);
-					intra_recon_mb(e, mx, my, r0);
+					intra_recon_mb(e, mx, my, r0, 0);
 				}
 		} else if (idr) {
 			for (my = r0; my < r1; my++)
@@ -1990,17 +2009,31 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 					intra_decide_mb(e, mx, my, r0);
 			for (my = r0; my < r1; my++)
 				for (mx = 0; mx < e->mb_w; mx++)
-					intra_recon_mb(e, mx, my, r0);
+					intra_recon_mb(e, mx, my, r0, 0);
 		} else {
 			for (my = r0; my < r1; my++)
-				for (mx = 0; mx < e->mb_w; mx++)
-					inter_mb(e, mx, my, r0, r1);
+				for (mx = 0; mx < e->mb_w; mx++) {
+					h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
+
+					if (!refresh_mb(e, mx, my)) {
+						inter_mb(e, mx, my, r0, r1);
+						continue;
+					}
+					mb->type = H264O_MB_I16x16;
+					mb->i16_mode = 2;    /* DC: the one mode that needs no neighbour */
+					mb->chroma_mode = 0; /* DC */
+					mb->mvx = mb->mvy = 0;
+					memset(mb->i4_modes, 2, sizeof(mb->i4_modes));
+					intra_recon_mb(e, mx, my, r0, 1);
+				}
 			/* skip decision needs the whole vector field */
 			for (my = r0; my < r1; my++)
 				for (mx = 0; mx < e->mb_w; mx++) {
 					h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
 					int px, py, skx, sky;
 
+					if (mb_is_intra(mb))
+						continue;
 					mv_pred(e, mx, my, r0, &px, &py, &skx, &sky);
 					if (mb->cbp == 0 && mb->mvx == skx && mb->mvy == sky)
 						mb->type = H264O_MB_PSKIP;
@@ -2043,7 +2076,9 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 				bw_ue(&b, (uint32_t)skip_run);
 				ue_bits_of_run = (int)(b.pos - mb_start);
 				skip_run = 0;
-				{
+				if (mb_is_intra(mb)) {
+					write_intra_mb(e, &b, mb, mx, my, r0, 1); /* mb_type 5 + the I slice's */
+				} else {
 					int px, py, skx, sky;
 
 					mv_pred(e, mx, my, r0, &px, &py, &skx, &sky);

@@ -522,6 +522,16 @@ class Decoder:
         m = self.mbs[my * s["mb_w"] + mx]
         return m if m.avail and m.slice == self.slice_no else None
 
+    def _mb_at_intra(self, mx, my):
+        """the neighbour as intra prediction sees it: with constrained_intra_pred_flag a macroblock coded
+        in Inter prediction mode is "not available for Intra prediction" (8.3.1.2, 8.3.3, 8.3.4) and sets
+        dcPredModePredictedFlag (8.3.1.1)"""
+        m = self._mb_at(mx, my)
+        if m is not None and self.pps["constrained_intra"] and not m.intra:
+            self.cover["constrained_intra_neighbour_hidden"] += 1
+            return None
+        return m
+
     # ---------------- macroblock layer (7.3.5) ----------------
     def _macroblock(self, b, addr, is_p):
         sps, pps = self.sps, self.pps
@@ -555,7 +565,7 @@ class Decoder:
             # mb_pred: Intra4x4 prediction modes (8.3.1.1)
             for blk in range(16):
                 bx, by = BLK_XY[blk]
-                pred = self._pred_i4_mode(m, A, B, bx, by)
+                pred = self._pred_i4_mode(m, self._mb_at_intra(mx - 1, my), self._mb_at_intra(mx, my - 1), bx, by)
                 if b.u(1):
                     mode = pred
                     self.cover["i4_mode_predicted"] += 1
@@ -866,14 +876,14 @@ class Decoder:
     def _pred_i4(self, mx, my, bx, by, mode):
         pic = self.cur.y
         x0, y0 = mx * 16 + 4 * bx, my * 16 + 4 * by
-        has_l = bx > 0 or self._mb_at(mx - 1, my) is not None
-        has_t = by > 0 or self._mb_at(mx, my - 1) is not None
+        has_l = bx > 0 or self._mb_at_intra(mx - 1, my) is not None
+        has_t = by > 0 or self._mb_at_intra(mx, my - 1) is not None
         if by > 0:
             has_tr = bx < 3 and blk_index(bx + 1, by - 1) < blk_index(bx, by)
         elif bx < 3:
             has_tr = has_t
         else:
-            has_tr = self._mb_at(mx + 1, my - 1) is not None
+            has_tr = self._mb_at_intra(mx + 1, my - 1) is not None
         if by > 0 and bx > 0:
             has_tl = True
         elif by > 0:
@@ -881,7 +891,7 @@ class Decoder:
         elif bx > 0:
             has_tl = has_t
         else:
-            has_tl = self._mb_at(mx - 1, my - 1) is not None
+            has_tl = self._mb_at_intra(mx - 1, my - 1) is not None
         T = [pic[y0 - 1][x0 + i] for i in range(4)] if has_t else None
         if has_t:
             T += [pic[y0 - 1][x0 + 4 + i] for i in range(4)] if has_tr else [T[3]] * 4
@@ -964,11 +974,11 @@ class Decoder:
     def _pred_i16(self, mx, my, mode):
         pic = self.cur.y
         x0, y0 = mx * 16, my * 16
-        has_l = self._mb_at(mx - 1, my) is not None
-        has_t = self._mb_at(mx, my - 1) is not None
+        has_l = self._mb_at_intra(mx - 1, my) is not None
+        has_t = self._mb_at_intra(mx, my - 1) is not None
         T = [pic[y0 - 1][x0 + i] for i in range(16)] if has_t else None
         L = [pic[y0 + i][x0 - 1] for i in range(16)] if has_l else None
-        if (mode == 0 and not has_t) or (mode == 1 and not has_l) or (mode == 3 and not (has_t and has_l and self._mb_at(mx - 1, my - 1) is not None)):
+        if (mode == 0 and not has_t) or (mode == 1 and not has_l) or (mode == 3 and not (has_t and has_l and self._mb_at_intra(mx - 1, my - 1) is not None)):
             raise SyntaxError264("Intra16x16 mode %d needs neighbours that are not available" % mode)
         if mode == 2:
             if has_t and has_l:
@@ -1001,9 +1011,9 @@ class Decoder:
                 row[x0 + x] = v
 
     def _pred_chroma(self, mx, my, mode):
-        has_l = self._mb_at(mx - 1, my) is not None
-        has_t = self._mb_at(mx, my - 1) is not None
-        if (mode == 1 and not has_l) or (mode == 2 and not has_t) or (mode == 3 and not (has_l and has_t and self._mb_at(mx - 1, my - 1) is not None)):
+        has_l = self._mb_at_intra(mx - 1, my) is not None
+        has_t = self._mb_at_intra(mx, my - 1) is not None
+        if (mode == 1 and not has_l) or (mode == 2 and not has_t) or (mode == 3 and not (has_l and has_t and self._mb_at_intra(mx - 1, my - 1) is not None)):
             raise SyntaxError264("chroma prediction mode %d needs neighbours that are not available" % mode)
         x0, y0 = mx * 8, my * 8
         for plane in (self.cur.cb, self.cur.cr):

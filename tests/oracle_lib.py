@@ -19,7 +19,7 @@ class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
         "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
-        "subpel", "bitrate", "strict_mb_bits")]
+        "subpel", "bitrate", "strict_mb_bits", "intra_refresh")]
 
 
 class MB(ctypes.Structure):

@@ -599,7 +599,7 @@ def test_lost_handoff_drains_and_reports_eio(ce, monkeypatch, which, keyint):
 
 def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
     """tests/golden/indep_decode.json (tools/gen_indep_golden.py): the bytes the HIP path emits for
-    the fifteen cases must hash to the committed stream vectors, and the independent Python decoder
+    the committed cases must hash to the committed stream vectors, and the independent Python decoder
     (tests/indep/h264_refdec.py: own code and tables, nothing shared with oracle/ or csrc/) must turn
     them into the session's own deblocked reconstruction."""
     import hashlib
@@ -608,9 +608,10 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cases = json.load(open(os.path.join(root, "tests", "golden", "indep_decode.json")))["cases"]
     for c in cases:
-        w, h, qp, keyint, frames, pattern, slices = c["case"]
+        w, h, qp, keyint, frames, pattern, slices = c["case"][:7]
+        opts = {k: int(v) for k, v in (kv.split("=") for kv in c["case"][7].split(","))} if len(c["case"]) > 7 else {}
         sh, dec = hashlib.sha1(), rd.Decoder()
-        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices) as ge:
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, **opts) as ge:
             for f in range(frames):
                 au = ge.encode_frame(*ol.gen_frame(pattern, w, h, f))
                 sh.update(au)

@@ -83,7 +83,8 @@ def test_the_streams_reach_every_part_of_the_standard_the_encoders_use(decoded):
             ["level_prefix_14", "level_prefix_15", "mvp_median", "mvp_only_A", "mvp_single_match", "mvp_D_for_C",
              "skip_mv_zero_rule", "skip_mv_predicted", "mb_P_Skip", "mb_I4x4", "mb_I16x16", "mb_P_L0_16x16",
              "mb_skip_run_0", "mb_skip_run_1", "mb_skip_run_n", "i4_top_right_substituted", "i4_mode_predicted", "i4_mode_rem",
-             "mvd_zero", "mvd_nonzero", "mc_chroma_frac_0_0", "mc_chroma_frac_4_0", "mc_chroma_frac_0_4", "mc_chroma_frac_4_4"] +
+             "mvd_zero", "mvd_nonzero", "mc_chroma_frac_0_0", "mc_chroma_frac_4_0", "mc_chroma_frac_0_4", "mc_chroma_frac_4_4",
+             "constrained_intra_neighbour_hidden"] +
             ["coeff_token/" + n for n in rd.vlc_tables() if n.startswith("coeff_token")])
     missing = [k for k in want if not cover[k]]
     assert not missing, missing

@@ -145,3 +145,46 @@ def test_rate_control_reaches_the_target_and_stays_decodable():
         assert qps[:17] == [30] * 17 and len(set(qps)) > 1       # nothing is known before frame 17
         rate = sum(sizes[60:110]) * 8 * 30 / 50.0               # two whole GOPs
         assert 0.80 * target <= rate <= 1.02 * target, (target, rate, qps[::10])
+
+
+@pytest.mark.parametrize("w,h,n,slices,subpel,pattern,keyint", [
+    (96, 64, 3, 1, 0, "B", 12), (112, 80, 5, 2, 2, "B", 25), (64, 48, 4, 1, 0, "A", 8),
+    (48, 48, 7, 1, 1, "C", 30), (16, 16, 3, 1, 0, "C", 6), (160, 32, 3, 2, 2, "B", 9)])
+def test_cyclic_intra_refresh(w, h, n, slices, subpel, pattern, keyint):
+    """h264o_config.intra_refresh = N: in the t-th P picture the macroblocks with (x + 2*y + t) % N == 0 are
+    Intra16x16 (the PPS says constrained_intra_pred), N pictures in a row renew every macroblock, and
+    both decoders -- the C one and the independent Python one -- rebuild the encoder's pictures."""
+    from tests.indep import h264_refdec as rd
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=28, keyint=keyint, slice_count=slices, subpel=subpel, intra_refresh=n))
+    dec, pdec = ol.OracleDecoder(), rd.Decoder()
+    mb_w, mb_h = (w + 15) // 16, (h + 15) // 16
+    my, mx = np.mgrid[0:mb_h, 0:mb_w]
+    seen = np.zeros((mb_h, mb_w), int)
+    for f in range(2 + n):
+        au = oe.encode(*ol.gen_frame(pattern, w, h, f))
+        assert dec.decode(au) == 1, dec.error()
+        ry, ruv = oe.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(ry, dy) and np.array_equal(ruv, duv), f
+        pic, = pdec.decode(au)
+        assert pic.luma_bytes() == ry.tobytes() and pic.nv12_chroma_bytes() == ruv.tobytes(), f
+        intra = (oe.mb_array()["type"] <= ol.MB_I16x16).reshape(mb_h, mb_w)
+        t = f % keyint
+        if t:
+            assert np.array_equal(intra, (mx + 2 * my + t) % n == 0), f
+            seen += intra
+    assert seen.min() >= 1
+    for bad in (1, 2, -1, 70000):
+        with pytest.raises(Exception):
+            ol.OracleEncoder(ol.default_config(w, h, intra_refresh=bad))
+
+
+def test_fuzzed_round_trips_with_round_2_options():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle_roundtrip.py"), "20261004", "80"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, FUZZ_R2="1"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    assert "80 cases, decode == recon" in r.stdout

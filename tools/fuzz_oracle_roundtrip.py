@@ -18,6 +18,8 @@ for case in range(n_cases):
               repeat_headers=int(rng.randint(0, 2)))
     if rng.randint(0, 2):
         kw.update(fps_num=int(rng.choice([24, 30000])), fps_den=int(rng.choice([1, 1001])))
+    if os.environ.get("FUZZ_R2"):   # round 2's options (their own draws: the default sweep keeps its cases)
+        kw.update(subpel=int(rng.choice([0, 1, 2])), intra_refresh=int(rng.choice([0, 3, 4, 11])))
     pat = str(rng.choice(["A", "B", "C"]))
     enc, dec = ol.OracleEncoder(ol.default_config(w, h, **kw)), ol.OracleDecoder()
     for f in range(int(rng.randint(2, 9))):

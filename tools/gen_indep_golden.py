@@ -15,18 +15,25 @@ sys.path.insert(0, ROOT)
 from tests import oracle_lib as ol                      # noqa: E402
 from tests.indep import h264_refdec as rd               # noqa: E402
 
-# w, h, qp, keyint, frames, pattern, slices
+# w, h, qp, keyint, frames, pattern, slices [, "option=value,..." of the oracle's configuration]
 CASES = [
     (64, 48, 30, 25, 4, "B", 1), (64, 48, 24, 25, 3, "C", 1), (64, 48, 30, 25, 3, "A", 1), (70, 50, 24, 25, 3, "B", 1),
     (64, 48, 5, 3, 4, "C", 1), (64, 48, 47, 3, 4, "B", 1), (16, 16, 24, 2, 3, "C", 1), (48, 80, 24, 4, 5, "B", 5),
     (96, 64, 36, 4, 5, "B", 2), (64, 48, 1, 2, 2, "C", 1), (128, 96, 40, 25, 3, "B", 1), (96, 112, 18, 25, 3, "C", 1),
     (16, 96, 24, 3, 6, "B", 1), (320, 240, 30, 25, 3, "B", 1), (320, 240, 24, 1, 2, "B", 4),
+    (96, 64, 28, 25, 4, "B", 1, "subpel=2"), (96, 64, 28, 12, 6, "B", 1, "intra_refresh=3"),
+    (112, 80, 30, 25, 5, "B", 2, "subpel=2,intra_refresh=5"), (48, 48, 20, 30, 9, "C", 1, "intra_refresh=7"),
 ]
 
 
+def case_options(case):
+    """the optional 8th element as keyword arguments (the names are h264o_config's and CedarEncoder's)"""
+    return {k: int(v) for k, v in (kv.split("=") for kv in case[7].split(","))} if len(case) > 7 else {}
+
+
 def encode_and_decode(case):
-    w, h, qp, keyint, frames, pattern, slices = case
-    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices))
+    w, h, qp, keyint, frames, pattern, slices = case[:7]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **case_options(case)))
     dec = rd.Decoder()
     stream, pics, same = hashlib.sha1(), hashlib.sha1(), True
     for f in range(frames):
