@@ -68,6 +68,8 @@ struct Params {
 	int32_t qp, qpc, search_range, lambda;
 	int32_t subpel;             // motion vector precision: 0 whole samples, 1 half, 2 quarter
 	int32_t is_idr;
+	int32_t intra_refresh;      // N >= 3: macroblocks with (x + 2*y + refresh_t) % N == 0 of a P picture are coded intra; 0 off
+	int32_t refresh_t;          // P pictures since the IDR (1 for the first)
 	// quantiser, luma (index = position class 0 even/even, 1 odd/odd, 2 mixed)
 	int32_t mf[3], dv[3], qbits, qshift;
 	int32_t mfc[3], dvc[3], qbits_c, qshift_c;

@@ -308,38 +308,51 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 			bw_se(b, 0);
 		}
 		write_residual(b, mi, cf, nb);
+	} else if (mi.type == MB_I16x16) {
+		// a refresh macroblock (Params::intra_refresh): intra in a P slice, mb_type 5 + the I slice's
+		const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
+		bw_ue(b, (uint32_t)(5 + t));
+		bw_ue(b, (uint32_t)mi.chroma_mode);
+		bw_se(b, 0);
+		write_residual(b, mi, cf, nb);
 	} else {
-		// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1)
+		// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1). An intra neighbour (a
+		// refresh macroblock) is available with refIdx -1 and a zero vector; ra/rb/rc = "has refIdx 0".
 		int ax = 0, ay = 0, bx_ = 0, by_ = 0, cx = 0, cy = 0;
 		bool hasA = has_left, hasB = has_top, hasC = false;
+		bool ra = false, rb = false, rc = false;
 		if (hasA) {
 			const MbInfo m = p.mbi[mbaddr - 1];
-			ax = m.mvx; ay = m.mvy;
+			ra = m.type >= MB_P16x16;
+			ax = m.mvx; ay = m.mvy; // (zero in an intra record)
 		}
 		if (hasB) {
 			const MbInfo m = p.mbi[mbaddr - p.mb_w];
+			rb = m.type >= MB_P16x16;
 			bx_ = m.mvx; by_ = m.mvy;
 			if (mx < p.mb_w - 1) {
 				const MbInfo c = p.mbi[mbaddr - p.mb_w + 1];
+				rc = c.type >= MB_P16x16;
 				cx = c.mvx; cy = c.mvy; hasC = true;
 			} else if (mx > 0) {
 				const MbInfo c = p.mbi[mbaddr - p.mb_w - 1];
+				rc = c.type >= MB_P16x16;
 				cx = c.mvx; cy = c.mvy; hasC = true;
 			}
 		}
 		int px, py;
-		const int n = (int)hasA + (int)hasB + (int)hasC;
+		const int n = (int)ra + (int)rb + (int)rc;
 		if (!hasB && !hasC && hasA) {
 			px = ax; py = ay;
 		} else if (n == 1) {
-			px = hasA ? ax : hasB ? bx_ : cx;
-			py = hasA ? ay : hasB ? by_ : cy;
+			px = ra ? ax : rb ? bx_ : cx;
+			py = ra ? ay : rb ? by_ : cy;
 		} else {
 			px = median3(ax, bx_, cx);
 			py = median3(ay, by_, cy);
 		}
 		int skx = px, sky = py;
-		if (!hasA || !hasB || (ax == 0 && ay == 0) || (bx_ == 0 && by_ == 0)) {
+		if (!hasA || !hasB || (ra && ax == 0 && ay == 0) || (rb && bx_ == 0 && by_ == 0)) {
 			skx = 0; sky = 0;
 		}
 		if (mi.cbp == 0 && mi.mvx == skx && mi.mvy == sky) {
@@ -600,26 +613,34 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 				lw_ue(b, (uint32_t)mi.chroma_mode);
 				lw_se(b, 0);
 			}
+		} else if (mi.type == MB_I16x16) {
+			// a refresh macroblock (Params::intra_refresh): intra in a P slice, mb_type 5 + the I slice's
+			const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
+			lw_ue(b, (uint32_t)(5 + t));
+			lw_ue(b, (uint32_t)mi.chroma_mode);
+			lw_se(b, 0);
 		} else {
-			// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1)
+			// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1). An intra neighbour (a
+			// refresh macroblock) is available with refIdx -1 and a zero vector; ra/rb/rc = "has refIdx 0".
 			const bool hasA = has_left, hasB = has_top, hasC = has_c;
 			const MbInfo mA = s_mi[half][1], mB = s_mi[half][2], mC = s_mi[half][3];
-			const int ax = hasA ? mA.mvx : 0, ay = hasA ? mA.mvy : 0;
-			const int bx_ = hasB ? mB.mvx : 0, by_ = hasB ? mB.mvy : 0;
-			const int cx = hasC ? mC.mvx : 0, cy = hasC ? mC.mvy : 0;
+			const bool ra = hasA && mA.type >= MB_P16x16, rb = hasB && mB.type >= MB_P16x16, rc = hasC && mC.type >= MB_P16x16;
+			const int ax = ra ? mA.mvx : 0, ay = ra ? mA.mvy : 0;
+			const int bx_ = rb ? mB.mvx : 0, by_ = rb ? mB.mvy : 0;
+			const int cx = rc ? mC.mvx : 0, cy = rc ? mC.mvy : 0;
 			int px, py;
-			const int n = (int)hasA + (int)hasB + (int)hasC;
+			const int n = (int)ra + (int)rb + (int)rc;
 			if (!hasB && !hasC && hasA) {
 				px = ax; py = ay;
 			} else if (n == 1) {
-				px = hasA ? ax : hasB ? bx_ : cx;
-				py = hasA ? ay : hasB ? by_ : cy;
+				px = ra ? ax : rb ? bx_ : cx;
+				py = ra ? ay : rb ? by_ : cy;
 			} else {
 				px = median3(ax, bx_, cx);
 				py = median3(ay, by_, cy);
 			}
 			int skx = px, sky = py;
-			if (!hasA || !hasB || (ax == 0 && ay == 0) || (bx_ == 0 && by_ == 0)) {
+			if (!hasA || !hasB || (ra && ax == 0 && ay == 0) || (rb && bx_ == 0 && by_ == 0)) {
 				skx = 0; sky = 0;
 			}
 			if (mi.cbp == 0 && mi.mvx == skx && mi.mvy == sky) {

@@ -224,7 +224,7 @@ DEVI uint32_t lds_bytes4(const uint8_t *base, int off)
 // rounded mean of four byte pairs: (a + b + 1) >> 1 per byte
 DEVI uint32_t avg_bytes4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
 
-template <int SUBPEL>
+template <int SUBPEL, bool REFRESH>
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
 	// one wave per macroblock, INTER_WAVES macroblocks per workgroup; each wave has its own
@@ -262,6 +262,10 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
 	const int band_y0 = r0 * 16, band_y1 = r1 * 16;
+	// Cyclic intra refresh (Params::intra_refresh = N, refresh_t = P pictures since the IDR): this
+	// macroblock is coded Intra16x16 (DC) when (x + 2*y + t) % N == 0. Its neighbours are inter, hence
+	// "not available" under constrained_intra_pred: the prediction is 128 everywhere, luma and chroma.
+	const bool refresh = REFRESH && (mx + 2 * my + p.refresh_t) % p.intra_refresh == 0; // wave-uniform
 
 	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
 	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
@@ -394,9 +398,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	best = wave_min_u32(best);
 	const int bidx = (int)(best & 2047u);
 	const int bdy = bidx / 33 - 16, bdx = bidx - (bidx / 33) * 33 - 16;
-	int qx = 4 * bdx, qy = 4 * bdy; // the vector in quarter samples
+	int qx = (REFRESH && refresh) ? 0 : 4 * bdx, qy = (REFRESH && refresh) ? 0 : 4 * bdy; // the vector in quarter samples
 	uint8_t *const s_sub = sa_sub[SUBPEL ? wave : 0];
-	if (SUBPEL && p.subpel > 0) {
+	if (SUBPEL && p.subpel > 0 && !(REFRESH && refresh)) {
 		// window coordinates of the best whole-sample block; plane sample (u, v) = window (wx0 + u, wy0 + v)
 		const int wx0 = 16 + bdx, wy0 = 16 + bdy;
 		int16_t *const s_b1 = (int16_t *)s_coef; // 22 rows x 18: the levels' place is free until the transform
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		((u32x4 *)s_coef)[i] = u32x4{ 0, 0, 0, 0 };
 	WAVE_LDS_SYNC();
 
-	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / 6;
+	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / ((REFRESH && refresh) ? 3 : 6);
 	const int gq = lane >> 4, l = lane & 15;
 	const int pi = l >> 2, pj = l & 3;
 	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
@@ -524,6 +528,60 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		pa_stride = k.pa ? SP_STRIDE : REF_STRIDE;
 		pb_stride = k.pb ? SP_STRIDE : REF_STRIDE;
 	}
+	if (REFRESH && refresh) {
+		// Intra16x16, prediction 128 (8.3.3 with no neighbour): the 16 DC coefficients go through the
+		// 4x4 Hadamard (8.5.10), the other 15 of a block are quantised with the intra dead zone
+		const int f_intra = (1 << p.qbits) / 3;
+		int wl[4], dcm[16];
+#pragma unroll
+		for (int pass = 0; pass < 4; pass++) {
+			const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
+			wl[pass] = fdct_lanes24((int)s_cur[(4 * by + pi) * 16 + 4 * bx + pj] - 128, ci, cj);
+#pragma unroll
+			for (int k = 0; k < 4; k++) // lane (0,0) of a group holds its DC: raster position of block 4*pass+k
+				dcm[blk_x(4 * pass + k) + 4 * blk_y(4 * pass + k)] = __builtin_amdgcn_readlane(wl[pass], 16 * k);
+		}
+		// Hadamard rows (1,1,1,1) (1,1,-1,-1) (1,-1,-1,1) (1,-1,1,-1): sign bit of row k at element r is
+		// bit 4k+r of 0xA6C0. Lane l < 16 makes output (k2 = l / 4, k1 = l % 4).
+		const uint32_t SB = 0xA6C0u;
+		const int k2 = (lane >> 2) & 3, k1 = lane & 3;
+		int hsum = 0;
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+				hsum += (((SB >> (4 * k2 + r)) ^ (SB >> (4 * k1 + c))) & 1u) ? -dcm[4 * r + c] : dcm[4 * r + c];
+		const int dlev = quant1((hsum + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
+		if (lane < 16)
+			s_coef[COEF_DC16 + zigzag_of(lane)] = (int16_t)dlev;
+		int cm[16];
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			cm[r] = __builtin_amdgcn_readlane(dlev, r);
+		int isum = 0; // lane l < 16: the scaled DC of the block at (bx = l % 4, by = l / 4)
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+				isum += (((SB >> (4 * k2 + r)) ^ (SB >> (4 * k1 + c))) & 1u) ? -cm[4 * r + c] : cm[4 * r + c];
+		const int ls = 16 * p.dv[0];
+		const int dcr = p.qshift >= 6 ? (isum * ls) << (p.qshift - 6) : (isum * ls + (1 << (5 - p.qshift))) >> (6 - p.qshift);
+		bool any_ac = false;
+#pragma unroll
+		for (int pass = 0; pass < 4; pass++) {
+			const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
+			const int x = 4 * bx + pj, y = 4 * by + pi;
+			const int level = l == 0 ? 0 : quant24(wl[pass], mf_y, f_intra, p.qbits);
+			s_coef[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
+			const int mydc = __shfl(dcr, bx + 4 * by);
+			const int rr = idct_lanes24(l == 0 ? mydc : __mul24(level, dv_y) << p.qshift, ci, cj);
+			s_recy[y * 16 + x] = (uint8_t)clip255(128 + rr);
+			const uint64_t bal = __ballot(level != 0);
+			s_nnz[bx + 4 * by] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
+			any_ac = any_ac || bal != 0;
+		}
+		nz_luma = any_ac ? 0xffffu : 0u; // Intra16x16: the luma part of the coded block pattern is 0 or 15
+	} else {
 #pragma unroll
 	for (int pass = 0; pass < 4; pass++) {
 		const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
@@ -542,6 +600,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		for (int k = 0; k < 4; k++)
 			nz_luma |= ((uint32_t)(bal >> (16 * k)) & 0xffffu) ? (1u << (4 * pass + k)) : 0u;
 	}
+	}
 	// chroma: pass = plane, group = block (raster 2x2)
 	// vector in 1/8 chroma samples = the luma vector in quarter samples (8.4.1.4)
 	const int ix = qx >> 3, iy = qy >> 3, fx = qx & 7, fy = qy & 7;
@@ -556,6 +615,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		const int A = s_refc[wr * REFC_STRIDE + 2 * wc + c], B = s_refc[wr * REFC_STRIDE + 2 * wc1 + c];
 		const int C = s_refc[wr1 * REFC_STRIDE + 2 * wc + c], D = s_refc[wr1 * REFC_STRIDE + 2 * wc1 + c];
 		cpv[c] = ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
+		if (REFRESH && refresh)
+			cpv[c] = 128;
 		const int res = (int)s_curc[y * 16 + 2 * x + c] - cpv[c];
 		const int w = fdct_lanes24(res, ci, cj);
 		// lane (0,0) of a group holds its DC coefficient: the four of a plane become wave-uniform
@@ -618,9 +679,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		*(u32x4 *)(p.i4modes + mbaddr * 16) = u32x4{ 0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u };
 	if (lane == 0) {
 		MbInfo m;
-		m.type = MB_P16x16;
-		m.i16_mode = 0;
-		m.chroma_mode = 0;
+		m.type = (REFRESH && refresh) ? MB_I16x16 : MB_P16x16;
+		m.i16_mode = (REFRESH && refresh) ? 2 : 0; // DC
+		m.chroma_mode = 0;                         // DC
 		m.cbp = (int8_t)cbp;
 		m.mvx = (int16_t)qx; // quarter samples
 		m.mvy = (int16_t)qy;
@@ -631,10 +692,16 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 int Launch::inter(const Params &p, void *stream, int n_mbs)
 {
 	const dim3 grid((n_mbs + INTER_WAVES - 1) / INTER_WAVES), block(64 * INTER_WAVES);
-	if (p.subpel > 0) // the refinement's planes take LDS: a kernel of its own, so the whole-sample one keeps its occupancy
-		hipLaunchKernelGGL(k_inter<1>, grid, block, 0, (hipStream_t)stream, p);
+	// the refinement's planes take LDS, the refresh branch registers: kernels of their own, so the
+	// whole-sample, all-inter one keeps its occupancy
+	if (p.intra_refresh > 0 && p.subpel > 0)
+		hipLaunchKernelGGL((k_inter<1, true>), grid, block, 0, (hipStream_t)stream, p);
+	else if (p.intra_refresh > 0)
+		hipLaunchKernelGGL((k_inter<0, true>), grid, block, 0, (hipStream_t)stream, p);
+	else if (p.subpel > 0)
+		hipLaunchKernelGGL((k_inter<1, false>), grid, block, 0, (hipStream_t)stream, p);
 	else
-		hipLaunchKernelGGL(k_inter<0>, grid, block, 0, (hipStream_t)stream, p);
+		hipLaunchKernelGGL((k_inter<0, false>), grid, block, 0, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 

@@ -175,6 +175,12 @@ DEVI void filt_chroma_s2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &
 	q0 = sel(m, nq0, q0);
 }
 
+// byte e of an edge-code word if it carries the bS 4 mark (0x40 on top of 0x80), else 0
+DEVI uint32_t strong_part(uint32_t w, int e)
+{
+	return ((w >> (8 * e)) & 0x40u) ? w & (0xffu << (8 * e)) : 0u;
+}
+
 // packed { int16 mvx, mvy } words: 1 if a component differs by 4 quarter samples or more
 DEVI int mv_far(int a, int b)
 {
@@ -252,9 +258,12 @@ struct Db2Shared {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 
-template <bool IDR, int PL>
+// MODE 0: a P picture of inter macroblocks; 1: an IDR picture (all intra: bS 4 on macroblock edges, 3 inside);
+// 2: a P picture with intra macroblocks in it (cyclic intra refresh): the strengths of both, per edge
+template <int MODE, int PL>
 DEVI void deblock2_body(const Params &p, const int wg)
 {
+	constexpr bool IDR = MODE == 1, MIXED = MODE == 2;
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
 	Db2Shared<PL> &S = *reinterpret_cast<Db2Shared<PL> *>(dyn_lds);
 	Db2GroupLds *s_g = S.g;
@@ -377,12 +386,21 @@ DEVI void deblock2_body(const Params &p, const int wg)
 							const int q = 4 + 4 * e;
 							if (!IDR && !__any((wv >> (8 * e)) & 0x80u))
 								continue;
-							if (IDR && e == 0)
+							if (IDR && e == 0) {
 								filt_luma_s2(wv, e, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
 									     px[q], px[q + 1], px[q + 2], px[q + 3]);
-							else
+							} else if (MIXED && e == 0) { // code 0xC0 = bS 4: one of the two filters per lane
+								const uint32_t ws = strong_part(wv, 0), wn = wv ^ ws;
+								if (__any(ws))
+									filt_luma_s2(ws, e, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+										     px[q], px[q + 1], px[q + 2], px[q + 3]);
+								if (__any(wn & 0x80u))
+									filt_luma_n2(wn, e, -p.alpha_y, -p.beta_y,
+										     px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
+							} else {
 								filt_luma_n2(wv, e, -p.alpha_y, -p.beta_y,
 									     px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
+							}
 						}
 						uint32_t *roww = (uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
 #pragma unroll
@@ -394,10 +412,15 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						uint8_t *cp = L.c[slot] + (2 + r) * DC_STRIDE + 16 + c;
 						int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
 						int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
-						if (IDR)
+						if (IDR) {
 							filt_chroma_s2(wc, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
-						else
+						} else if (MIXED) {
+							const uint32_t ws = strong_part(wc, 0);
+							filt_chroma_s2(ws, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_n2(wc ^ ws, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+						} else {
 							filt_chroma_n2(wc, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+						}
 						filt_chroma_n2(wc, 1, -p.alpha_c, -p.beta_c, c1, c0, d0, d1);
 						cp[-2] = (uint8_t)a0;
 						cp[0] = (uint8_t)b0;
@@ -460,12 +483,21 @@ DEVI void deblock2_body(const Params &p, const int wg)
 							const int q = 4 + 4 * e;
 							if (!IDR && !__any((wh >> (8 * e)) & 0x80u))
 								continue;
-							if (IDR && e == 0)
+							if (IDR && e == 0) {
 								filt_luma_s2(wh, e, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
 									     py[q], py[q + 1], py[q + 2], py[q + 3]);
-							else
+							} else if (MIXED && e == 0) {
+								const uint32_t ws = strong_part(wh, 0), wn = wh ^ ws;
+								if (__any(ws))
+									filt_luma_s2(ws, e, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+										     py[q], py[q + 1], py[q + 2], py[q + 3]);
+								if (__any(wn & 0x80u))
+									filt_luma_n2(wn, e, -p.alpha_y, -p.beta_y,
+										     py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
+							} else {
 								filt_luma_n2(wh, e, -p.alpha_y, -p.beta_y,
 									     py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
+							}
 						}
 #pragma unroll
 						for (int r = 1; r < 19; r++)
@@ -475,10 +507,15 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						uint8_t *cp = L.c[slot] + 16 + l;
 						int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
 						int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
-						if (IDR)
+						if (IDR) {
 							filt_chroma_s2(wc, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
-						else
+						} else if (MIXED) {
+							const uint32_t ws = strong_part(wc, 2);
+							filt_chroma_s2(ws, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_n2(wc ^ ws, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+						} else {
 							filt_chroma_n2(wc, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+						}
 						filt_chroma_n2(wc, 3, -p.alpha_c, -p.beta_c, c1, c0, d0, d1);
 						cp[DC_STRIDE] = (uint8_t)a0;
 						cp[2 * DC_STRIDE] = (uint8_t)b0;
@@ -582,12 +619,14 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			u32x4 in, c;
 			uint64_t topx;
 			uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
+			uint32_t ty, tyt; // MIXED: its first dword (type in the low byte)
 			uint8_t nz, nzt;
 			bool top_ok;
 		};
 		MoverRegs RA{}, RB{};
 		uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
 		int mvl = 0;
+		bool intra_left = false;
 		int pending_x = -1;
 
 		auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t into the r_* registers
@@ -619,6 +658,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				const size_t at = (top_edge && row_ok) ? a - p.mb_w : a;
 				R.mvt = ((const uint32_t *)&p.mbi[at])[1];
 				R.nzt = p.nnz[at * NNZ_PER_MB + l];
+				if (MIXED) {
+					R.ty = ((const uint32_t *)&p.mbi[a])[0];
+					R.tyt = ((const uint32_t *)&p.mbi[at])[0];
+				}
 			}
 			if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
 				R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
@@ -680,6 +723,24 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					}
 					wc = ((cod_c >> (8 * bsc0)) & 0xffu) | ((cod_c >> (8 * bsc2)) & 0xffu) << 8 |
 					     ((cod_c >> (8 * bh[0])) & 0xffu) << 16 | ((cod_c >> (8 * bh[2])) & 0xffu) << 24;
+					if (MIXED) { // an intra macroblock on either side: bS 4 on the macroblock edge (code 0xC0), 3 inside
+						const bool ic = (int)(int8_t)(R.ty & 0xffu) < MB_P16x16, it = (int)(int8_t)(R.tyt & 0xffu) < MB_P16x16;
+						if (ic) {
+							const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
+							wv = (wv & 0xffu) | in_y;
+							wh = (wh & 0xffu) | in_y;
+							wc = (wc & 0x00ff00ffu) | in_c << 8 | in_c << 24;
+						}
+						if (left_edge && (ic || intra_left)) {
+							wv = (wv & ~0xffu) | 0xC0u;
+							wc = (wc & ~0xffu) | 0xC0u;
+						}
+						if (top_edge && (ic || it)) {
+							wh = (wh & ~0xffu) | 0xC0u;
+							wc = (wc & ~0xff0000u) | 0xC00000u;
+						}
+						intra_left = ic;
+					}
 				}
 				nz_left = nz_cur;
 				mvl = mvc;
@@ -777,21 +838,21 @@ DEVI void deblock2_body(const Params &p, const int wg)
 
 // planes: 1 luma, 2 chroma, 3 both planes in every wave pair (many units), 4 both planes in
 // one launch as separate workgroups (first half of the grid luma, second half chroma)
-template <bool IDR>
+template <int MODE>
 __global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2_planes(Params p, int planes)
 {
 	const int nwg = p.n_streams * p.slice_num * p.wf_split;
 	if (planes == 4) {
 		if ((int)blockIdx.x < nwg)
-			deblock2_body<IDR, 1>(p, (int)blockIdx.x);
+			deblock2_body<MODE, 1>(p, (int)blockIdx.x);
 		else
-			deblock2_body<IDR, 2>(p, (int)blockIdx.x - nwg);
+			deblock2_body<MODE, 2>(p, (int)blockIdx.x - nwg);
 	} else if (planes == 1) {
-		deblock2_body<IDR, 1>(p, (int)blockIdx.x);
+		deblock2_body<MODE, 1>(p, (int)blockIdx.x);
 	} else if (planes == 2) {
-		deblock2_body<IDR, 2>(p, (int)blockIdx.x);
+		deblock2_body<MODE, 2>(p, (int)blockIdx.x);
 	} else {
-		deblock2_body<IDR, 3>(p, (int)blockIdx.x);
+		deblock2_body<MODE, 3>(p, (int)blockIdx.x);
 	}
 	if (!p.db_self_reset)
 		return;
@@ -1565,16 +1626,19 @@ int Launch::deblock(const Params &p, void *stream, int planes)
 	const size_t lds = sizeof(Db2Shared<1>) > sizeof(Db2Shared<3>) ? sizeof(Db2Shared<1>) : sizeof(Db2Shared<3>);
 	static bool attr_set = false;
 	if (!attr_set) {
-		if (hipFuncSetAttribute((const void *)k_deblock2_planes<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
 			return -1;
 		attr_set = true;
 	}
 	dim3 grid(planes == 4 ? 2 * nwg : nwg);
 	if (p.is_idr)
-		hipLaunchKernelGGL(k_deblock2_planes<true>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+		hipLaunchKernelGGL(k_deblock2_planes<1>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+	else if (p.intra_refresh > 0) // intra macroblocks among the inter ones: both sets of boundary strengths
+		hipLaunchKernelGGL(k_deblock2_planes<2>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
 	else
-		hipLaunchKernelGGL(k_deblock2_planes<false>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+		hipLaunchKernelGGL(k_deblock2_planes<0>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
 	return (int)hipGetLastError();
 }
 

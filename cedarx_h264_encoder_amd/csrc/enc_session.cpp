@@ -541,7 +541,7 @@ void build_sps_pps(cedar_enc *e)
 	pps.se(c.qp - 26);
 	pps.se(e->chroma_qp_offset);
 	pps.put(1, 1); // deblocking_filter_control_present_flag
-	pps.put(0, 1);
+	pps.put(e->ext.intra_refresh > 0, 1); // constrained_intra_pred_flag: refresh macroblocks must not lean on inter samples
 	pps.put(0, 1);
 	pps.trailing();
 	e->sps_pps.clear();
@@ -667,6 +667,7 @@ void fill_static_params(cedar_enc *e)
 	P.row_num = q1 - r0;
 	P.search_range = e->ext.search_range;
 	P.subpel = e->ext.subpel;
+	P.intra_refresh = e->ext.intra_refresh;
 	set_qp_params(P, c.qp, e->chroma_qp_offset);
 }
 
@@ -835,6 +836,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "gop_low_latency must be 0 or 1");
 	if (ext.subpel < 0 || ext.subpel > 2)
 		return fail(e, -EINVAL, "subpel %d outside 0..2", ext.subpel);
+	if (ext.intra_refresh < 0 || (ext.intra_refresh > 0 && ext.intra_refresh < 3) || ext.intra_refresh > 65535)
+		return fail(e, -EINVAL, "intra_refresh %d: 0 (off) or 3..65535", ext.intra_refresh);
 	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
@@ -1446,6 +1449,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	f.done_tag = seq;
 	Params P = e->P;
 	P.is_idr = idr;
+	P.refresh_t = e->frame_p_count; // P pictures since the IDR (cyclic intra refresh)
 	f.qp_bump = replay ? replay->qp_bump : 0;
 	if (e->rc_target > 0 || f.qp_bump)
 		set_qp_params(P, (e->rc_target > 0 ? rc_pick_qp(e->cfg.qp, e->rc_target, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyframe_interval)

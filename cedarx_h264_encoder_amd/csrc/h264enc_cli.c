@@ -64,6 +64,7 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.first_frame_index = env_int("H264ENC_FIRST_FRAME", 0);
 	ext.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	ext.bitrate = env_int("H264ENC_BITRATE", 0);
+	ext.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
 	ext.subpel = env_int("H264ENC_SUBPEL", 0);
 
 	ret = cedar_enc_config_ext(cedar, &config, &ext);

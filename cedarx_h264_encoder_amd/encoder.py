@@ -42,7 +42,7 @@ class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate")]
+        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh")]
 
 
 class _Stats(ctypes.Structure):
@@ -170,6 +170,7 @@ class EncoderConfig:
     subpel: int = 0             # motion vectors: 0 whole samples, 1 half, 2 quarter
     gop_low_latency: int = 0    # gop_parallel: 1 = half the latency, every group's IDR step exposed
     bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
+    intra_refresh: int = 0      # N >= 3: macroblocks with (x + 2*y + t) % N == 0 of the t-th P picture are coded intra
 
 
 class CedarEncoder:
@@ -198,7 +199,7 @@ class CedarEncoder:
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate"):
+                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh"):
             setattr(x, n, getattr(cfg, n))
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")

@@ -130,6 +130,14 @@ struct cedar_enc_config_ext {
 				depend on how many frames the caller keeps in flight. qp is the starting
 				point. One stream, all slices, no gop_parallel. 0: fixed QP, as the reference
 				(cedar.c:1165-1168)                                                      */
+	int intra_refresh;   /* N >= 3: cyclic intra refresh -- the VE has a register for it that the reference
+				never writes (cedar_regs.h:43 CEDAR_H264ENC_CYCLICINTRAREFRESH, SURVEY
+				8(f)-4). In the t-th P picture after an IDR the macroblocks with
+				(x + 2*y + t) % N == 0 are coded Intra16x16 (DC), so any N consecutive P
+				pictures renew every macroblock; the PPS then carries
+				constrained_intra_pred_flag = 1 (a refresh macroblock must not lean on inter
+				samples, or it would refresh nothing). 0 (default): off, PPS as the
+				reference's (cedar.c:976)                                                  */
 };
 
 typedef struct cedar_enc cedar_enc;

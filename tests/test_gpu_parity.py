@@ -958,7 +958,59 @@ def test_gop_parallel_two_streams_and_collect_before_input_is_there(ce):
         assert [g[s] for g in got] == want[s], s
 
 
-@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2"])
+@pytest.mark.parametrize("w,h,qp,n,keyint,slices,subpel,streams,frames", [
+    (96, 64, 28, 3, 12, 1, 0, 1, 8), (320, 240, 30, 5, 25, 3, 2, 1, 8), (16, 16, 24, 3, 6, 1, 0, 1, 8),
+    (70, 50, 20, 4, 9, 2, 1, 2, 7), (640, 368, 24, 11, 25, 1, 2, 1, 5), (1920, 1080, 26, 30, 25, 1, 0, 1, 3),
+    (32, 160, 33, 3, 30, 2, 0, 3, 6)])
+def test_cyclic_intra_refresh_equals_the_oracle(ce, w, h, qp, n, keyint, slices, subpel, streams, frames):
+    """intra_refresh = N: in the t-th P picture the macroblocks with (x + 2*y + t) % N == 0 are coded
+    Intra16x16 from the constant prediction (constrained_intra_pred in the PPS): k_inter's refresh branch,
+    intra macroblock types and intra-aware vector prediction in both CAVLC kernels, bS 3/4 beside inter
+    edges in the deblock kernel. Records, levels, reconstruction and bytes equal the scalar twin's,
+    frames kept in flight; the independent decoder rebuilds the same pictures."""
+    from tests.indep import h264_refdec as rd
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, subpel=subpel, intra_refresh=n))
+           for _ in range(streams)]
+    dec = rd.Decoder() if w <= 320 else None
+    src = [[ol.gen_frame("BC"[s & 1], w, h, f, s << 8) for s in range(streams)] for f in range(frames)]
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, subpel=subpel,
+                         n_streams=streams, intra_refresh=n) as ge:
+        for f in range(frames):   # one at a time: the whole state is compared
+            for s in range(streams):
+                ge.set_input(src[f][s][0], src[f][s][1], stream=s)
+            ge.encode()
+            refs = [oes[s].encode(*src[f][s]) for s in range(streams)]
+            if streams == 1:
+                _compare_state(oes[0], ge)
+                mb = ge.debug_read("mbinfo")
+                my, mx = np.mgrid[0:ge.mb_h, 0:ge.mb_w]
+                t = f % keyint
+                if t:
+                    assert np.array_equal((mb["type"] <= 1).reshape(ge.mb_h, ge.mb_w), (mx + 2 * my + t) % n == 0)
+            for s in range(streams):
+                assert ge.output(s) == refs[s], "frame %d stream %d: bytestream differs" % (f, s)
+            if dec:
+                pic, = dec.decode(ge.output(0))
+                assert pic.luma_bytes() == ge.debug_read("recon_y").tobytes()
+    # the same stream with frames in flight
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, subpel=subpel, intra_refresh=n))
+    want = [oe.encode(*src[f][0]) for f in range(frames)]
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, subpel=subpel, intra_refresh=n) as ge:
+        got, q = [], 0
+        for f in range(frames):
+            if q == ge.pipeline_depth:
+                ge.collect(); got.append(ge.output(0)); q -= 1
+            ge.set_input(src[f][0][0], src[f][0][1])
+            ge.submit(); q += 1
+        while q:
+            ge.collect(); got.append(ge.output(0)); q -= 1
+    assert got == want
+    for bad in (1, 2, -3, 70000):
+        with pytest.raises(ce.EncoderError):
+            ce.CedarEncoder(width=w, height=h, intra_refresh=bad)
+
+
+@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2", "refresh"])
 def test_fuzz_sweep_against_oracle(mode):
     """tools/fuzz_parity.py with a fixed seed: random geometry (every other picture 1-3 macroblocks
     wide or high in "narrow"), QP, GOP length, slices, streams (up to 33 in "wide"), search range,
@@ -973,6 +1025,8 @@ def test_fuzz_sweep_against_oracle(mode):
         env["FUZZ_WIDE"] = "1"
     if mode == "r2":   # round 2's options on top: sub-sample vectors, the macroblock bit cap, rate control, GOP lanes
         env["FUZZ_R2"] = "1"
+    if mode == "refresh":   # ... and cyclic intra refresh on top of those
+        env["FUZZ_R2"] = env["FUZZ_REFRESH"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "40"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=root)

@@ -55,6 +55,10 @@ for case in range(n_cases):
             G = int(rng.randint(2, 5))
             n = int(rng.randint(3, 3 * keyint * G + 3))
             kw.pop("repeat_headers", None)
+    if os.environ.get("FUZZ_REFRESH"):   # cyclic intra refresh on top of whatever the case drew
+        kw.update(intra_refresh=int(rng.choice([3, 3, 4, 7, 50])))
+        if "subpel" not in kw:
+            kw.update(subpel=int(rng.choice([0, 2])))
     if case < first_case:
         continue
     print("case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s n %d depth<=%d" % (case, w, h, qp, keyint, slices, S, pat, kw, n, depth_draw), flush=True)
