@@ -38,7 +38,8 @@ constexpr int SLOT_WORDS = SLOT_BYTES / 4;
 constexpr int ESC_CHUNK = 32;     // bytes of RBSP per emulation-prevention thread
 constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
-constexpr int WF_MAX_SPLIT = 8;   // workgroups sharing one unit's wavefront
+constexpr int DB2_XRING = 16;     // deblock: macroblocks of bottom rows a band keeps for the band below (power of two)
+constexpr int WF_MAX_SPLIT = 16;  // workgroups sharing one unit's wavefront
 constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress
 constexpr int PROG_BANDS = 128;     // deblock bands (4 macroblock rows) per unit with a progress word
 constexpr int PROG_ALL = 0xffff;     // progress value: everything through
@@ -112,6 +113,7 @@ struct Params {
 	uint64_t *wf_hbuf_intra;         // same shape, intra reconstruction (the two kernels of an IDR picture overlap)
 	int32_t wf_split;                // workgroups per unit: deblock
 	int32_t wf_split_intra;          // workgroups per unit: intra recon
+	int32_t db_pairs;                // filter/mover wave pairs per deblock workgroup: 8 (a whole CU) or 2
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
 	// picture along diagonals s = x + 2*y (absolute macroblock coordinates), so progress is
 	// counted in diagonals: "every macroblock with x + 2*y < D is through". Words live in device

@@ -188,8 +188,7 @@ DEVI int mv_far(int a, int b)
 	return (int)((uint32_t)(3 - iabs(dx)) >> 31) | (int)((uint32_t)(3 - iabs(dy)) >> 31);
 }
 
-constexpr int DB2_PAIRS = WF_WAVES / 2;
-constexpr int DB2_XRING = 16; // macroblocks of bottom rows a band keeps for the band below (power of two)
+constexpr int DB2_PAIRS_MAX = WF_WAVES / 2;
 
 struct Db2GroupLds {
 	uint8_t y[3][20 * DT_STRIDE];
@@ -245,13 +244,17 @@ DEVI void lds_signal(int *word, int value, int lane)
 // Everything a deblock workgroup keeps in LDS. It lives in DYNAMIC shared memory so that the
 // luma and the chroma instantiation can sit in one kernel (k_deblock2_planes: one launch, the
 // plane picked per workgroup) without their footprints adding up.
-template <int PL>
+// PAIRS filter/mover wave pairs per workgroup: 8 (a whole CU: one unit's wavefront as fast as it goes)
+// or 2 (a workgroup small enough to find room beside the analysis of other units)
+template <int PL, int PAIRS>
 struct Db2Shared {
-	Db2GroupLds g[DB2_PAIRS * 4];
+	Db2GroupLds g[PAIRS * 4];
 	// bottom rows of a band's last macroblock row, for the pair that filters the band below
-	uint8_t xbot[DB2_PAIRS][DB2_XRING][(PL & 1) ? 64 : 16];
-	uint8_t xbotc[DB2_PAIRS][DB2_XRING][(PL & 2) ? 32 : 16];
-	int staged[DB2_PAIRS], filtered[DB2_PAIRS], vdone[DB2_PAIRS]; // steps staged / filtered / through their vertical edges
+	// (a pair with few partners is back at its ring while the band below its previous one still reads
+	// it: two rings, taken in turn)
+	uint8_t xbot[PAIRS][PAIRS < 8 ? 2 : 1][DB2_XRING][(PL & 1) ? 64 : 16];
+	uint8_t xbotc[PAIRS][PAIRS < 8 ? 2 : 1][DB2_XRING][(PL & 2) ? 32 : 16];
+	int staged[PAIRS], filtered[PAIRS], vdone[PAIRS]; // steps staged / filtered / through their vertical edges
 	int ticket;
 	int abort; // a wait of this workgroup ran out: stop waiting
 };
@@ -260,12 +263,13 @@ extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 
 // MODE 0: a P picture of inter macroblocks; 1: an IDR picture (all intra: bS 4 on macroblock edges, 3 inside);
 // 2: a P picture with intra macroblocks in it (cyclic intra refresh): the strengths of both, per edge
-template <int MODE, int PL>
+template <int MODE, int PL, int PAIRS>
 DEVI void deblock2_body(const Params &p, const int wg)
 {
 	constexpr bool IDR = MODE == 1, MIXED = MODE == 2;
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
-	Db2Shared<PL> &S = *reinterpret_cast<Db2Shared<PL> *>(dyn_lds);
+
+	Db2Shared<PL, PAIRS> &S = *reinterpret_cast<Db2Shared<PL, PAIRS> *>(dyn_lds);
 	Db2GroupLds *s_g = S.g;
 	auto &s_xbot = S.xbot;
 	auto &s_xbotc = S.xbotc;
@@ -275,8 +279,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	// waves land on SIMD wave%4: filter k on SIMD k%4, its mover on SIMD (k+2)%4, so the
 	// busy filter waves of a workgroup (bands come in pair order) never share a SIMD early
-	const bool is_mover = wave >= DB2_PAIRS;
-	const int pair = is_mover ? (wave + 6) & (DB2_PAIRS - 1) : wave;
+	const bool is_mover = wave >= PAIRS;
+	const int pair = is_mover ? (wave + 6) & (PAIRS - 1) : wave;
 	const int g = lane >> 4, l = lane & 15;
 	const int NWG = p.wf_split;
 	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
@@ -284,7 +288,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : wg;
 		S.abort = 0;
 	}
-	if (threadIdx.x < DB2_PAIRS) {
+	if (threadIdx.x < PAIRS) {
 		s_staged[threadIdx.x] = 0;
 		s_filtered[threadIdx.x] = 0;
 		s_vdone[threadIdx.x] = 0;
@@ -325,7 +329,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	uint32_t xseen = 0;
 
 	int iter = 0;
-	for (int band = b_lo + pair; band < b_hi; band += DB2_PAIRS, iter++) {
+	for (int band = b_lo + pair; band < b_hi; band += PAIRS, iter++) {
 		const int base = iter * (nsteps + 2); // absolute step numbering of this pair's counters
 		const int my = r0 + 4 * band + g;
 		const bool row_ok = my < r1;
@@ -335,8 +339,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		// wave would; its movers stay out of that dependency chain
 		const int rel = band - b_lo;
 		const bool in_top = rel > 0, in_bot = band + 1 < b_hi;
-		const int pair_up = (rel - 1) & (DB2_PAIRS - 1), base_up = ((rel - 1) / DB2_PAIRS) * (nsteps + 2);
-		const int pair_dn = (rel + 1) & (DB2_PAIRS - 1), base_dn = ((rel + 1) / DB2_PAIRS) * (nsteps + 2);
+		const int pair_up = (rel - 1) & (PAIRS - 1), base_up = ((rel - 1) / PAIRS) * (nsteps + 2);
+		const int pair_dn = (rel + 1) & (PAIRS - 1), base_dn = ((rel + 1) / PAIRS) * (nsteps + 2);
+		constexpr int NBUF = PAIRS < 8 ? 2 : 1;
+		const int wb = iter & (NBUF - 1), rb = ((rel - 1) / PAIRS) & (NBUF - 1); // this band's ring, the ring of the band above
 		const bool feeds_next = g == 3 && band + 1 < nbands; // its last 4 rows are stored by whoever filters below
 		const bool xwg_band = band == b_lo && b_lo > 0;
 		const bool xwg_top = g == 0 && xwg_band;
@@ -346,10 +352,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			// =========================== filter wave ===========================
 			// The hand-off ring of this pair may still hold the end of the pair's PREVIOUS band (8
 			// bands up), which the band below that one reads: wait until it is through before the
-			// ring is written again (only when a workgroup has more bands than pairs).
-			if (iter > 0 && in_bot) {
-				const int relc = rel - DB2_PAIRS + 1;
-				lds_wait_ge(&s_filtered[relc & (DB2_PAIRS - 1)], (relc / DB2_PAIRS) * (nsteps + 2) + nsteps, xw);
+			// ring is written again (only when a workgroup has more bands than pairs: NBUF times more).
+			if (iter >= NBUF && in_bot) {
+				const int relc = rel - NBUF * PAIRS + 1;
+				lds_wait_ge(&s_filtered[relc & (PAIRS - 1)], (relc / PAIRS) * (nsteps + 2) + nsteps, xw);
 			}
 			for (int t = 0; t < nsteps; t++) {
 				const int mx = t - g;
@@ -434,9 +440,9 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				// horizontal edges of this step
 				if (act && left_edge && g == 3 && in_bot) {
 					if (DO_Y && l >= 12)
-						*(uint32_t *)(s_xbot[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+						*(uint32_t *)(s_xbot[pair][wb][(mx - 1) & (DB2_XRING - 1)] + (l - 12) * 16 + 12) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
 					else if (DO_C && l >= 6 && l < 8)
-						*(uint32_t *)(s_xbotc[pair][(mx - 1) & (DB2_XRING - 1)] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+						*(uint32_t *)(s_xbotc[pair][wb][(mx - 1) & (DB2_XRING - 1)] + (l - 6) * 16 + 12) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
 				}
 				lds_signal(&s_vdone[pair], base + t + 1, lane);
 				// rows above: saved by the group above a step ago, their last columns patched by its
@@ -464,9 +470,9 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						}
 					} else if (in_top) {
 						if (DO_Y && l < 4)
-							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(s_xbot[pair_up][mx & (DB2_XRING - 1)] + l * 16);
+							*(u32x4 *)(L.y[slot] + l * DT_STRIDE + 16) = *(const u32x4 *)(s_xbot[pair_up][rb][mx & (DB2_XRING - 1)] + l * 16);
 						else if (DO_C && l >= 4 && l < 6)
-							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(s_xbotc[pair_up][mx & (DB2_XRING - 1)] + (l - 4) * 16);
+							*(u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16) = *(const u32x4 *)(s_xbotc[pair_up][rb][mx & (DB2_XRING - 1)] + (l - 4) * 16);
 					}
 				}
 				WAVE_SYNC();
@@ -534,7 +540,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						if (left_edge)
 							*(uint32_t *)(L.bot[(mx - 1) & 3] + (l - 12) * 16 + 12) = patch;
 						if (g == 3 && in_bot)
-							*(u32x4 *)(s_xbot[pair][mx & (DB2_XRING - 1)] + (l - 12) * 16) = rowv;
+							*(u32x4 *)(s_xbot[pair][wb][mx & (DB2_XRING - 1)] + (l - 12) * 16) = rowv;
 					} else if (DO_C && l >= 6 && l < 8) {
 						const u32x4 rowv = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
 						const uint32_t patch = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
@@ -542,7 +548,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						if (left_edge)
 							*(uint32_t *)(L.botc[(mx - 1) & 3] + (l - 6) * 16 + 12) = patch;
 						if (g == 3 && in_bot)
-							*(u32x4 *)(s_xbotc[pair][mx & (DB2_XRING - 1)] + (l - 6) * 16) = rowv;
+							*(u32x4 *)(s_xbotc[pair][wb][mx & (DB2_XRING - 1)] + (l - 6) * 16) = rowv;
 					}
 				}
 				lds_signal(&s_filtered[pair], base + t + 1, lane);
@@ -838,21 +844,21 @@ DEVI void deblock2_body(const Params &p, const int wg)
 
 // planes: 1 luma, 2 chroma, 3 both planes in every wave pair (many units), 4 both planes in
 // one launch as separate workgroups (first half of the grid luma, second half chroma)
-template <int MODE>
-__global__ __launch_bounds__(64 * WF_WAVES) void k_deblock2_planes(Params p, int planes)
+template <int MODE, int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS) void k_deblock2_planes(Params p, int planes)
 {
 	const int nwg = p.n_streams * p.slice_num * p.wf_split;
 	if (planes == 4) {
 		if ((int)blockIdx.x < nwg)
-			deblock2_body<MODE, 1>(p, (int)blockIdx.x);
+			deblock2_body<MODE, 1, PAIRS>(p, (int)blockIdx.x);
 		else
-			deblock2_body<MODE, 2>(p, (int)blockIdx.x - nwg);
+			deblock2_body<MODE, 2, PAIRS>(p, (int)blockIdx.x - nwg);
 	} else if (planes == 1) {
-		deblock2_body<MODE, 1>(p, (int)blockIdx.x);
+		deblock2_body<MODE, 1, PAIRS>(p, (int)blockIdx.x);
 	} else if (planes == 2) {
-		deblock2_body<MODE, 2>(p, (int)blockIdx.x);
+		deblock2_body<MODE, 2, PAIRS>(p, (int)blockIdx.x);
 	} else {
-		deblock2_body<MODE, 3>(p, (int)blockIdx.x);
+		deblock2_body<MODE, 3, PAIRS>(p, (int)blockIdx.x);
 	}
 	if (!p.db_self_reset)
 		return;
@@ -1618,28 +1624,33 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 }
 
 
-int Launch::deblock(const Params &p, void *stream, int planes)
+template <int PAIRS>
+static int launch_deblock(const Params &p, hipStream_t s, int planes)
 {
 	const int nwg = p.n_streams * p.slice_num * p.wf_split;
-	hipStream_t s = (hipStream_t)stream;
-	// ~130 KiB of dynamic LDS: one workgroup per CU by construction
-	const size_t lds = sizeof(Db2Shared<1>) > sizeof(Db2Shared<3>) ? sizeof(Db2Shared<1>) : sizeof(Db2Shared<3>);
+	// 8 pairs: ~130 KiB of dynamic LDS, one workgroup per CU by construction; 2 pairs: ~33 KiB
+	const size_t lds = sizeof(Db2Shared<1, PAIRS>) > sizeof(Db2Shared<3, PAIRS>) ? sizeof(Db2Shared<1, PAIRS>) : sizeof(Db2Shared<3, PAIRS>);
 	static bool attr_set = false;
 	if (!attr_set) {
-		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<1, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
 			return -1;
 		attr_set = true;
 	}
 	dim3 grid(planes == 4 ? 2 * nwg : nwg);
 	if (p.is_idr)
-		hipLaunchKernelGGL(k_deblock2_planes<1>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+		hipLaunchKernelGGL((k_deblock2_planes<1, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
 	else if (p.intra_refresh > 0) // intra macroblocks among the inter ones: both sets of boundary strengths
-		hipLaunchKernelGGL(k_deblock2_planes<2>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+		hipLaunchKernelGGL((k_deblock2_planes<2, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
 	else
-		hipLaunchKernelGGL(k_deblock2_planes<0>, grid, dim3(64 * WF_WAVES), lds, s, p, planes);
+		hipLaunchKernelGGL((k_deblock2_planes<0, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
 	return (int)hipGetLastError();
+}
+
+int Launch::deblock(const Params &p, void *stream, int planes)
+{
+	return p.db_pairs == 2 ? launch_deblock<2>(p, (hipStream_t)stream, planes) : launch_deblock<DB2_PAIRS_MAX>(p, (hipStream_t)stream, planes);
 }
 
 int Launch::intra_recon(const Params &p, void *stream)

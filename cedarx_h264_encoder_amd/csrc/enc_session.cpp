@@ -263,6 +263,7 @@ struct cedar_enc {
 	int inter_bands = 1;
 	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
 	int wf_split = 1, wf_split_intra = 1;
+	int db_pairs = 8;
 	// pinned host memory
 	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
 	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = {}, *dv_out[CEDAR_ENC_PIPELINE_DEPTH] = {};     // pinned + mapped, and its device view
@@ -291,6 +292,7 @@ struct cedar_enc {
 	// reconstruction deblocked (s_db)
 	// (x MAX_COHORTS: index slot * MAX_COHORTS + cohort)
 	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH * 4] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH * 4] = {}, ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH * 4] = {};
+
 	InFlight fl[CEDAR_ENC_PIPELINE_DEPTH];
 	int fl_head = 0, fl_count = 0; // ring of frames in flight
 	// results of the last collected frame
@@ -997,6 +999,32 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// 62-67 M; x 16: pipelining loses (80 M against 91 M), frames run back to back from there.
 		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
 		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 3) / 4);
+		const char *env_p = getenv("CEDAR_DB_PAIRS");
+		// Deblock workgroups: 8 wave pairs (a whole CU: one unit's wavefront as fast as it goes, what the
+		// pipelined sessions of up to 8 units want) or 2 pairs -- a quarter of the LDS and of the waves,
+		// which finds room on a CU beside other kernels' workgroups. Above 8 units frames run back to back
+		// and the small form wins: 16 x 1080p 114 -> 120 M MB/s, 32: 134 -> 139, 64: 139 -> 146.
+		e->db_pairs = env_p ? (atoi(env_p) == 2 ? 2 : 8) : n_units > 8 ? 2 : 8;
+		if (e->db_pairs == 2 && !env) { // small workgroups: as many as it takes to give every band a wave pair
+			const int want = (nb_min + 1) / 2;
+			e->wf_split = want > WF_MAX_SPLIT ? WF_MAX_SPLIT : want < 1 ? 1 : want;
+		}
+		// A band runs at most DB2_XRING (+3) macroblocks ahead of the band below it (the hand-off ring in
+		// LDS), and a workgroup with more bands than wave pairs starts band b + pairs when band b is
+		// through: on a row longer than pairs x ring that is a cycle. Then every band needs a pair.
+		auto db_safe = [&](int split, int pairs) {
+			return (nb_max + split - 1) / split <= pairs || P.mb_w + 3 <= pairs * DB2_XRING;
+		};
+		auto widen = [&](int pairs) {
+			while (!db_safe(e->wf_split, pairs) && e->wf_split < WF_MAX_SPLIT && e->wf_split < nb_min)
+				e->wf_split++;
+			return db_safe(e->wf_split, pairs);
+		};
+		if (!widen(e->db_pairs)) {
+			e->db_pairs = 8;
+			if (!widen(8))
+				return fail(e, -EINVAL, "picture too tall for the deblock wavefront (%d bands of a slice)", nb_max);
+		}
 	}
 	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
@@ -1164,15 +1192,18 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			}
 		}
 		{
-			// cohorts (submit_frame): off unless asked for. Measured on MI355X, 32 x 1080p: 2 cohorts 2.29 ms
-			// per step against 2.20 ms with one, 16 x 1080p 1.63 against 1.32 -- the deblocking of one
-			// cohort does NOT run beside the search of the other: a deblock workgroup is 16 waves of 128
-			// registers, i.e. a whole CU's register file, and never finds an empty CU while k_inter's
-			// small workgroups keep refilling them (CU masks for the two streams: 2.96 ms; a higher
-			// stream priority for the deblocking: no change). Kept for the day the wavefront kernels
-			// come in a small-workgroup form.
+			// cohorts (submit_frame): two from 32 units on. With whole-CU deblock workgroups the deblocking
+			// of one cohort never ran beside the search of the other (16 waves of 128 registers find no
+			// empty CU while k_inter's small workgroups keep refilling them: 32 x 1080p 2.29 ms per step
+			// against 2.20 ms with one cohort; CU masks 2.96 ms; stream priority no change). With the
+			// 2-pair workgroups it does: 32 x 1080p 1.87 -> 1.73 ms (139 -> 151 M MB/s), 64: 3.58 -> 3.18 ms
+			// (146 -> 164 M). Not below: the deblock wavefront of a picture takes its ~0.45 ms however few
+			// pictures there are, and half of 16 streams' search is shorter than that (16: 120 -> 92 M).
+			// Three or four cohorts lose everywhere (more, smaller launches on the same four hardware queues).
+			// Wave priority (s_setprio) for the deblock waves and sleeping instead of spinning in their
+			// waits changed nothing either way.
 			const char *envc = getenv("CEDAR_COHORTS");
-			int C = envc ? atoi(envc) : 1;
+			int C = envc ? atoi(envc) : (n_units >= 32 && e->db_pairs == 2 ? 2 : 1);
 			if (e->row_pipe || C < 1)
 				C = 1;
 			if (C > MAX_COHORTS) C = MAX_COHORTS;
@@ -1257,6 +1288,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.stripe_s1 = 0;
 	P.prog_tag = P.prev_tag = 0;
 	P.wf_split = e->wf_split;
+	P.db_pairs = e->db_pairs;
 	P.wf_split_intra = e->wf_split_intra;
 	{
 		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO

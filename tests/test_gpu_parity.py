@@ -174,6 +174,22 @@ def test_4k_single_slice_row_count_not_multiple_of_four(ce):
             assert np.array_equal(duv, ge.debug_read("recon_uv"))
 
 
+@pytest.mark.parametrize("pairs", ["8", "2"])
+def test_wide_picture_with_more_bands_than_wave_pairs(ce, monkeypatch, pairs):
+    """3840x592 (240 x 37 macroblocks, 10 deblock bands) asked to run as ONE deblock workgroup: a band
+    may only run 16 (+3) macroblocks ahead of the band below (the LDS hand-off ring) while band b + pairs
+    waits for band b's wave pair, so on a row this long ten bands on eight (or two) pairs would wait for
+    each other forever (-EIO after the spin bound). The session widens the split until every band has a pair."""
+    monkeypatch.setenv("CEDAR_WF_SPLIT", "1")
+    monkeypatch.setenv("CEDAR_DB_PAIRS", pairs)
+    w, h = 3840, 592
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25))
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25) as ge:
+        for f in range(3):
+            y, uv = ol.gen_frame("B", w, h, f)
+            assert ge.encode_frame(y, uv) == oe.encode(y, uv), f
+
+
 def test_slices_on_separate_sessions_concatenate_to_the_whole(ce):
     """configs[3] sharding: each 'GPU' encodes one slice with its own session; the
     host concatenates the NALs. Must equal the single-session 4-slice stream."""
