@@ -84,6 +84,21 @@ int main(int argc, char **argv)
 	cfg.bitrate = env_int("H264ENC_BITRATE", 0);
 	cfg.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	cfg.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
+	if (getenv("H264ENC_ROI")) { /* "x,y,w,h,dqp;..." in macroblocks, up to 4 regions */
+		const char *r = getenv("H264ENC_ROI");
+
+		while (*r && cfg.roi_count < 4) {
+			int *v = cfg.roi[cfg.roi_count];
+
+			if (sscanf(r, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5)
+				break;
+			cfg.roi_count++;
+			r = strchr(r, ';');
+			if (!r)
+				break;
+			r++;
+		}
+	}
 	enc = h264o_open(&cfg, &err);
 	if (!enc) {
 		fprintf(stderr, "%s(): config failed: %s\n", __func__, strerror(-err));

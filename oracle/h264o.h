@@ -59,6 +59,11 @@ typedef struct h264o_config {
 	                       * CYCLICINTRAREFRESH, that the driver never writes) -- in the t-th P picture after an IDR
 	                       * the macroblocks with (x + 2*y + t) % N == 0 are coded Intra16x16 (DC), and the PPS sets
 	                       * constrained_intra_pred_flag so that they do not lean on inter samples; 0: off */
+	int roi_count;        /* 0..4 regions of interest (the VE has four, cedar_regs.h:76-80 ROI_QP_OFFSET, ROI_n_AREA;
+	                       * the driver never writes them) */
+	int roi[4][5];        /* x, y, width, height in macroblocks and the QP offset (-24..24) of the macroblocks inside;
+	                       * where regions overlap the first one counts. QP of a macroblock = slice QP + offset,
+	                       * clipped to 1..51, carried by mb_qp_delta */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */
@@ -102,6 +107,7 @@ const uint8_t *h264o_recon_chroma(const h264o_enc *e);
 int h264o_last_frame_type(const h264o_enc *e); /* 1 = IDR, 0 = P */
 int h264o_frame_qp(const h264o_enc *e);        /* slice QP of the last frame (rate control) */
 int h264o_max_mb_bits(const h264o_enc *e);     /* largest macroblock_layer() of the last frame, in bits */
+const uint8_t *h264o_mb_qp(const h264o_enc *e); /* [mb] QP_Y the decoder holds for every macroblock of the last frame */
 
 /* stand-alone pieces exported for known-answer tests */
 int h264o_write_sps(const h264o_config *cfg, uint8_t *out, int cap);

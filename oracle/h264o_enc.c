@@ -37,6 +37,9 @@ struct h264o_enc {
 	h264o_mb *mbs;
 	int last_idr;
 	int qp;          /* slice QP of the frame being coded: cfg.qp, or what the rate control picks */
+	int mbqp;        /* QP of the macroblock being analysed: qp + the offset of its region of interest */
+	uint8_t *qp_t;   /* [mb] QP every macroblock is quantised with (qp when no region covers it) */
+	uint8_t *qp_eff; /* [mb] QP_Y the decoder holds for it (7.4.5: a macroblock without mb_qp_delta keeps its predecessor's) */
 	int64_t rc_bits[64]; /* rate control history, index = frame number % 64: bits of the access unit ... */
 	int rc_qp[64];       /* ... and the QP it was coded at */
 	int closed_loop; /* env H264O_CLOSED_LOOP_INTRA=1 (tools/rd_record.py only): intra modes decided on reconstructed neighbours */
@@ -769,7 +772,7 @@ static void blk4_avail(const h264o_enc *e, int mx, int my, int row0, int idx,
 
 static int chroma_qp_of(const h264o_enc *e)
 {
-	int q = e->qp + e->cfg.chroma_qp_offset;
+	int q = e->mbqp + e->cfg.chroma_qp_offset;
 
 	return h264o_chroma_qp[q < 0 ? 0 : q > 51 ? 51 : q];
 }
@@ -870,7 +873,7 @@ static void chroma_residual(h264o_enc *e, h264o_mb *mb, int mx, int my,
 static int luma_block_16(const h264o_enc *e, const int16_t res[16], int16_t lv[16],
 			 uint8_t *rec, int stride, int intra)
 {
-	int qp = e->qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
+	int qp = e->mbqp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
 	int f = (1 << qbits) / (intra ? 3 : 6);
 	int16_t w[16];
 	int d[16], i, n = 0;
@@ -955,7 +958,7 @@ static void intra_decide_mb(h264o_enc *e, int mx, int my, int row0)
 		}
 	}
 	mb->i16_mode = (int8_t)best16;
-	mb->type = (sum4 + 32 * h264o_lambda[e->qp] < best16_sad) ? H264O_MB_I4x4 : H264O_MB_I16x16;
+	mb->type = (sum4 + 32 * h264o_lambda[e->mbqp] < best16_sad) ? H264O_MB_I4x4 : H264O_MB_I16x16;
 
 	bestc = -1;
 	for (mode = 0; mode < 4; mode++) {
@@ -993,7 +996,7 @@ static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0, int isolated)
 	uint8_t *ry = e->rec_y[e->cur], *ruv = e->rec_uv[e->cur];
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
 	int top_mb = !isolated && my > row0, left_mb = !isolated && mx > 0;
-	int qp = e->qp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
+	int qp = e->mbqp, qbits = 15 + qp / 6, rem = qp % 6, qs = qp / 6;
 	int idx, i, c;
 	uint8_t predc[2][64];
 
@@ -1231,7 +1234,7 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 	const uint8_t *refy = e->rec_y[e->cur ^ 1], *refuv = e->rec_uv[e->cur ^ 1];
 	uint8_t *ry = e->rec_y[e->cur];
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
-	int R = e->cfg.search_range, lam = h264o_lambda[e->qp];
+	int R = e->cfg.search_range, lam = h264o_lambda[e->mbqp];
 	int dx, dy, idx, c, qx, qy;
 	long best_key = -1;
 	int bdx = 0, bdy = 0;
@@ -1497,13 +1500,22 @@ static void filter_chroma_line(uint8_t *pix, int step, int bs, int alpha, int be
 	}
 }
 
+static int chroma_qp_at(const h264o_enc *e, int qp_y)
+{
+	int q = qp_y + e->cfg.chroma_qp_offset;
+
+	return h264o_chroma_qp[q < 0 ? 0 : q > 51 ? 51 : q];
+}
+
 static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 {
 	const h264o_mb *q = &e->mbs[my * e->mb_w + mx];
 	uint8_t *ry = e->rec_y[e->cur], *ruv = e->rec_uv[e->cur];
 	int stride = e->cw;
-	int qp = e->qp;
-	int qpc = chroma_qp_of(e);
+	/* thresholds come from the mean of the two macroblocks' QP_Y (and of their QP_C) across a macroblock
+	 * edge (8.7.2.2); they only differ from picture to picture unless regions of interest are set */
+	const int qq = e->qp_eff[my * e->mb_w + mx], qqc = chroma_qp_at(e, qq);
+	int qp = qq, qpc = qqc;
 	int alpha_y = h264o_alpha[qp], beta_y = h264o_beta[qp];
 	int alpha_c = h264o_alpha[qpc], beta_c = h264o_beta[qpc];
 	int edge, k, c;
@@ -1517,6 +1529,14 @@ static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 			if (mx == 0)
 				continue;
 			p = &e->mbs[my * e->mb_w + mx - 1];
+		}
+		{
+			const int qn = edge == 0 ? e->qp_eff[my * e->mb_w + mx - 1] : qq;
+
+			qp = (qn + qq + 1) >> 1;
+			qpc = (chroma_qp_at(e, qn) + qqc + 1) >> 1;
+			alpha_y = h264o_alpha[qp]; beta_y = h264o_beta[qp];
+			alpha_c = h264o_alpha[qpc]; beta_c = h264o_beta[qpc];
 		}
 		for (k = 0; k < 4; k++)
 			bs[k] = edge == 0 ? bs_of(p, 3, k, q, 0, k, 1) : bs_of(q, edge - 1, k, q, edge, k, 0);
@@ -1546,6 +1566,14 @@ static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 			if (my == row0) /* picture top, or slice top with idc 2 */
 				continue;
 			p = &e->mbs[(my - 1) * e->mb_w + mx];
+		}
+		{
+			const int qn = edge == 0 ? e->qp_eff[(my - 1) * e->mb_w + mx] : qq;
+
+			qp = (qn + qq + 1) >> 1;
+			qpc = (chroma_qp_at(e, qn) + qqc + 1) >> 1;
+			alpha_y = h264o_alpha[qp]; beta_y = h264o_beta[qp];
+			alpha_c = h264o_alpha[qpc]; beta_c = h264o_beta[qpc];
 		}
 		for (k = 0; k < 4; k++)
 			bs[k] = edge == 0 ? bs_of(p, k, 3, q, k, 0, 1) : bs_of(q, k, edge - 1, q, k, edge, 0);
@@ -1743,6 +1771,14 @@ static int pred_i4_mode(const h264o_enc *e, int mx, int my, int row0, int idx)
 	return a < b ? a : b;
 }
 
+/* mb_qp_delta (7.4.5): against QP_Y of the macroblock before it in decoding order, the slice's at its start */
+static int qp_delta_of(const h264o_enc *e, int mx, int my, int row0)
+{
+	const int i = my * e->mb_w + mx;
+
+	return e->qp_t[i] - (i == row0 * e->mb_w ? e->qp : e->qp_eff[i - 1]);
+}
+
 static void write_intra_mb(const h264o_enc *e, bitw *b, const h264o_mb *mb, int mx, int my,
 			   int row0, int p_slice)
 {
@@ -1763,13 +1799,13 @@ static void write_intra_mb(const h264o_enc *e, bitw *b, const h264o_mb *mb, int 
 		bw_ue(b, (uint32_t)mb->chroma_mode);
 		bw_ue(b, e->cbp_code_intra[mb->cbp & 0x3f]);
 		if (mb->cbp & 0x3f)
-			bw_se(b, 0); /* mb_qp_delta */
+			bw_se(b, qp_delta_of(e, mx, my, row0)); /* mb_qp_delta */
 	} else {
 		int t = 1 + mb->i16_mode + 4 * ((mb->cbp >> 4) & 3) + ((mb->cbp & 15) ? 12 : 0);
 
 		bw_ue(b, (uint32_t)(t + (p_slice ? 5 : 0)));
 		bw_ue(b, (uint32_t)mb->chroma_mode);
-		bw_se(b, 0); /* mb_qp_delta */
+		bw_se(b, qp_delta_of(e, mx, my, row0)); /* mb_qp_delta */
 	}
 	write_residual(e, b, mb, mx, my, row0);
 }
@@ -1810,6 +1846,12 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		return NULL;
 	if (cfg->subpel < 0 || cfg->subpel > 2)
 		return NULL;
+	if (cfg->roi_count < 0 || cfg->roi_count > 4)
+		return NULL;
+	for (i = 0; i < cfg->roi_count; i++)
+		if (cfg->roi[i][0] < 0 || cfg->roi[i][1] < 0 || cfg->roi[i][2] <= 0 || cfg->roi[i][3] <= 0 ||
+		    cfg->roi[i][4] < -24 || cfg->roi[i][4] > 24)
+			return NULL;
 	if (cfg->intra_refresh < 0 || (cfg->intra_refresh > 0 && cfg->intra_refresh < 3) || cfg->intra_refresh > 65535)
 		return NULL;
 	if (cfg->search_range < 0 || cfg->search_range > 16)
@@ -1838,10 +1880,12 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		e->rec_uv[i] = calloc((size_t)e->cw * e->ch / 2, 1);
 	}
 	e->mbs = calloc((size_t)e->mb_w * e->mb_h, sizeof(h264o_mb));
+	e->qp_t = calloc((size_t)e->mb_w * e->mb_h, 1);
+	e->qp_eff = calloc((size_t)e->mb_w * e->mb_h, 1);
 	e->rbsp_cap = e->mb_w * e->mb_h * 2048 + 1024;
 	e->rbsp = malloc((size_t)e->rbsp_cap);
 	if (!e->src_y || !e->src_uv || !e->rec_y[0] || !e->rec_y[1] || !e->rec_uv[0] ||
-	    !e->rec_uv[1] || !e->mbs || !e->rbsp) {
+	    !e->rec_uv[1] || !e->mbs || !e->rbsp || !e->qp_t || !e->qp_eff) {
 		h264o_close(e);
 		return NULL;
 	}
@@ -1866,6 +1910,8 @@ void h264o_close(h264o_enc *e)
 		free(e->rec_uv[i]);
 	}
 	free(e->mbs);
+	free(e->qp_t);
+	free(e->qp_eff);
 	free(e->rbsp);
 	free(e);
 }
@@ -1884,6 +1930,7 @@ const uint8_t *h264o_recon_chroma(const h264o_enc *e) { return e->rec_uv[e->cur 
 int h264o_last_frame_type(const h264o_enc *e) { return e->last_idr; }
 int h264o_max_mb_bits(const h264o_enc *e) { return e->max_mb_bits; }
 int h264o_frame_qp(const h264o_enc *e) { return e->qp; }
+const uint8_t *h264o_mb_qp(const h264o_enc *e) { return e->qp_eff; }
 
 /* ---- frame-level rate control (the VE has RC registers the driver never programs, cedar_regs.h:43-53;
  * SURVEY 8(f)-4). One QP per picture, carried by slice_qp_delta. The law, integer only:
@@ -1981,6 +2028,22 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is coded again, 6 QP steps coarser */
 	o = o_hdr;
 	max_mb_bits = 0;
+	/* regions of interest: the first one that covers a macroblock moves its QP */
+	for (my = 0; my < e->mb_h; my++)
+		for (mx = 0; mx < e->mb_w; mx++) {
+			int q = e->qp, k;
+
+			for (k = 0; k < e->cfg.roi_count; k++) {
+				const int *r = e->cfg.roi[k];
+
+				if (mx >= r[0] && mx < r[0] + r[2] && my >= r[1] && my < r[1] + r[3]) {
+					q += r[4];
+					break;
+				}
+			}
+			e->qp_t[my * e->mb_w + mx] = (uint8_t)(q < 1 ? 1 : q > 51 ? 51 : q);
+		}
+	e->mbqp = e->qp;
 
 	/* analysis + reconstruction */
 	for (s = 0; s < e->cfg.slice_count; s++) {
@@ -2000,21 +2063,27 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 					for (y = 0; y < 8; y++)
 						memcpy(e->rec_uv[e->cur] + (size_t)(my * 8 + y) * e->cw + mx * 16,
 						       e->src_uv + (size_t)(my * 8 + y) * e->cw + mx * 16, 16);
+					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					intra_decide_mb(e, mx, my, r0);
 					intra_recon_mb(e, mx, my, r0, 0);
 				}
 		} else if (idr) {
 			for (my = r0; my < r1; my++)
-				for (mx = 0; mx < e->mb_w; mx++)
+				for (mx = 0; mx < e->mb_w; mx++) {
+					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					intra_decide_mb(e, mx, my, r0);
+				}
 			for (my = r0; my < r1; my++)
-				for (mx = 0; mx < e->mb_w; mx++)
+				for (mx = 0; mx < e->mb_w; mx++) {
+					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					intra_recon_mb(e, mx, my, r0, 0);
+				}
 		} else {
 			for (my = r0; my < r1; my++)
 				for (mx = 0; mx < e->mb_w; mx++) {
 					h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
 
+					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					if (!refresh_mb(e, mx, my)) {
 						inter_mb(e, mx, my, r0, r1);
 						continue;
@@ -2039,6 +2108,22 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 						mb->type = H264O_MB_PSKIP;
 				}
 		}
+	}
+
+	/* QP_Y as the decoder will hold it: only a macroblock with an mb_qp_delta (Intra16x16, or any coded
+	 * block) can change it; the others, P_Skip included, inherit their predecessor's (7.4.5) */
+	for (s = 0; s < e->cfg.slice_count; s++) {
+		int r0, r1, prev = e->qp;
+
+		slice_rows(e, s, &r0, &r1);
+		for (my = r0; my < r1; my++)
+			for (mx = 0; mx < e->mb_w; mx++) {
+				const h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
+
+				if (mb->type == H264O_MB_I16x16 || (mb->cbp & 0x3f))
+					prev = e->qp_t[my * e->mb_w + mx];
+				e->qp_eff[my * e->mb_w + mx] = (uint8_t)prev;
+			}
 	}
 
 	/* in-loop deblocking of the whole picture in macroblock order */
@@ -2087,7 +2172,7 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 					bw_se(&b, mb->mvy - py);
 					bw_ue(&b, e->cbp_code_inter[mb->cbp & 0x3f]);
 					if (mb->cbp & 0x3f)
-						bw_se(&b, 0); /* mb_qp_delta */
+						bw_se(&b, qp_delta_of(e, mx, my, r0)); /* mb_qp_delta */
 					write_residual(e, &b, mb, mx, my, r0);
 				}
 				/* macroblock_layer() only: mb_skip_run belongs to slice_data() */

@@ -19,7 +19,7 @@ class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
         "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
-        "subpel", "bitrate", "strict_mb_bits", "intra_refresh")]
+        "subpel", "bitrate", "strict_mb_bits", "intra_refresh", "roi_count")] + [("roi", (ctypes.c_int * 5) * 4)]
 
 
 class MB(ctypes.Structure):
@@ -96,7 +96,13 @@ def default_config(width, height, **kw):
     c = Config()
     lib().h264o_default_config(ctypes.byref(c), width, height)
     for k, v in kw.items():
-        setattr(c, k, v)
+        if k == "roi":   # [(x, y, w, h, qp_offset), ...] in macroblocks
+            c.roi_count = len(v)
+            for i, r in enumerate(v):
+                for j in range(5):
+                    c.roi[i][j] = int(r[j])
+        else:
+            setattr(c, k, v)
     return c
 
 
@@ -139,6 +145,14 @@ class OracleEncoder:
     def frame_qp(self):
         """slice QP of the last frame (cfg.qp unless rate control is on)"""
         return lib().h264o_frame_qp(self.h)
+
+    def mb_qp(self):
+        """QP_Y the decoder holds for every macroblock of the last frame (regions of interest)"""
+        L = lib()
+        L.h264o_mb_qp.restype = ctypes.POINTER(ctypes.c_uint8)
+        L.h264o_mb_qp.argtypes = [ctypes.c_void_p]
+        n = L.h264o_mb_width(self.h) * L.h264o_mb_height(self.h)
+        return np.ctypeslib.as_array(L.h264o_mb_qp(self.h), shape=(n,)).copy()
 
     def max_mb_bits(self):
         """largest macroblock_layer() of the last frame, in bits (H.264 A.3.1 allows 3200)"""

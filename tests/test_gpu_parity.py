@@ -625,7 +625,8 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
     cases = json.load(open(os.path.join(root, "tests", "golden", "indep_decode.json")))["cases"]
     for c in cases:
         w, h, qp, keyint, frames, pattern, slices = c["case"][:7]
-        opts = {k: int(v) for k, v in (kv.split("=") for kv in c["case"][7].split(","))} if len(c["case"]) > 7 else {}
+        from tools.gen_indep_golden import case_options
+        opts = case_options(c["case"])
         sh, dec = hashlib.sha1(), rd.Decoder()
         with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, **opts) as ge:
             for f in range(frames):

@@ -179,6 +179,40 @@ def test_cyclic_intra_refresh(w, h, n, slices, subpel, pattern, keyint):
             ol.OracleEncoder(ol.default_config(w, h, intra_refresh=bad))
 
 
+@pytest.mark.parametrize("w,h,qp,roi,slices,subpel,pattern,keyint,extra", [
+    (96, 64, 30, [(1, 1, 3, 2, -8)], 1, 0, "B", 12, {}),
+    (160, 96, 28, [(0, 0, 4, 3, -6), (2, 1, 6, 4, 10), (9, 5, 1, 1, -20)], 2, 2, "B", 25, {}),
+    (112, 80, 24, [(3, 0, 2, 5, -12), (0, 2, 7, 1, 12)], 1, 1, "C", 4, dict(intra_refresh=3)),
+    (48, 48, 47, [(1, 1, 1, 1, -24)], 1, 0, "B", 30, {}), (48, 48, 5, [(0, 0, 3, 3, -24)], 1, 0, "C", 30, {})])
+def test_regions_of_interest(w, h, qp, roi, slices, subpel, pattern, keyint, extra):
+    """h264o_config.roi: the macroblocks of a region are quantised at slice QP + offset (first region wins,
+    1..51), carried by mb_qp_delta; a macroblock without one (no coded block, P_Skip) keeps its
+    predecessor's QP_Y, which is what deblocking then uses for it. Both decoders rebuild the pictures."""
+    from tests.indep import h264_refdec as rd
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, subpel=subpel, roi=roi, **extra))
+    dec, pdec = ol.OracleDecoder(), rd.Decoder()
+    mb_w, mb_h = (w + 15) // 16, (h + 15) // 16
+    want = np.full((mb_h, mb_w), qp)
+    for x, y, rw, rh, dq in reversed(roi):
+        want[y:y + rh, x:x + rw] = min(51, max(1, qp + dq))
+    for f in range(6):
+        au = oe.encode(*ol.gen_frame(pattern, w, h, f))
+        assert dec.decode(au) == 1, dec.error()
+        ry, ruv = oe.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(ry, dy) and np.array_equal(ruv, duv), f
+        pic, = pdec.decode(au)
+        assert pic.luma_bytes() == ry.tobytes() and pic.nv12_chroma_bytes() == ruv.tobytes(), f
+        mb = oe.mb_array()
+        coded = ((mb["type"] == ol.MB_I16x16) | ((mb["cbp"] & 0x3f) != 0)).reshape(mb_h, mb_w)
+        got = oe.mb_qp().reshape(mb_h, mb_w)
+        assert np.array_equal(got[coded], want[coded]), f   # a coded macroblock has the QP of its region
+    assert pdec.cover["mb_qp_delta_nonzero"] > 0
+    for bad in ([(0, 0, 0, 1, 3)], [(-1, 0, 1, 1, 3)], [(0, 0, 1, 1, 25)], [(0, 0, 1, 1, 1)] * 5):
+        with pytest.raises(Exception):
+            ol.OracleEncoder(ol.default_config(w, h, roi=bad))
+
+
 def test_fuzzed_round_trips_with_round_2_options():
     import os
     import subprocess

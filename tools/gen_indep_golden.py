@@ -23,12 +23,16 @@ CASES = [
     (16, 96, 24, 3, 6, "B", 1), (320, 240, 30, 25, 3, "B", 1), (320, 240, 24, 1, 2, "B", 4),
     (96, 64, 28, 25, 4, "B", 1, "subpel=2"), (96, 64, 28, 12, 6, "B", 1, "intra_refresh=3"),
     (112, 80, 30, 25, 5, "B", 2, "subpel=2,intra_refresh=5"), (48, 48, 20, 30, 9, "C", 1, "intra_refresh=7"),
+    (160, 96, 28, 25, 4, "B", 2, "subpel=2,roi=0:0:4:3:-6/2:1:6:4:10/9:5:1:1:-20"), (96, 64, 36, 6, 7, "C", 1, "roi=1:1:3:2:-12"),
 ]
 
 
 def case_options(case):
     """the optional 8th element as keyword arguments (the names are h264o_config's and CedarEncoder's)"""
-    return {k: int(v) for k, v in (kv.split("=") for kv in case[7].split(","))} if len(case) > 7 else {}
+    opts = {}
+    for k, v in (kv.split("=") for kv in case[7].split(",")) if len(case) > 7 else ():
+        opts[k] = [tuple(int(t) for t in r.split(":")) for r in v.split("/")] if k == "roi" else int(v)   # roi=x:y:w:h:dqp/...
+    return opts
 
 
 def encode_and_decode(case):
