@@ -252,6 +252,21 @@ DEVI int mv_bits(int d)
 	return a == 0 ? 1 : 2 * (31 - __clz(8 * a)) + 1;
 }
 
+// regions of interest: QP_Y the macroblock is quantised with (the picture's + its region's offset)
+DEVI int roi_qp(const Params &p, int mx, int my)
+{
+	return min(max(p.qp + (int)p.roi_off[my * p.mb_w + mx], 1), 51);
+}
+
+// mb_qp_delta (7.4.5): against QP_Y of the macroblock before it in decoding order (k_qp_eff), the
+// slice's at its start; 0 without regions of interest
+DEVI int mb_qp_delta(const Params &p, int mx, int my, int row0, size_t mbaddr)
+{
+	if (!p.roi_off)
+		return 0;
+	return roi_qp(p, mx, my) - ((mx == 0 && my == row0) ? p.qp : (int)p.qp_eff[mbaddr - 1]);
+}
+
 DEVI int median3(int a, int b, int c)
 {
 	int mn = a < b ? a : b, mx = a < b ? b : a;

@@ -47,6 +47,30 @@ constexpr int INTER_WAVES = 4;       // macroblocks (waves) per k_inter workgrou
 constexpr int IN_K_STREAMS = 8;     // up to this many streams pass their frame pointers as kernel arguments
 constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
+// Regions of interest (cedar_enc_config_ext.roi): macroblocks differ in QP, so nothing derived from
+// the QP can sit in Params. One row per QP_Y, built once per session: the kernels look a macroblock's
+// row up (and row[qpc] for its chroma). 64 bytes.
+struct QpRow {
+	int32_t mf[3], dv[3];       // quantiser / scaling by position class
+	int32_t qbits, qshift;      // 15 + qp / 6, qp / 6
+	int32_t lambda;
+	int32_t qpc;                // QP_C of this QP_Y (the session's chroma_qp_index_offset applied)
+	int32_t alpha, beta;        // deblocking thresholds at indexA = indexB = this QP
+	int32_t tc0[3];             // ... and tc0 for bS 1..3
+	int32_t pad;
+};
+
+// What the deblock kernel needs of one macroblock when QPs differ: thresholds of its left edge, its
+// top edge (both from the mean QP with the neighbour, 8.7.2.2) and its inner edges, luma then chroma.
+// Written by k_qp_eff once the picture is analysed (QP_Y of a macroblock without mb_qp_delta is
+// its predecessor's, 7.4.5: known only then). 32 bytes.
+struct DbRec {
+	uint8_t y[3][5];            // [left, top, inner][alpha, beta, tc0 of bS 1, 2, 3]
+	uint8_t pad0;
+	uint8_t c[3][5];
+	uint8_t pad1;
+};
+
 // What one picture-slice header contributes in front of the macroblock data.
 struct SliceHdr {
 	uint64_t bits;   // right-aligned header bits (<= 64)
@@ -85,6 +109,11 @@ struct Params {
 	uint8_t *rec_y, *rec_uv;         // reconstruction being written
 	const uint8_t *ref_y, *ref_uv;   // previous reconstruction (deblocked)
 	MbInfo *mbi;
+	// regions of interest (nullptr: every macroblock at the slice QP, all of the above holds)
+	const int8_t *roi_off;           // [n_mb] QP offset of every macroblock of the picture (same for all streams)
+	const QpRow *qtab;               // [52]
+	uint8_t *qp_eff;                 // [n_streams][n_mb] QP_Y the decoder holds for the macroblock (k_qp_eff)
+	DbRec *dbrec;                    // [n_streams][n_mb]
 	int8_t *i4modes;                 // [n_mb][16]
 	uint8_t *nnz;                    // [n_mb][24]
 	int16_t *coef;                   // [n_mb][COEF_PER_MB]
@@ -180,6 +209,7 @@ struct Launch {
 	static int intra_decide(const Params &p, void *stream);
 	static int intra_recon(const Params &p, void *stream);
 	static int inter(const Params &p, void *stream, int n_mbs); // n_mbs macroblocks: the picture, or the diagonals [stripe_s0, stripe_s1)
+	static int qp_eff(const Params &p, void *stream);           // regions of interest: QP_Y per macroblock + deblock thresholds, after the analysis
 	// 1 wave: publish prog_inter = publish_d (if >= 0), then wait until every deblock band of the
 	// previous frame has written back all macroblocks with x + 2*y < need_d (if > 0)
 	static int gate(const Params &p, void *stream, int publish_d, int need_d);

@@ -224,6 +224,34 @@ DEVI uint32_t lds_bytes4(const uint8_t *base, int off)
 // rounded mean of four byte pairs: (a + b + 1) >> 1 per byte
 DEVI uint32_t avg_bytes4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
 
+// What a macroblock's QP decides. Without regions of interest it is the picture's and sits in Params;
+// with them the macroblock's QP_Y picks a row of the session's table (and the row of its QP_C).
+struct QpSet {
+	int lambda, qbits, qshift, qbits_c, qshift_c;
+	int mf[3], dv[3], mfc[3], dvc[3];
+};
+
+DEVI QpSet qp_set(const Params &p, int mx, int my)
+{
+	QpSet q;
+	if (p.roi_off) {
+		const QpRow &y = p.qtab[roi_qp(p, mx, my)];
+		const QpRow &c = p.qtab[y.qpc];
+		q.lambda = y.lambda; q.qbits = y.qbits; q.qshift = y.qshift; q.qbits_c = c.qbits; q.qshift_c = c.qshift;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			q.mf[k] = y.mf[k]; q.dv[k] = y.dv[k]; q.mfc[k] = c.mf[k]; q.dvc[k] = c.dv[k];
+		}
+	} else {
+		q.lambda = p.lambda; q.qbits = p.qbits; q.qshift = p.qshift; q.qbits_c = p.qbits_c; q.qshift_c = p.qshift_c;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			q.mf[k] = p.mf[k]; q.dv[k] = p.dv[k]; q.mfc[k] = p.mfc[k]; q.dvc[k] = p.dvc[k];
+		}
+	}
+	return q;
+}
+
 template <int SUBPEL, bool REFRESH>
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
@@ -266,6 +294,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// macroblock is coded Intra16x16 (DC) when (x + 2*y + t) % N == 0. Its neighbours are inter, hence
 	// "not available" under constrained_intra_pred: the prediction is 128 everywhere, luma and chroma.
 	const bool refresh = REFRESH && (mx + 2 * my + p.refresh_t) % p.intra_refresh == 0; // wave-uniform
+	// everything that follows from the QP: the picture's, or this macroblock's (regions of interest)
+	const QpSet qs = qp_set(p, mx, my);
 
 	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
 	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
@@ -381,13 +411,13 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		for (int k = 0; k < 4; k++) {
 			const int dx = dx0 + k;
 			const bool ok = dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
-			cost_x[k] = ((uint32_t)(p.lambda * mv_bits(dx)) << 11 | (uint32_t)(dx + 16)) + (ok ? 0u : 0x40000000u);
+			cost_x[k] = ((uint32_t)(qs.lambda * mv_bits(dx)) << 11 | (uint32_t)(dx + 16)) + (ok ? 0u : 0x40000000u);
 		}
 #pragma unroll
 		for (int i = 0; i < 5; i++) {
 			const int dy = d0 + i - 16;
 			const bool yok = dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
-			const uint32_t key_y = ((uint32_t)(p.lambda * mv_bits(dy)) << 11) + (uint32_t)((dy + 16) * 33) + (yok ? 0u : 0x40000000u);
+			const uint32_t key_y = ((uint32_t)(qs.lambda * mv_bits(dy)) << 11) + (uint32_t)((dy + 16) * 33) + (yok ? 0u : 0x40000000u);
 			const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
 			best = min(best, ((lo & 0xffffu) << 11) + (key_y + cost_x[0]));
 			best = min(best, ((lo >> 16) << 11) + (key_y + cost_x[1]));
@@ -475,7 +505,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 				for (int hh = 0; hh < 2; hh++) {
 					const int n = 2 * pr + hh, ci = n < 4 ? n : n + 1;
 					const int vx = cx + (ci % 3 - 1) * step, vy = cy + (ci / 3 - 1) * step;
-					const uint32_t j = ((tot >> (16 * hh)) & 0xffffu) + (uint32_t)(p.lambda * (mv_bits_q(vx) + mv_bits_q(vy)));
+					const uint32_t j = ((tot >> (16 * hh)) & 0xffffu) + (uint32_t)(qs.lambda * (mv_bits_q(vx) + mv_bits_q(vy)));
 					const uint32_t k2 = (j << 4) | (uint32_t)(n + 1);
 					key = (allowed(vx, vy) && k2 < key) ? k2 : key;
 				}
@@ -497,7 +527,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		((u32x4 *)s_coef)[i] = u32x4{ 0, 0, 0, 0 };
 	WAVE_LDS_SYNC();
 
-	const int f_inter = (1 << p.qbits) / 6, f_inter_c = (1 << p.qbits_c) / ((REFRESH && refresh) ? 3 : 6);
+	const int f_inter = (1 << qs.qbits) / 6, f_inter_c = (1 << qs.qbits_c) / ((REFRESH && refresh) ? 3 : 6);
 	const int gq = lane >> 4, l = lane & 15;
 	const int pi = l >> 2, pj = l & 3;
 	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
@@ -505,10 +535,10 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	const int rpos = 4 * kv + kh;             // coefficient (raster) this lane ends up holding
 	const int pclass = (kv & 1) == (kh & 1) ? (kv & 1) : 2;
 	const int zz = zigzag_of(rpos);
-	const int mf_y = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
-	const int dv_y = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
-	const int mf_c = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
-	const int dv_c = pclass == 0 ? p.dvc[0] : pclass == 1 ? p.dvc[1] : p.dvc[2];
+	const int mf_y = pclass == 0 ? qs.mf[0] : pclass == 1 ? qs.mf[1] : qs.mf[2];
+	const int dv_y = pclass == 0 ? qs.dv[0] : pclass == 1 ? qs.dv[1] : qs.dv[2];
+	const int mf_c = pclass == 0 ? qs.mfc[0] : pclass == 1 ? qs.mfc[1] : qs.mfc[2];
+	const int dv_c = pclass == 0 ? qs.dvc[0] : pclass == 1 ? qs.dvc[1] : qs.dvc[2];
 
 	// (counts go to LDS from every lane of a block -- same value, same address, no branch -- and
 	// leave as three 8-byte stores at the end)
@@ -531,7 +561,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	if (REFRESH && refresh) {
 		// Intra16x16, prediction 128 (8.3.3 with no neighbour): the 16 DC coefficients go through the
 		// 4x4 Hadamard (8.5.10), the other 15 of a block are quantised with the intra dead zone
-		const int f_intra = (1 << p.qbits) / 3;
+		const int f_intra = (1 << qs.qbits) / 3;
 		int wl[4], dcm[16];
 #pragma unroll
 		for (int pass = 0; pass < 4; pass++) {
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 #pragma unroll
 			for (int c = 0; c < 4; c++)
 				hsum += (((SB >> (4 * k2 + r)) ^ (SB >> (4 * k1 + c))) & 1u) ? -dcm[4 * r + c] : dcm[4 * r + c];
-		const int dlev = quant1((hsum + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
+		const int dlev = quant1((hsum + 1) >> 1, qs.mf[0], 2 * f_intra, qs.qbits + 1);
 		if (lane < 16)
 			s_coef[COEF_DC16 + zigzag_of(lane)] = (int16_t)dlev;
 		int cm[16];
@@ -564,17 +594,17 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 #pragma unroll
 			for (int c = 0; c < 4; c++)
 				isum += (((SB >> (4 * k2 + r)) ^ (SB >> (4 * k1 + c))) & 1u) ? -cm[4 * r + c] : cm[4 * r + c];
-		const int ls = 16 * p.dv[0];
-		const int dcr = p.qshift >= 6 ? (isum * ls) << (p.qshift - 6) : (isum * ls + (1 << (5 - p.qshift))) >> (6 - p.qshift);
+		const int ls = 16 * qs.dv[0];
+		const int dcr = qs.qshift >= 6 ? (isum * ls) << (qs.qshift - 6) : (isum * ls + (1 << (5 - qs.qshift))) >> (6 - qs.qshift);
 		bool any_ac = false;
 #pragma unroll
 		for (int pass = 0; pass < 4; pass++) {
 			const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
 			const int x = 4 * bx + pj, y = 4 * by + pi;
-			const int level = l == 0 ? 0 : quant24(wl[pass], mf_y, f_intra, p.qbits);
+			const int level = l == 0 ? 0 : quant24(wl[pass], mf_y, f_intra, qs.qbits);
 			s_coef[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
 			const int mydc = __shfl(dcr, bx + 4 * by);
-			const int rr = idct_lanes24(l == 0 ? mydc : __mul24(level, dv_y) << p.qshift, ci, cj);
+			const int rr = idct_lanes24(l == 0 ? mydc : __mul24(level, dv_y) << qs.qshift, ci, cj);
 			s_recy[y * 16 + x] = (uint8_t)clip255(128 + rr);
 			const uint64_t bal = __ballot(level != 0);
 			s_nnz[bx + 4 * by] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
@@ -590,9 +620,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 				    : (int)predp[y * REF_STRIDE + x];
 		const int res = (int)s_cur[y * 16 + x] - pv;
 		const int w = fdct_lanes24(res, ci, cj);
-		const int level = quant24(w, mf_y, f_inter, p.qbits);
+		const int level = quant24(w, mf_y, f_inter, qs.qbits);
 		s_coef[COEF_LUMA + idx * 16 + zz] = (int16_t)level;
-		const int rr = idct_lanes24(__mul24(level, dv_y) << p.qshift, ci, cj);
+		const int rr = idct_lanes24(__mul24(level, dv_y) << qs.qshift, ci, cj);
 		s_recy[y * 16 + x] = (uint8_t)clip255(pv + rr);
 		const uint64_t bal = __ballot(level != 0);
 		s_nnz[bx + 4 * by] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
@@ -623,9 +653,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 			dcw[c][k] = __builtin_amdgcn_readlane(w, 16 * k);
-		const int level = l == 0 ? 0 : quant24(w, mf_c, f_inter_c, p.qbits_c);
+		const int level = l == 0 ? 0 : quant24(w, mf_c, f_inter_c, qs.qbits_c);
 		s_coef[COEF_CAC + (4 * c + gq) * 16 + zz] = (int16_t)level; // (entry 0 of a block is unused: lane 0 writes its 0 there)
-		cdq[c] = __mul24(level, dv_c) << p.qshift_c;
+		cdq[c] = __mul24(level, dv_c) << qs.qshift_c;
 		const uint64_t bal = __ballot(level != 0);
 		s_nnz[16 + 4 * c + gq] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 		nz_cac |= bal ? 1u : 0u;
@@ -639,7 +669,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		const int d2c = c ? dcw[1][2] : dcw[0][2], d3c = c ? dcw[1][3] : dcw[0][3];
 		const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 		const int hd = d0c + s1 * d1c + s2 * d2c + s1 * s2 * d3c;
-		lqv = quant1(hd, p.mfc[0], 2 * f_inter_c, p.qbits_c + 1);
+		lqv = quant1(hd, qs.mfc[0], 2 * f_inter_c, qs.qbits_c + 1);
 	}
 	if (lane < 8)
 		s_coef[COEF_CDC + lane] = (int16_t)lqv;
@@ -654,7 +684,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		const int x = 4 * bx + pj, y = 4 * by + pi;
 		const int s1 = (gq & 1) ? -1 : 1, s2 = (gq & 2) ? -1 : 1;
 		const int fd = lqs[4 * c] + s1 * lqs[4 * c + 1] + s2 * lqs[4 * c + 2] + s1 * s2 * lqs[4 * c + 3];
-		const int dcr = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
+		const int dcr = ((fd * qs.dvc[0] * 16) << qs.qshift_c) >> 5;
 		const int rr = idct_lanes24(l == 0 ? dcr : cdq[c], ci, cj);
 		s_recc[y * 16 + 2 * x + c] = (uint8_t)clip255(cpv[c] + rr);
 	}
@@ -687,6 +717,84 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		m.mvy = (int16_t)qy;
 		p.mbi[mbaddr] = m;
 	}
+}
+
+// ------------------------------------------------------------------------
+// k_qp_eff (regions of interest only): QP_Y of every macroblock as the decoder will hold it, and
+// from it the deblocking thresholds of the macroblock's edges. One workgroup per unit (stream x
+// slice), after the unit's analysis. A macroblock changes QP_Y only if it carries mb_qp_delta --
+// Intra16x16, or any coded block (7.3.5, 7.4.5); the others, P_Skip included, keep that of the
+// macroblock before them in decoding order (the slice's at its start): a max-scan over "index of
+// the last macroblock with an mb_qp_delta".
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_qp_eff(Params p)
+{
+	__shared__ int s_wave[16];
+	__shared__ int s_carry;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int unit = blockIdx.x, st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+	const int n = (r1 - r0) * p.mb_w;
+	const size_t base = (size_t)st * p.n_mb + (size_t)r0 * p.mb_w;
+	if (tid == 0)
+		s_carry = -1;
+	__syncthreads();
+	for (int i0 = 0; i0 < n; i0 += 1024) {
+		const int i = i0 + tid;
+		int v = -1;
+		if (i < n) {
+			const MbInfo m = p.mbi[base + i];
+			if (m.type == MB_I16x16 || (m.cbp & 0x3f))
+				v = i;
+		}
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const int o = __shfl_up(v, off);
+			if (lane >= off)
+				v = max(v, o);
+		}
+		if (lane == 63)
+			s_wave[wave] = v;
+		__syncthreads();
+		int before = s_carry;
+		for (int w = 0; w < wave; w++)
+			before = max(before, s_wave[w]);
+		v = max(v, before);
+		if (i < n) {
+			const int row = v / p.mb_w;
+			p.qp_eff[base + i] = (uint8_t)(v >= 0 ? roi_qp(p, v - row * p.mb_w, r0 + row) : p.qp);
+		}
+		__syncthreads(); // (everybody has read s_carry and s_wave; the QPs of this chunk are visible to the workgroup)
+		if (tid == 1023)
+			s_carry = v;
+		if (i < n) {
+			const int my = i / p.mb_w, mx = i - my * p.mb_w;
+			const int qc = p.qp_eff[base + i];
+			const int ql = mx > 0 ? p.qp_eff[base + i - 1] : qc, qt = my > 0 ? p.qp_eff[base + i - p.mb_w] : qc;
+			const int cc = p.qtab[qc].qpc, cl = p.qtab[ql].qpc, ct = p.qtab[qt].qpc;
+			const int qy[3] = { (ql + qc + 1) >> 1, (qt + qc + 1) >> 1, qc };
+			const int qch[3] = { (cl + cc + 1) >> 1, (ct + cc + 1) >> 1, cc };
+			DbRec r;
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				const QpRow &a = p.qtab[qy[k]], &b = p.qtab[qch[k]];
+				r.y[k][0] = (uint8_t)a.alpha; r.y[k][1] = (uint8_t)a.beta;
+				r.y[k][2] = (uint8_t)a.tc0[0]; r.y[k][3] = (uint8_t)a.tc0[1]; r.y[k][4] = (uint8_t)a.tc0[2];
+				r.c[k][0] = (uint8_t)b.alpha; r.c[k][1] = (uint8_t)b.beta;
+				r.c[k][2] = (uint8_t)b.tc0[0]; r.c[k][3] = (uint8_t)b.tc0[1]; r.c[k][4] = (uint8_t)b.tc0[2];
+			}
+			r.pad0 = r.pad1 = 0;
+			p.dbrec[base + i] = r;
+		}
+		__syncthreads();
+	}
+}
+
+int Launch::qp_eff(const Params &p, void *stream)
+{
+	hipLaunchKernelGGL(k_qp_eff, dim3(p.n_streams * p.slice_num), dim3(1024), 0, (hipStream_t)stream, p);
+	return (int)hipGetLastError();
 }
 
 int Launch::inter(const Params &p, void *stream, int n_mbs)
@@ -1084,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 		p.i4modes[mbaddr * 16 + lane] = (int8_t)best4;
 	if (lane == 0) {
 		MbInfo m;
-		m.type = (sum4 + 32 * p.lambda < (int)(best16 >> 2)) ? MB_I4x4 : MB_I16x16;
+		m.type = (sum4 + 32 * (p.roi_off ? p.qtab[roi_qp(p, mx, my)].lambda : p.lambda) < (int)(best16 >> 2)) ? MB_I4x4 : MB_I16x16;
 		m.i16_mode = (int8_t)(best16 & 3u);
 		m.chroma_mode = (int8_t)(bestc & 3u);
 		m.cbp = 0;

@@ -198,6 +198,7 @@ struct Db2GroupLds {
 	uint32_t bsv[3][16];  // per lane (= sample row): edge codes of the 4 vertical luma edges, one byte each
 	uint32_t bsh[3][16];  // per lane (= sample column): the 4 horizontal luma edges
 	uint32_t bsc[3][16];  // chroma codes: bytes 0,1 vertical edges 0,2 (lane = plane, row); bytes 2,3 horizontal 0,2 (lane = column)
+	__attribute__((aligned(16))) uint32_t ab[3][4]; // MODE 3: alpha | beta << 8 of the left edge, the same << 16 of the top edge; of the inner edges; chroma likewise
 };
 
 // Where a wave of a wavefront workgroup reports a wait that ran out, and where it looks for the
@@ -262,11 +263,13 @@ struct Db2Shared {
 extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 
 // MODE 0: a P picture of inter macroblocks; 1: an IDR picture (all intra: bS 4 on macroblock edges, 3 inside);
-// 2: a P picture with intra macroblocks in it (cyclic intra refresh): the strengths of both, per edge
+// 2: a P picture with intra macroblocks in it (cyclic intra refresh): the strengths of both, per edge;
+// 3: any picture of a session with regions of interest: as 2 (an IDR picture is the case "all intra"), and the
+//    thresholds alpha / beta / tc0 are the macroblock's own, per edge class (left, top, inner: DbRec)
 template <int MODE, int PL, int PAIRS>
 DEVI void deblock2_body(const Params &p, const int wg)
 {
-	constexpr bool IDR = MODE == 1, MIXED = MODE == 2;
+	constexpr bool IDR = MODE == 1, MIXED = MODE >= 2, QPM = MODE == 3;
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
 
 	Db2Shared<PL, PAIRS> &S = *reinterpret_cast<Db2Shared<PL, PAIRS> *>(dyn_lds);
@@ -373,6 +376,16 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				}
 				WAVE_SYNC();
 				const uint32_t wv = DO_Y ? L.bsv[slot][l] : 0u, wh = DO_Y ? L.bsh[slot][l] : 0u, wc = DO_C ? L.bsc[slot][l] : 0u;
+				// thresholds by edge class: the picture's, or this macroblock's (MODE 3)
+				int ayL = p.alpha_y, byL = p.beta_y, ayT = p.alpha_y, byT = p.beta_y, ayI = p.alpha_y, byI = p.beta_y;
+				int acL = p.alpha_c, bcL = p.beta_c, acT = p.alpha_c, bcT = p.beta_c, acI = p.alpha_c, bcI = p.beta_c;
+				if (QPM) {
+					const u32x4 abw = *(const u32x4 *)L.ab[slot];
+					ayL = abw.x & 0xff; byL = (abw.x >> 8) & 0xff; ayT = (abw.x >> 16) & 0xff; byT = abw.x >> 24;
+					ayI = abw.y & 0xff; byI = (abw.y >> 8) & 0xff;
+					acL = abw.z & 0xff; bcL = (abw.z >> 8) & 0xff; acT = (abw.z >> 16) & 0xff; bcT = abw.z >> 24;
+					acI = abw.w & 0xff; bcI = (abw.w >> 8) & 0xff;
+				}
 				const bool any_work = __any((wv | wh | wc) != 0); // codes are 0 on idle lanes
 				if (act && any_work) {
 					// ---- vertical edges: lane = sample row l ----
@@ -393,18 +406,18 @@ DEVI void deblock2_body(const Params &p, const int wg)
 							if (!IDR && !__any((wv >> (8 * e)) & 0x80u))
 								continue;
 							if (IDR && e == 0) {
-								filt_luma_s2(wv, e, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+								filt_luma_s2(wv, e, ayL, byL, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
 									     px[q], px[q + 1], px[q + 2], px[q + 3]);
 							} else if (MIXED && e == 0) { // code 0xC0 = bS 4: one of the two filters per lane
 								const uint32_t ws = strong_part(wv, 0), wn = wv ^ ws;
 								if (__any(ws))
-									filt_luma_s2(ws, e, p.alpha_y, p.beta_y, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
+									filt_luma_s2(ws, e, ayL, byL, px[q - 4], px[q - 3], px[q - 2], px[q - 1],
 										     px[q], px[q + 1], px[q + 2], px[q + 3]);
 								if (__any(wn & 0x80u))
-									filt_luma_n2(wn, e, -p.alpha_y, -p.beta_y,
+									filt_luma_n2(wn, e, -ayL, -byL,
 										     px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
 							} else {
-								filt_luma_n2(wv, e, -p.alpha_y, -p.beta_y,
+								filt_luma_n2(wv, e, e == 0 ? -ayL : -ayI, e == 0 ? -byL : -byI,
 									     px[q - 3], px[q - 2], px[q - 1], px[q], px[q + 1], px[q + 2]);
 							}
 						}
@@ -419,15 +432,15 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						int a1 = cp[-4], a0 = cp[-2], b0 = cp[0], b1 = cp[2];
 						int c1 = cp[4], c0 = cp[6], d0 = cp[8], d1 = cp[10];
 						if (IDR) {
-							filt_chroma_s2(wc, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_s2(wc, 0, -acL, -bcL, a1, a0, b0, b1);
 						} else if (MIXED) {
 							const uint32_t ws = strong_part(wc, 0);
-							filt_chroma_s2(ws, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
-							filt_chroma_n2(wc ^ ws, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_s2(ws, 0, -acL, -bcL, a1, a0, b0, b1);
+							filt_chroma_n2(wc ^ ws, 0, -acL, -bcL, a1, a0, b0, b1);
 						} else {
-							filt_chroma_n2(wc, 0, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_n2(wc, 0, -acL, -bcL, a1, a0, b0, b1);
 						}
-						filt_chroma_n2(wc, 1, -p.alpha_c, -p.beta_c, c1, c0, d0, d1);
+						filt_chroma_n2(wc, 1, -acI, -bcI, c1, c0, d0, d1);
 						cp[-2] = (uint8_t)a0;
 						cp[0] = (uint8_t)b0;
 						cp[6] = (uint8_t)c0;
@@ -490,18 +503,18 @@ DEVI void deblock2_body(const Params &p, const int wg)
 							if (!IDR && !__any((wh >> (8 * e)) & 0x80u))
 								continue;
 							if (IDR && e == 0) {
-								filt_luma_s2(wh, e, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+								filt_luma_s2(wh, e, ayT, byT, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
 									     py[q], py[q + 1], py[q + 2], py[q + 3]);
 							} else if (MIXED && e == 0) {
 								const uint32_t ws = strong_part(wh, 0), wn = wh ^ ws;
 								if (__any(ws))
-									filt_luma_s2(ws, e, p.alpha_y, p.beta_y, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
+									filt_luma_s2(ws, e, ayT, byT, py[q - 4], py[q - 3], py[q - 2], py[q - 1],
 										     py[q], py[q + 1], py[q + 2], py[q + 3]);
 								if (__any(wn & 0x80u))
-									filt_luma_n2(wn, e, -p.alpha_y, -p.beta_y,
+									filt_luma_n2(wn, e, -ayT, -byT,
 										     py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
 							} else {
-								filt_luma_n2(wh, e, -p.alpha_y, -p.beta_y,
+								filt_luma_n2(wh, e, e == 0 ? -ayT : -ayI, e == 0 ? -byT : -byI,
 									     py[q - 3], py[q - 2], py[q - 1], py[q], py[q + 1], py[q + 2]);
 							}
 						}
@@ -514,15 +527,15 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						int a1 = cp[0], a0 = cp[DC_STRIDE], b0 = cp[2 * DC_STRIDE], b1 = cp[3 * DC_STRIDE];
 						int c1 = cp[4 * DC_STRIDE], c0 = cp[5 * DC_STRIDE], d0 = cp[6 * DC_STRIDE], d1 = cp[7 * DC_STRIDE];
 						if (IDR) {
-							filt_chroma_s2(wc, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_s2(wc, 2, -acT, -bcT, a1, a0, b0, b1);
 						} else if (MIXED) {
 							const uint32_t ws = strong_part(wc, 2);
-							filt_chroma_s2(ws, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
-							filt_chroma_n2(wc ^ ws, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_s2(ws, 2, -acT, -bcT, a1, a0, b0, b1);
+							filt_chroma_n2(wc ^ ws, 2, -acT, -bcT, a1, a0, b0, b1);
 						} else {
-							filt_chroma_n2(wc, 2, -p.alpha_c, -p.beta_c, a1, a0, b0, b1);
+							filt_chroma_n2(wc, 2, -acT, -bcT, a1, a0, b0, b1);
 						}
-						filt_chroma_n2(wc, 3, -p.alpha_c, -p.beta_c, c1, c0, d0, d1);
+						filt_chroma_n2(wc, 3, -acI, -bcI, c1, c0, d0, d1);
 						cp[DC_STRIDE] = (uint8_t)a0;
 						cp[2 * DC_STRIDE] = (uint8_t)b0;
 						cp[5 * DC_STRIDE] = (uint8_t)c0;
@@ -626,6 +639,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			uint64_t topx;
 			uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
 			uint32_t ty, tyt; // MIXED: its first dword (type in the low byte)
+			u32x4 rec0, rec1; // MODE 3: the macroblock's DbRec
 			uint8_t nz, nzt;
 			bool top_ok;
 		};
@@ -668,6 +682,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					R.ty = ((const uint32_t *)&p.mbi[a])[0];
 					R.tyt = ((const uint32_t *)&p.mbi[at])[0];
 				}
+				if (QPM) {
+					R.rec0 = ((const u32x4 *)&p.dbrec[a])[0];
+					R.rec1 = ((const u32x4 *)&p.dbrec[a])[1];
+				}
 			}
 			if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
 				R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
@@ -705,6 +723,19 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					wh = in_y | (top_edge ? 0x80u : 0u);
 					wc = (left_edge ? 0x80u : 0u) | in_c << 8 | (top_edge ? 0x80u : 0u) << 16 | in_c << 24;
 				} else {
+					// edge code by strength for the macroblock's left edge, top edge, inner edges (MODE 3: its own tc0)
+					uint32_t cyL = cod_y, cyT = cod_y, cyI = cod_y, ccL = cod_c, ccT = cod_c, ccI = cod_c;
+					if (QPM) {
+						const uint32_t r0w[4] = { R.rec0.x, R.rec0.y, R.rec0.z, R.rec0.w }, r1w[4] = { R.rec1.x, R.rec1.y, R.rec1.z, R.rec1.w };
+						auto yb = [&](int i) { return (r0w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+						auto cb = [&](int i) { return (r1w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+						auto code3 = [](uint32_t t1, uint32_t t2, uint32_t t3) { return (0x80u | t1) << 8 | (0x80u | t2) << 16 | (0x80u | t3) << 24; };
+						cyL = code3(yb(2), yb(3), yb(4)); cyT = code3(yb(7), yb(8), yb(9)); cyI = code3(yb(12), yb(13), yb(14));
+						ccL = code3(cb(2), cb(3), cb(4)); ccT = code3(cb(7), cb(8), cb(9)); ccI = code3(cb(12), cb(13), cb(14));
+						if (l == 0)
+							*(u32x4 *)L.ab[slot] = u32x4{ yb(0) | yb(1) << 8 | yb(5) << 16 | yb(6) << 24, yb(10) | yb(11) << 8,
+										      cb(0) | cb(1) << 8 | cb(5) << 16 | cb(6) << 24, cb(10) | cb(11) << 8 };
+					}
 					const int k = l >> 2, ks = (l & 7) >> 1;
 					int bv[4], bh[4];
 					// vectors are in quarter samples: bS 1 from a difference of a whole sample on (8.7.2.1)
@@ -724,15 +755,15 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					// boundary strength -> edge code byte (0x80 | tc0, 0 = leave the edge alone)
 #pragma unroll
 					for (int e = 0; e < 4; e++) {
-						wv |= ((cod_y >> (8 * bv[e])) & 0xffu) << (8 * e);
-						wh |= ((cod_y >> (8 * bh[e])) & 0xffu) << (8 * e);
+						wv |= (((e == 0 ? cyL : cyI) >> (8 * bv[e])) & 0xffu) << (8 * e);
+						wh |= (((e == 0 ? cyT : cyI) >> (8 * bh[e])) & 0xffu) << (8 * e);
 					}
-					wc = ((cod_c >> (8 * bsc0)) & 0xffu) | ((cod_c >> (8 * bsc2)) & 0xffu) << 8 |
-					     ((cod_c >> (8 * bh[0])) & 0xffu) << 16 | ((cod_c >> (8 * bh[2])) & 0xffu) << 24;
+					wc = ((ccL >> (8 * bsc0)) & 0xffu) | ((ccI >> (8 * bsc2)) & 0xffu) << 8 |
+					     ((ccT >> (8 * bh[0])) & 0xffu) << 16 | ((ccI >> (8 * bh[2])) & 0xffu) << 24;
 					if (MIXED) { // an intra macroblock on either side: bS 4 on the macroblock edge (code 0xC0), 3 inside
 						const bool ic = (int)(int8_t)(R.ty & 0xffu) < MB_P16x16, it = (int)(int8_t)(R.tyt & 0xffu) < MB_P16x16;
 						if (ic) {
-							const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
+							const uint32_t in_y = (cyI >> 24) * 0x01010100u, in_c = ccI >> 24;
 							wv = (wv & 0xffu) | in_y;
 							wh = (wh & 0xffu) | in_y;
 							wc = (wc & 0x00ff00ffu) | in_c << 8 | in_c << 24;
@@ -909,6 +940,7 @@ struct __attribute__((aligned(16))) Ir2GroupLds {
 	uint8_t topy[3][32];        // group 0 only, laid out as tile row 0: [7] x=-1, [8..23], [24..27] x=16..19
 	uint8_t topc[3][32];        // [6..7] pair x=-1, [8..23]
 	uint32_t info[3][4];        // [0..1] MbInfo, [2..3] the 16 Intra4x4 modes, one nibble each
+	uint32_t qpw[4];            // regions of interest: QP_Y of the macroblock, ring by step
 	int cbp_y[3], cbp_yb[3], cbp_c[3]; // luma bits found by the luma wave / by the chroma wave, chroma bits
 	int dc[16], dcl[16], cdc[8], cdl[8];
 };
@@ -975,8 +1007,10 @@ DEVI int i4_block(const uint32_t *ptab, const I4Ctx &c, const LaneK &ci, const L
 	return (c.is4 && nn) ? (1 << (idx >> 2)) : 0;
 }
 
+template <bool ROI>
 __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 {
+	__shared__ QpRow s_qtab[ROI ? 52 : 1]; // regions of interest: the session's table of everything a QP decides
 	__shared__ Ir2GroupLds s_g[IR_TRIPLES * 4];
 	// last reconstructed row of every band's bottom macroblock row, for the triple that does the
 	// band below (dynamic LDS: 2 x IR_TRIPLES rows of mb_w * 16 + 32 bytes; the rest of the
@@ -1051,7 +1085,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
-	const int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
+	int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
 	const int nbands = (r1 - r0 + 3) >> 2;
 	const int b_lo = nbands * wj / NWG, b_hi = nbands * (wj + 1) / NWG;
 	const int nsteps = p.mb_w + 6;
@@ -1066,10 +1100,19 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	for (int z = 0; z < 16; z++)
 		zz = kZigzag[z] == rpos ? z : zz;
 	const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
-	const int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
-	const int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
-	const int my_mfc = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
-	const int my_dvc = pclass == 0 ? p.dvc[0] : pclass == 1 ? p.dvc[1] : p.dvc[2];
+	int my_mf = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
+	int my_dv = pclass == 0 ? p.dv[0] : pclass == 1 ? p.dv[1] : p.dv[2];
+	int my_mfc = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
+	int my_dvc = pclass == 0 ? p.dvc[0] : pclass == 1 ? p.dvc[1] : p.dvc[2];
+	// what the QP decides: the picture's (Params), or -- regions of interest -- the macroblock's, looked up
+	// at the start of every step from the QP the mover staged with the macroblock
+	int q_mf[3] = { p.mf[0], p.mf[1], p.mf[2] }, q_dv[3] = { p.dv[0], p.dv[1], p.dv[2] };
+	int q_qbits = p.qbits, q_qshift = p.qshift, q_qbits_c = p.qbits_c, q_qshift_c = p.qshift_c, q_mfc0 = p.mfc[0], q_dvc0 = p.dvc[0];
+	if (ROI) {
+		for (int i = threadIdx.x; i < 52 * (int)(sizeof(QpRow) / 4); i += blockDim.x)
+			((uint32_t *)s_qtab)[i] = ((const uint32_t *)p.qtab)[i];
+		__syncthreads();
+	}
 
 	int iter = 0;
 	for (int band = b_lo + trip; band < b_hi; band += IR_TRIPLES, iter++) {
@@ -1087,6 +1130,21 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		const int trip_up = (rel + IR_TRIPLES - 1) % IR_TRIPLES, base_up = ((rel - 1) / IR_TRIPLES) * (nsteps + 2);
 		uint8_t *const rowy_mine = s_rows + (size_t)(2 * trip) * row_bytes, *const rowc_mine = rowy_mine + row_bytes;
 		const uint8_t *const rowy_up = s_rows + (size_t)(2 * trip_up) * row_bytes, *const rowc_up = rowy_up + row_bytes;
+		auto load_q = [&](int slot) { // the macroblock's QP, staged by the mover, picks the rows
+			if (!ROI)
+				return;
+			const QpRow &Y = s_qtab[L.qpw[slot] & 63u];
+			const QpRow &C = s_qtab[Y.qpc];
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				q_mf[k] = Y.mf[k];
+				q_dv[k] = Y.dv[k];
+			}
+			q_qbits = Y.qbits; q_qshift = Y.qshift; q_qbits_c = C.qbits; q_qshift_c = C.qshift; q_mfc0 = C.mf[0]; q_dvc0 = C.dv[0];
+			my_mf = Y.mf[pclass]; my_dv = Y.dv[pclass]; my_mfc = C.mf[pclass]; my_dvc = C.dv[pclass];
+			f_intra = (1 << q_qbits) / 3;
+			f_intra_c = (1 << q_qbits_c) / 3;
+		};
 
 		if (role == 0) {
 			// ============================ luma wave ============================
@@ -1097,6 +1155,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				const int slot = t % 3;
 				const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
 				lds_wait_ge(&s_staged[trip], base + t + 1, xw);
+				load_q(slot);
 				const uint32_t miw = L.info[slot][0];
 				const uint64_t modes64 = (uint64_t)L.info[slot][2] | (uint64_t)L.info[slot][3] << 32;
 				const int mb_type = (int)(int8_t)(miw & 0xff), i16_mode = (int)((miw >> 8) & 0xff);
@@ -1151,7 +1210,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 						cf[COEF_DC16 + l] = 0;
 					const int key = (base + t) * 16;
 					const I4Ctx cx{ L.t, SY, cf_lane, nnz_mb, modes64, top_mb, left_mb, tr_mb, is4, g, l, pi, pj, zz,
-							my_mf, my_dv, f_intra, p.qbits, p.qshift };
+							my_mf, my_dv, f_intra, q_qbits, q_qshift };
 					uint32_t tab = i4_tab(s_ptab, cx, 0);
 					cbp |= i4_block(s_ptab, cx, ci, cj, 0, 1, tab);
 					cbp |= i4_block(s_ptab, cx, ci, cj, 1, 2, tab);
@@ -1212,10 +1271,10 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 #pragma unroll
 						for (int i = 1; i < 16; i++) {
 							const int r = kZigzag[i], c = kPosClass[r];
-							const int lq = quant1(w[r], p.mf[c], f_intra, p.qbits);
+							const int lq = quant1(w[r], q_mf[c], f_intra, q_qbits);
 							cf[COEF_LUMA + l * 16 + i] = (int16_t)lq;
 							nn += lq != 0;
-							d[r] = (lq * p.dv[c]) << p.qshift;
+							d[r] = (lq * q_dv[c]) << q_qshift;
 						}
 					}
 					WAVE_SYNC();
@@ -1227,7 +1286,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 #pragma unroll
 							for (int b = 0; b < 4; b++)
 								s += hsign(i, a) * hsign(j, b) * L.dc[4 * a + b];
-						L.dcl[l] = quant1((s + 1) >> 1, p.mf[0], 2 * f_intra, p.qbits + 1);
+						L.dcl[l] = quant1((s + 1) >> 1, q_mf[0], 2 * f_intra, q_qbits + 1);
 					}
 					WAVE_SYNC();
 					if (is16) {
@@ -1238,8 +1297,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 #pragma unroll
 							for (int b = 0; b < 4; b++)
 								s += hsign(by, a) * hsign(bx, b) * L.dcl[4 * a + b];
-						const int ls = 16 * p.dv[0];
-						d[0] = p.qp >= 36 ? (s * ls) << (p.qshift - 6) : (s * ls + (1 << (5 - p.qshift))) >> (6 - p.qshift);
+						const int ls = 16 * q_dv[0];
+						d[0] = q_qshift >= 6 ? (s * ls) << (q_qshift - 6) : (s * ls + (1 << (5 - q_qshift))) >> (6 - q_qshift);
 						int pred[16], out[16];
 #pragma unroll
 						for (int i = 0; i < 16; i++)
@@ -1282,6 +1341,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				const int slot = t % 3;
 				const size_t mbaddr = (size_t)st * p.n_mb + (size_t)(act ? my : r0) * p.mb_w + (act ? mx : 0);
 				lds_wait_ge(&s_staged[trip], base + t + 1, xw);
+				load_q(slot);
 				const int chroma_mode = (int)((L.info[slot][0] >> 16) & 0xff);
 				const uint8_t *SC = L.srcc[slot];
 				if (in_top && t < p.mb_w) // only the macroblock above is needed here, but the luma wave's bound is as good
@@ -1311,7 +1371,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 						const int key = (base + t) * 16;
 						const I4Ctx cx{ L.t, L.srcy[slot], p.coef + mbaddr * COEF_PER_MB + COEF_LUMA + zz, p.nnz + mbaddr * NNZ_PER_MB,
 								modes64, top_mb, left_mb, tr_mb, is4, g, l, pi, pj, zz,
-								my_mf, my_dv, f_intra, p.qbits, p.qshift };
+								my_mf, my_dv, f_intra, q_qbits, q_qshift };
 						uint32_t tab = i4_tab(s_ptab, cx, 4);
 						lds_wait_ge(&s_i4a[trip], key + 2, xw); // tile neighbours set up, blocks 0, 1
 						cbp_b |= i4_block(s_ptab, cx, ci, cj, 4, 5, tab);
@@ -1376,10 +1436,10 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const int w = fdct_lanes(res, ci, cj);
 					if (act && l == 0)
 						L.cdc[4 * c + blk] = w; // lane (0,0) holds the DC coefficient
-					const int level = l == 0 ? 0 : quant1(w, my_mfc, f_intra_c, p.qbits_c);
+					const int level = l == 0 ? 0 : quant1(w, my_mfc, f_intra_c, q_qbits_c);
 					if (act)
 						cf[COEF_CAC + (4 * c + blk) * 16 + zz] = (int16_t)level;
-					cdq[it] = (level * my_dvc) << p.qshift_c;
+					cdq[it] = (level * my_dvc) << q_qshift_c;
 					pvs[it] = pv;
 					const uint64_t bal = __ballot(act && level != 0);
 					const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
@@ -1394,7 +1454,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const int *dcs = L.cdc + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
-					const int lq = quant1(hd, p.mfc[0], 2 * f_intra_c, p.qbits_c + 1);
+					const int lq = quant1(hd, q_mfc0, 2 * f_intra_c, q_qbits_c + 1);
 					L.cdl[l] = lq;
 					cf[COEF_CDC + l] = (int16_t)lq;
 					cdcnz = lq != 0;
@@ -1407,7 +1467,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const int *ls = L.cdl + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
-					const int dcr = ((fd * p.dvc[0] * 16) << p.qshift_c) >> 5;
+					const int dcr = ((fd * q_dvc0 * 16) << q_qshift_c) >> 5;
 					const int r = idct_lanes(l == 0 ? dcr : cdq[it], ci, cj);
 					if (act)
 						L.c[(1 + y) * IC_STRIDE + 8 + 2 * x + c] = (uint8_t)clip255(pvs[it] + r);
@@ -1436,6 +1496,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		struct MoverRegs {
 			u32x4 sy, sc, modes;
 			uint64_t mi, ta, tb;
+			int qoff; // regions of interest: the macroblock's QP offset
 			bool top_ok;
 		};
 		MoverRegs RA{}, RB{};
@@ -1462,6 +1523,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			R.sc = *(const u32x4 *)(src_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
 			R.mi = *(const uint64_t *)&p.mbi[a];
 			R.modes = *(const u32x4 *)(p.i4modes + a * 16);
+			if (ROI)
+				R.qoff = (int)p.roi_off[cmy * p.mb_w + cmx];
 			R.ta = R.tb = 0;
 			if (g == 0 && top_mb && nact && R.top_ok && !in_top) {
 				if (xwg_top) { // the other workgroup's write-through buffer
@@ -1512,6 +1575,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				for (int k = 0; k < 16; k++)
 					modes64 |= (uint64_t)((mw[k >> 2] >> (8 * (k & 3))) & 15u) << (4 * k);
 				*(u32x4 *)L.info[slot] = u32x4{ (uint32_t)R.mi, (uint32_t)(R.mi >> 32), (uint32_t)modes64, (uint32_t)(modes64 >> 32) };
+				if (ROI)
+					L.qpw[slot] = (uint32_t)min(max(p.qp + R.qoff, 1), 51);
 			}
 			if (g == 0 && top_mb && !in_top) {
 				if (xwg_top) {
@@ -1630,16 +1695,20 @@ static int launch_deblock(const Params &p, hipStream_t s, int planes)
 	const int nwg = p.n_streams * p.slice_num * p.wf_split;
 	// 8 pairs: ~130 KiB of dynamic LDS, one workgroup per CU by construction; 2 pairs: ~33 KiB
 	const size_t lds = sizeof(Db2Shared<1, PAIRS>) > sizeof(Db2Shared<3, PAIRS>) ? sizeof(Db2Shared<1, PAIRS>) : sizeof(Db2Shared<3, PAIRS>);
+	static_assert(sizeof(Db2Shared<1, PAIRS>) <= 160 * 1024 && sizeof(Db2Shared<3, PAIRS>) <= 160 * 1024, "a CU has 160 KiB of LDS");
 	static bool attr_set = false;
 	if (!attr_set) {
 		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
 		    hipFuncSetAttribute((const void *)k_deblock2_planes<1, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<3, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
 			return -1;
 		attr_set = true;
 	}
 	dim3 grid(planes == 4 ? 2 * nwg : nwg);
-	if (p.is_idr)
+	if (p.roi_off) // regions of interest: thresholds per macroblock; an IDR picture is "every macroblock intra" there
+		hipLaunchKernelGGL((k_deblock2_planes<3, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
+	else if (p.is_idr)
 		hipLaunchKernelGGL((k_deblock2_planes<1, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
 	else if (p.intra_refresh > 0) // intra macroblocks among the inter ones: both sets of boundary strengths
 		hipLaunchKernelGGL((k_deblock2_planes<2, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
@@ -1660,7 +1729,10 @@ int Launch::intra_recon(const Params &p, void *stream)
 	// two of them can never share one CU (160 KiB per CU)
 	// dynamic LDS: the band-to-band row buffers, padded so that two workgroups never share a CU
 	const size_t rows = (size_t)2 * IR_TRIPLES * (p.mb_w * 16 + 32);
-	hipLaunchKernelGGL(k_intra_recon2, grid, dim3(64 * 3 * IR_TRIPLES), rows > 64 * 1024 ? rows : 64 * 1024, (hipStream_t)stream, p);
+	if (p.roi_off)
+		hipLaunchKernelGGL(k_intra_recon2<true>, grid, dim3(64 * 3 * IR_TRIPLES), rows > 64 * 1024 ? rows : 64 * 1024, (hipStream_t)stream, p);
+	else
+		hipLaunchKernelGGL(k_intra_recon2<false>, grid, dim3(64 * 3 * IR_TRIPLES), rows > 64 * 1024 ? rows : 64 * 1024, (hipStream_t)stream, p);
 	return (int)hipGetLastError();
 }
 

@@ -236,6 +236,11 @@ struct cedar_enc {
 	// frames that have been collected (written by frame n - nrec, searched by frame n - nrec + 1)
 	uint8_t *d_rec_y[CEDAR_ENC_PIPELINE_DEPTH + 1] = {}, *d_rec_uv[CEDAR_ENC_PIPELINE_DEPTH + 1] = {};
 	MbInfo *d_mbi[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	// regions of interest
+	int8_t *d_roi_off = nullptr;
+	QpRow *d_qtab = nullptr;
+	uint8_t *d_qp_eff[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	DbRec *d_dbrec[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int8_t *d_i4[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint8_t *d_nnz[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int16_t *d_coef[CEDAR_ENC_PIPELINE_DEPTH] = {};
@@ -343,11 +348,13 @@ void free_all(cedar_enc *e)
 	auto F = [](void *p) { if (p) hipFree(p); };
 	auto H = [](void *p) { if (p) hipHostFree(p); };
 	F(e->d_in_y); F(e->d_in_uv); F((void *)e->d_in_ptrs);
+	F(e->d_roi_off); F(e->d_qtab);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH + 1; i++) {
 		F(e->d_rec_y[i]); F(e->d_rec_uv[i]);
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
+		F(e->d_qp_eff[i]); F(e->d_dbrec[i]);
 		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
 	for (int l = 0; l < ENT_LANES; l++) {
@@ -840,6 +847,11 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "subpel %d outside 0..2", ext.subpel);
 	if (ext.intra_refresh < 0 || (ext.intra_refresh > 0 && ext.intra_refresh < 3) || ext.intra_refresh > 65535)
 		return fail(e, -EINVAL, "intra_refresh %d: 0 (off) or 3..65535", ext.intra_refresh);
+	if (ext.roi_count < 0 || ext.roi_count > 4)
+		return fail(e, -EINVAL, "roi_count %d outside 0..4", ext.roi_count);
+	for (int k = 0; k < ext.roi_count; k++)
+		if (ext.roi[k][0] < 0 || ext.roi[k][1] < 0 || ext.roi[k][2] <= 0 || ext.roi[k][3] <= 0 || ext.roi[k][4] < -24 || ext.roi[k][4] > 24)
+			return fail(e, -EINVAL, "region of interest %d: x, y >= 0, width, height > 0 (macroblocks), QP offset -24..24", k);
 	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
@@ -931,6 +943,47 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if ((rc = dalloc(e, &e->d_i4[i], ((size_t)P.n_mb * S + 1) * 16))) return rc;
 		if ((rc = dalloc(e, &e->d_nnz[i], ((size_t)P.n_mb * S + 1) * NNZ_PER_MB))) return rc;
 		if ((rc = dalloc(e, &e->d_coef[i], ((size_t)P.n_mb * S + 1) * COEF_PER_MB))) return rc;
+		if (ext.roi_count > 0) {
+			if ((rc = dalloc(e, &e->d_qp_eff[i], (size_t)P.n_mb * S))) return rc;
+			if ((rc = dalloc(e, &e->d_dbrec[i], (size_t)P.n_mb * S))) return rc;
+		}
+	}
+	if (ext.roi_count > 0) {
+		// the offset of every macroblock (the first region that covers it), and one row of derived
+		// parameters per QP_Y
+		std::vector<int8_t> off((size_t)P.n_mb, 0);
+		for (int my = 0; my < P.mb_h; my++)
+			for (int mx = 0; mx < P.mb_w; mx++)
+				for (int k = 0; k < ext.roi_count; k++) {
+					const int *r = ext.roi[k];
+					if (mx >= r[0] && mx < r[0] + r[2] && my >= r[1] && my < r[1] + r[3]) {
+						off[(size_t)my * P.mb_w + mx] = (int8_t)r[4];
+						break;
+					}
+				}
+		std::vector<QpRow> rows(52);
+		for (int q = 0; q < 52; q++) {
+			QpRow &r = rows[q];
+			const int qi = q + e->chroma_qp_offset;
+			for (int k = 0; k < 3; k++) {
+				r.mf[k] = kQuantMF[q % 6][k];
+				r.dv[k] = kDequantV[q % 6][k];
+				r.tc0[k] = kTc0[q][k];
+			}
+			r.qbits = 15 + q / 6;
+			r.qshift = q / 6;
+			r.lambda = lambda_of_qp(q);
+			r.qpc = kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi];
+			r.alpha = kAlpha[q];
+			r.beta = kBeta[q];
+			r.pad = 0;
+		}
+		if ((rc = dalloc(e, &e->d_roi_off, (size_t)P.n_mb))) return rc;
+		if ((rc = dalloc(e, &e->d_qtab, (size_t)52))) return rc;
+		HIP_TRY(e, hipMemcpy(e->d_roi_off, off.data(), off.size(), hipMemcpyHostToDevice));
+		HIP_TRY(e, hipMemcpy(e->d_qtab, rows.data(), rows.size() * sizeof(QpRow), hipMemcpyHostToDevice));
+		P.roi_off = e->d_roi_off;
+		P.qtab = e->d_qtab;
 	}
 	{
 		// A second entropy lane (frames alternating between two streams with scratch of their own)
@@ -1085,6 +1138,10 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// 2x3 15.8, 3x3 15.9, 1x3 12: the leanest set that overlaps two deblock kernels wins
 		const int db_max = envd ? atoi(envd) : 2;
 		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * db_max <= cus / 2;
+		// regions of interest: QP_Y of a macroblock without coded blocks is its predecessor's in decoding
+		// order, and deblocking wants it -- a pass over the analysed picture between the two
+		if (ext.roi_count > 0)
+			want = false;
 		if (want && !e->holds_pipe_token) {
 			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
 				e->holds_pipe_token = true;
@@ -1421,6 +1478,10 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	Q.ref_y += (size_t)s0 * P.plane_y_stride;
 	Q.ref_uv += (size_t)s0 * P.plane_uv_stride;
 	Q.mbi += m0;
+	if (Q.qp_eff) {
+		Q.qp_eff += m0;
+		Q.dbrec += m0;
+	}
 	Q.i4modes += m0 * 16;
 	Q.nnz += m0 * NNZ_PER_MB;
 	Q.coef += m0 * COEF_PER_MB;
@@ -1498,6 +1559,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.src_y = e->d_src_y[ds];
 	P.src_uv = e->d_src_uv[ds];
 	P.mbi = e->d_mbi[ds];
+	P.qp_eff = e->d_qp_eff[ds];
+	P.dbrec = e->d_dbrec[ds];
 	P.i4modes = e->d_i4[ds];
 	P.nnz = e->d_nnz[ds];
 	P.coef = e->d_coef[ds];
@@ -1764,6 +1827,9 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			if (c == C - 1)
 				tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
 		}
+		// regions of interest: QP_Y as the decoder will hold it + the deblock thresholds of every edge
+		if (Pc.roi_off && Launch::qp_eff(Pc, s_ana))
+			return fail(e, -EIO, "k_qp_eff launch failed");
 		HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
 		t_main = now_ms();
 

@@ -65,6 +65,21 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	ext.bitrate = env_int("H264ENC_BITRATE", 0);
 	ext.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
+	if (getenv("H264ENC_ROI")) { /* "x,y,w,h,dqp;..." in macroblocks, up to 4 regions */
+		const char *r = getenv("H264ENC_ROI");
+
+		while (*r && ext.roi_count < 4) {
+			int *v = ext.roi[ext.roi_count];
+
+			if (sscanf(r, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5)
+				break;
+			ext.roi_count++;
+			r = strchr(r, ';');
+			if (!r)
+				break;
+			r++;
+		}
+	}
 	ext.subpel = env_int("H264ENC_SUBPEL", 0);
 
 	ret = cedar_enc_config_ext(cedar, &config, &ext);

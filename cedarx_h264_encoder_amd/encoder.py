@@ -42,7 +42,7 @@ class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh")]
+        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "roi_count")] + [("roi", (ctypes.c_int * 5) * 4)]
 
 
 class _Stats(ctypes.Structure):
@@ -171,6 +171,7 @@ class EncoderConfig:
     gop_low_latency: int = 0    # gop_parallel: 1 = half the latency, every group's IDR step exposed
     bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
     intra_refresh: int = 0      # N >= 3: macroblocks with (x + 2*y + t) % N == 0 of the t-th P picture are coded intra
+    roi: tuple = ()             # up to 4 regions of interest: (x, y, width, height in macroblocks, QP offset)
 
 
 class CedarEncoder:
@@ -201,6 +202,12 @@ class CedarEncoder:
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
                   "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh"):
             setattr(x, n, getattr(cfg, n))
+        if len(cfg.roi) > 4:
+            raise EncoderError(22, "at most 4 regions of interest")
+        x.roi_count = len(cfg.roi)
+        for i, r in enumerate(cfg.roi):
+            for j in range(5):
+                x.roi[i][j] = int(r[j])
         r = self._L.cedar_enc_config_ext(self._h, ctypes.byref(c), ctypes.byref(x))
         self._check(r, "CEDAR_IOCTL_CONFIG")
         self.cfg = cfg

@@ -138,6 +138,15 @@ struct cedar_enc_config_ext {
 				constrained_intra_pred_flag = 1 (a refresh macroblock must not lean on inter
 				samples, or it would refresh nothing). 0 (default): off, PPS as the
 				reference's (cedar.c:976)                                                  */
+	int roi_count;       /* 0..4 regions of interest: the VE has four plus their QP offsets
+				(cedar_regs.h:76-80 ROI_QP_OFFSET, ROI_0..3_AREA) that the reference never
+				programs                                                   */
+	int roi[4][5];       /* x, y, width, height in macroblocks and the QP offset (-24..24) of the
+				macroblocks inside; where regions overlap the first counts. A macroblock's QP
+				= the picture's (qp, or what rate control / requantising make of it) + offset,
+				clipped to 1..51, carried by mb_qp_delta. Frames of such a session run back
+				to back (a macroblock without coded blocks inherits QP_Y from its predecessor
+				in decoding order, which deblocking needs: known once the picture is analysed) */
 };
 
 typedef struct cedar_enc cedar_enc;

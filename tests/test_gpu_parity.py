@@ -4,6 +4,7 @@ identical Annex-B bytes, identical per-macroblock decisions/levels and
 identical deblocked reconstruction. All tests here need an MI355X."""
 import errno
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -625,7 +626,8 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
     cases = json.load(open(os.path.join(root, "tests", "golden", "indep_decode.json")))["cases"]
     for c in cases:
         w, h, qp, keyint, frames, pattern, slices = c["case"][:7]
-        from tools.gen_indep_golden import case_options
+        sys.path.insert(0, os.path.join(root, "tools"))
+        from gen_indep_golden import case_options
         opts = case_options(c["case"])
         sh, dec = hashlib.sha1(), rd.Decoder()
         with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, **opts) as ge:
@@ -1027,7 +1029,67 @@ def test_cyclic_intra_refresh_equals_the_oracle(ce, w, h, qp, n, keyint, slices,
             ce.CedarEncoder(width=w, height=h, intra_refresh=bad)
 
 
-@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2", "refresh"])
+@pytest.mark.parametrize("w,h,qp,roi,keyint,slices,subpel,streams,frames,extra", [
+    (96, 64, 30, [(1, 1, 3, 2, -8)], 12, 1, 0, 1, 6, {}),
+    (320, 240, 28, [(0, 0, 4, 3, -6), (2, 1, 6, 4, 10), (19, 14, 1, 1, -20)], 25, 3, 2, 1, 6, {}),
+    (112, 80, 24, [(3, 0, 2, 5, -12), (0, 2, 7, 1, 12)], 4, 1, 1, 2, 7, dict(intra_refresh=3)),
+    (48, 48, 47, [(1, 1, 1, 1, -24)], 30, 1, 0, 1, 5, {}), (48, 48, 5, [(0, 0, 3, 3, -24)], 30, 1, 0, 1, 4, {}),
+    (640, 368, 26, [(10, 5, 20, 12, -10), (0, 0, 40, 23, 6)], 25, 1, 2, 1, 4, {}),
+    (1920, 1080, 30, [(40, 20, 40, 30, -8), (0, 60, 120, 8, 12)], 25, 1, 0, 1, 3, {}),
+    (160, 96, 30, [(2, 1, 5, 3, -9)], 5, 2, 0, 3, 8, dict(gop_parallel=2))])
+def test_regions_of_interest_equal_the_oracle(ce, w, h, qp, roi, keyint, slices, subpel, streams, frames, extra):
+    """roi: macroblocks of a region are quantised at the picture's QP + the region's offset. Every kernel that
+    derives something from the QP looks it up per macroblock (k_intra_decide, k_intra_recon2<ROI>, k_inter),
+    k_qp_eff scans QP_Y as the decoder will hold it (a macroblock without coded blocks inherits) and lays down
+    the deblocking thresholds per edge, deblock mode 3 filters with them, CAVLC writes mb_qp_delta.
+    Records, levels, reconstruction and bytes equal the scalar twin's; the independent decoder agrees."""
+    from tests.indep import h264_refdec as rd
+    G = extra.get("gop_parallel", 0)
+    okw = {k: v for k, v in extra.items() if k != "gop_parallel"}
+    src = [[ol.gen_frame("BC"[s & 1], w, h, f, s << 8) for s in range(streams)] for f in range(frames)]
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, subpel=subpel, roi=roi, **okw))
+           for _ in range(streams)]
+    want = [[oes[s].encode(*src[f][s]) for f in range(frames)] for s in range(streams)]
+    if G:
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, subpel=subpel,
+                             n_streams=streams, roi=tuple(roi), **extra) as ge:
+            got = _encode_gop_parallel(ge, [[src[f][s] for s in range(streams)] for f in range(frames)], streams=streams)
+        for s in range(streams):
+            assert [g[s] for g in got] == want[s], s
+        return
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, subpel=subpel, roi=roi, **okw))
+    dec = rd.Decoder() if w <= 320 else None
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, subpel=subpel,
+                         n_streams=streams, roi=tuple(roi), **extra) as ge:
+        for f in range(frames):
+            for s in range(streams):
+                ge.set_input(src[f][s][0], src[f][s][1], stream=s)
+            ge.encode()
+            oe.encode(*src[f][0])
+            _compare_state(oe, ge)   # stream 0: records, levels, reconstruction
+            for s in range(streams):
+                assert ge.output(s) == want[s][f], "frame %d stream %d: bytestream differs" % (f, s)
+            if dec:
+                pic, = dec.decode(ge.output(0))
+                assert pic.luma_bytes() == ge.debug_read("recon_y").tobytes()
+    # frames in flight
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, subpel=subpel,
+                         roi=tuple(roi), **extra) as ge:
+        got, q = [], 0
+        for f in range(frames):
+            if q == min(ge.pipeline_depth, 3):
+                ge.collect(); got.append(ge.output(0)); q -= 1
+            ge.set_input(src[f][0][0], src[f][0][1])
+            ge.submit(); q += 1
+        while q:
+            ge.collect(); got.append(ge.output(0)); q -= 1
+    assert got == want[0]
+    for bad in ([(0, 0, 0, 1, 3)], [(-1, 0, 1, 1, 3)], [(0, 0, 1, 1, 25)], [(0, 0, 1, 1, 1)] * 5):
+        with pytest.raises(ce.EncoderError):
+            ce.CedarEncoder(width=w, height=h, roi=tuple(bad))
+
+
+@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2", "refresh", "roi"])
 def test_fuzz_sweep_against_oracle(mode):
     """tools/fuzz_parity.py with a fixed seed: random geometry (every other picture 1-3 macroblocks
     wide or high in "narrow"), QP, GOP length, slices, streams (up to 33 in "wide"), search range,
@@ -1044,6 +1106,8 @@ def test_fuzz_sweep_against_oracle(mode):
         env["FUZZ_R2"] = "1"
     if mode == "refresh":   # ... and cyclic intra refresh on top of those
         env["FUZZ_R2"] = env["FUZZ_REFRESH"] = "1"
+    if mode == "roi":       # ... and regions of interest on top of all of it
+        env["FUZZ_R2"] = env["FUZZ_REFRESH"] = env["FUZZ_ROI"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "40"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=root)

@@ -59,6 +59,10 @@ for case in range(n_cases):
         kw.update(intra_refresh=int(rng.choice([3, 3, 4, 7, 50])))
         if "subpel" not in kw:
             kw.update(subpel=int(rng.choice([0, 2])))
+    if os.environ.get("FUZZ_ROI"):   # regions of interest on top of whatever the case drew
+        mbw, mbh = (w + 15) // 16, (h + 15) // 16
+        kw.update(roi=[(int(rng.randint(0, mbw)), int(rng.randint(0, mbh)), int(rng.randint(1, mbw + 1)), int(rng.randint(1, mbh + 1)),
+                        int(rng.randint(-24, 25))) for _ in range(int(rng.randint(1, 5)))])
     if case < first_case:
         continue
     print("case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s n %d depth<=%d" % (case, w, h, qp, keyint, slices, S, pat, kw, n, depth_draw), flush=True)
