@@ -39,7 +39,7 @@ def main():
         rows.append((k, n, fr, wr, rd_bytes, wr_bytes, rd_bytes + wr_bytes))
         stage = k.replace("cedar::k_", "").split("<")[0]
         stage = {"deblock2": "deblock", "deblock2_planes": "deblock", "intra_recon2": "intra_recon", "cavlc2": "cavlc"}.get(stage, stage)
-        if stage == "deblock" and "," in k:   # older k_deblock<IDR, planes>: 1 luma, 2 chroma, 3 both
+        if k.startswith("cedar::k_deblock<") and "," in k:   # older k_deblock<IDR, planes>: 1 luma, 2 chroma, 3 both
             planes = k.split(",")[1].strip(" >")
             stage = {"1": "deblock_luma", "2": "deblock_chroma"}.get(planes, "deblock")
         key = "%s@%s" % (stage, geom)
