@@ -258,13 +258,22 @@ DEVI int roi_qp(const Params &p, int mx, int my)
 	return min(max(p.qp + (int)p.roi_off[my * p.mb_w + mx], 1), 51);
 }
 
+// MAD classes: luma SAD / 256 of the macroblock against its chosen prediction -> one of five QP offsets
+DEVI int mad_class_qp(const Params &p, int qp_base, int sad)
+{
+	const int mad = sad >> 8;
+	const int cls = (int)(mad >= p.mad_th[0]) + (int)(mad >= p.mad_th[1]) + (int)(mad >= p.mad_th[2]) + (int)(mad >= p.mad_th[3]);
+	const int dq = cls == 0 ? p.mad_dqp[0] : cls == 1 ? p.mad_dqp[1] : cls == 2 ? p.mad_dqp[2] : cls == 3 ? p.mad_dqp[3] : p.mad_dqp[4];
+	return min(max(qp_base + dq, 1), 51);
+}
+
 // mb_qp_delta (7.4.5): against QP_Y of the macroblock before it in decoding order (k_qp_eff), the
 // slice's at its start; 0 without regions of interest
 DEVI int mb_qp_delta(const Params &p, int mx, int my, int row0, size_t mbaddr)
 {
 	if (!p.roi_off)
 		return 0;
-	return roi_qp(p, mx, my) - ((mx == 0 && my == row0) ? p.qp : (int)p.qp_eff[mbaddr - 1]);
+	return (int)p.qp_t[mbaddr] - ((mx == 0 && my == row0) ? p.qp : (int)p.qp_eff[mbaddr - 1]);
 }
 
 DEVI int median3(int a, int b, int c)

@@ -112,6 +112,8 @@ struct Params {
 	// regions of interest (nullptr: every macroblock at the slice QP, all of the above holds)
 	const int8_t *roi_off;           // [n_mb] QP offset of every macroblock of the picture (same for all streams)
 	const QpRow *qtab;               // [52]
+	uint8_t *qp_t;                   // [n_streams][n_mb] QP_Y the macroblock is quantised with (k_intra_decide / k_inter)
+	int32_t mad_on, mad_th[4], mad_dqp[5]; // MAD classes: thresholds on luma SAD / 256 against the chosen prediction, QP offset per class
 	uint8_t *qp_eff;                 // [n_streams][n_mb] QP_Y the decoder holds for the macroblock (k_qp_eff)
 	DbRec *dbrec;                    // [n_streams][n_mb]
 	int8_t *i4modes;                 // [n_mb][16]

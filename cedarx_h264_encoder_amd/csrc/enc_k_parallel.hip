@@ -231,11 +231,12 @@ struct QpSet {
 	int mf[3], dv[3], mfc[3], dvc[3];
 };
 
-DEVI QpSet qp_set(const Params &p, int mx, int my)
+template <bool MBQP>
+DEVI QpSet qp_set(const Params &p, int qp_mb)
 {
 	QpSet q;
-	if (p.roi_off) {
-		const QpRow &y = p.qtab[roi_qp(p, mx, my)];
+	if (MBQP) {
+		const QpRow &y = p.qtab[qp_mb];
 		const QpRow &c = p.qtab[y.qpc];
 		q.lambda = y.lambda; q.qbits = y.qbits; q.qshift = y.qshift; q.qbits_c = c.qbits; q.qshift_c = c.qshift;
 #pragma unroll
@@ -252,7 +253,9 @@ DEVI QpSet qp_set(const Params &p, int mx, int my)
 	return q;
 }
 
-template <int SUBPEL, bool REFRESH>
+// MBQP: macroblocks differ in QP (regions of interest, MAD classes) -- a kernel of its own, like the
+// sub-sample refinement and the refresh branch, so that the plain one keeps its registers
+template <int SUBPEL, bool REFRESH, bool MBQP>
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
 	// one wave per macroblock, INTER_WAVES macroblocks per workgroup; each wave has its own
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// "not available" under constrained_intra_pred: the prediction is 128 everywhere, luma and chroma.
 	const bool refresh = REFRESH && (mx + 2 * my + p.refresh_t) % p.intra_refresh == 0; // wave-uniform
 	// everything that follows from the QP: the picture's, or this macroblock's (regions of interest)
-	const QpSet qs = qp_set(p, mx, my);
+	const int qp_base = MBQP ? roi_qp(p, mx, my) : p.qp;
+	QpSet qs = qp_set<MBQP>(p, qp_base);
 
 	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
 	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	const int bdy = bidx / 33 - 16, bdx = bidx - (bidx / 33) * 33 - 16;
 	int qx = (REFRESH && refresh) ? 0 : 4 * bdx, qy = (REFRESH && refresh) ? 0 : 4 * bdy; // the vector in quarter samples
 	uint8_t *const s_sub = sa_sub[SUBPEL ? wave : 0];
+	uint32_t final_cost = best >> 11; // SAD + lambda * bits of the vector that is kept
 	if (SUBPEL && p.subpel > 0 && !(REFRESH && refresh)) {
 		// window coordinates of the best whole-sample block; plane sample (u, v) = window (wx0 + u, wy0 + v)
 		const int wx0 = 16 + bdx, wy0 = 16 + bdy;
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 			ok = ok && (!fy || (Y - 2 >= band_y0 && Y + 18 < band_y1 && iy >= -14 && iy <= 13));
 			return ok;
 		};
-		uint32_t bestj = best >> 11; // SAD + lambda * bits of the incumbent
+		uint32_t bestj = final_cost; // SAD + lambda * bits of the incumbent
 		for (int stage = 1; stage <= p.subpel && stage <= 2; stage++) {
 			const int step = stage == 1 ? 2 : 1, cx = qx, cy = qy;
 			uint32_t key = bestj << 4; // incumbent: index 0, wins ties
@@ -518,6 +523,21 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 				bestj = key >> 4;
 			}
 		}
+		final_cost = bestj;
+	}
+	// MAD classes (Params::mad_on): the SAD of the chosen prediction -- its cost without the vector's
+	// share -- picks one of five QP offsets for the residual; the decision above was taken without it
+	if (MBQP) {
+		int qp_mb = qp_base;
+		if (p.mad_on) {
+			int sad = (int)final_cost - qs.lambda * (mv_bits_q(qx) + mv_bits_q(qy));
+			if (REFRESH && refresh) // against the constant prediction
+				sad = wave_sum_i32((int)__builtin_amdgcn_sad_u8(((const uint32_t *)s_cur)[lane], 0x80808080u, 0u));
+			qp_mb = mad_class_qp(p, qp_base, sad);
+			qs = qp_set<true>(p, qp_mb);
+		}
+		if (lane == 0 && valid)
+			p.qp_t[mbaddr] = (uint8_t)qp_mb;
 	}
 
 	// ---- residual, transform, quantisation, reconstruction: one lane per SAMPLE ----
@@ -762,8 +782,7 @@ __global__ __launch_bounds__(1024) void k_qp_eff(Params p)
 			before = max(before, s_wave[w]);
 		v = max(v, before);
 		if (i < n) {
-			const int row = v / p.mb_w;
-			p.qp_eff[base + i] = (uint8_t)(v >= 0 ? roi_qp(p, v - row * p.mb_w, r0 + row) : p.qp);
+			p.qp_eff[base + i] = (uint8_t)(v >= 0 ? (int)p.qp_t[base + v] : p.qp);
 		}
 		__syncthreads(); // (everybody has read s_carry and s_wave; the QPs of this chunk are visible to the workgroup)
 		if (tid == 1023)
@@ -800,16 +819,19 @@ int Launch::qp_eff(const Params &p, void *stream)
 int Launch::inter(const Params &p, void *stream, int n_mbs)
 {
 	const dim3 grid((n_mbs + INTER_WAVES - 1) / INTER_WAVES), block(64 * INTER_WAVES);
-	// the refinement's planes take LDS, the refresh branch registers: kernels of their own, so the
-	// whole-sample, all-inter one keeps its occupancy
-	if (p.intra_refresh > 0 && p.subpel > 0)
-		hipLaunchKernelGGL((k_inter<1, true>), grid, block, 0, (hipStream_t)stream, p);
-	else if (p.intra_refresh > 0)
-		hipLaunchKernelGGL((k_inter<0, true>), grid, block, 0, (hipStream_t)stream, p);
-	else if (p.subpel > 0)
-		hipLaunchKernelGGL((k_inter<1, false>), grid, block, 0, (hipStream_t)stream, p);
-	else
-		hipLaunchKernelGGL((k_inter<0, false>), grid, block, 0, (hipStream_t)stream, p);
+	// the refinement's planes take LDS, the refresh branch and the per-macroblock QP registers: kernels
+	// of their own, so the whole-sample, all-inter, one-QP one keeps its occupancy
+	const int form = (p.subpel > 0 ? 1 : 0) | (p.intra_refresh > 0 ? 2 : 0) | (p.roi_off ? 4 : 0);
+	switch (form) {
+	case 0: hipLaunchKernelGGL((k_inter<0, false, false>), grid, block, 0, (hipStream_t)stream, p); break;
+	case 1: hipLaunchKernelGGL((k_inter<1, false, false>), grid, block, 0, (hipStream_t)stream, p); break;
+	case 2: hipLaunchKernelGGL((k_inter<0, true, false>), grid, block, 0, (hipStream_t)stream, p); break;
+	case 3: hipLaunchKernelGGL((k_inter<1, true, false>), grid, block, 0, (hipStream_t)stream, p); break;
+	case 4: hipLaunchKernelGGL((k_inter<0, false, true>), grid, block, 0, (hipStream_t)stream, p); break;
+	case 5: hipLaunchKernelGGL((k_inter<1, false, true>), grid, block, 0, (hipStream_t)stream, p); break;
+	case 6: hipLaunchKernelGGL((k_inter<0, true, true>), grid, block, 0, (hipStream_t)stream, p); break;
+	default: hipLaunchKernelGGL((k_inter<1, true, true>), grid, block, 0, (hipStream_t)stream, p); break;
+	}
 	return (int)hipGetLastError();
 }
 
@@ -1192,7 +1214,10 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 		p.i4modes[mbaddr * 16 + lane] = (int8_t)best4;
 	if (lane == 0) {
 		MbInfo m;
-		m.type = (sum4 + 32 * (p.roi_off ? p.qtab[roi_qp(p, mx, my)].lambda : p.lambda) < (int)(best16 >> 2)) ? MB_I4x4 : MB_I16x16;
+		const int qp_base = p.roi_off ? roi_qp(p, mx, my) : p.qp;
+		m.type = (sum4 + 32 * (p.roi_off ? p.qtab[qp_base].lambda : p.lambda) < (int)(best16 >> 2)) ? MB_I4x4 : MB_I16x16;
+		if (p.roi_off) // the QP the macroblock is quantised with: its region's, moved by its MAD class (SAD of the chosen kind of prediction)
+			p.qp_t[mbaddr] = (uint8_t)(p.mad_on ? mad_class_qp(p, qp_base, m.type == MB_I4x4 ? sum4 : (int)(best16 >> 2)) : qp_base);
 		m.i16_mode = (int8_t)(best16 & 3u);
 		m.chroma_mode = (int8_t)(bestc & 3u);
 		m.cbp = 0;

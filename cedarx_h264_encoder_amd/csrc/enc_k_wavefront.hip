@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		struct MoverRegs {
 			u32x4 sy, sc, modes;
 			uint64_t mi, ta, tb;
-			int qoff; // regions of interest: the macroblock's QP offset
+			int qoff; // regions of interest / MAD classes: the macroblock's QP (k_intra_decide)
 			bool top_ok;
 		};
 		MoverRegs RA{}, RB{};
@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			R.mi = *(const uint64_t *)&p.mbi[a];
 			R.modes = *(const u32x4 *)(p.i4modes + a * 16);
 			if (ROI)
-				R.qoff = (int)p.roi_off[cmy * p.mb_w + cmx];
+				R.qoff = (int)p.qp_t[a];
 			R.ta = R.tb = 0;
 			if (g == 0 && top_mb && nact && R.top_ok && !in_top) {
 				if (xwg_top) { // the other workgroup's write-through buffer
@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					modes64 |= (uint64_t)((mw[k >> 2] >> (8 * (k & 3))) & 15u) << (4 * k);
 				*(u32x4 *)L.info[slot] = u32x4{ (uint32_t)R.mi, (uint32_t)(R.mi >> 32), (uint32_t)modes64, (uint32_t)(modes64 >> 32) };
 				if (ROI)
-					L.qpw[slot] = (uint32_t)min(max(p.qp + R.qoff, 1), 51);
+					L.qpw[slot] = (uint32_t)R.qoff;
 			}
 			if (g == 0 && top_mb && !in_top) {
 				if (xwg_top) {

@@ -239,7 +239,8 @@ struct cedar_enc {
 	// regions of interest
 	int8_t *d_roi_off = nullptr;
 	QpRow *d_qtab = nullptr;
-	uint8_t *d_qp_eff[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint8_t *d_qp_eff[CEDAR_ENC_PIPELINE_DEPTH] = {}, *d_qp_t[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	bool mb_qp = false; // macroblocks differ in QP: regions of interest and / or MAD classes
 	DbRec *d_dbrec[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int8_t *d_i4[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint8_t *d_nnz[CEDAR_ENC_PIPELINE_DEPTH] = {};
@@ -354,7 +355,7 @@ void free_all(cedar_enc *e)
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
-		F(e->d_qp_eff[i]); F(e->d_dbrec[i]);
+		F(e->d_qp_eff[i]); F(e->d_qp_t[i]); F(e->d_dbrec[i]);
 		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
 	for (int l = 0; l < ENT_LANES; l++) {
@@ -852,6 +853,12 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (int k = 0; k < ext.roi_count; k++)
 		if (ext.roi[k][0] < 0 || ext.roi[k][1] < 0 || ext.roi[k][2] <= 0 || ext.roi[k][3] <= 0 || ext.roi[k][4] < -24 || ext.roi[k][4] > 24)
 			return fail(e, -EINVAL, "region of interest %d: x, y >= 0, width, height > 0 (macroblocks), QP offset -24..24", k);
+	for (int k = 0; k < 5; k++)
+		if (ext.mad_dqp[k] < -12 || ext.mad_dqp[k] > 12)
+			return fail(e, -EINVAL, "mad_dqp[%d] = %d outside -12..12", k, ext.mad_dqp[k]);
+	for (int k = 0; k < 4; k++)
+		if (ext.mad_th[k] < 0 || ext.mad_th[k] > 255 || (k && ext.mad_th[k] < ext.mad_th[k - 1]))
+			return fail(e, -EINVAL, "mad_th: four ascending thresholds 0..255");
 	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
@@ -870,6 +877,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	e->device = ext.device;
 	e->cfg = *cfg;
 	e->ext = ext;
+	e->mb_qp = ext.roi_count > 0;
+	for (int k = 0; k < 5; k++)
+		e->mb_qp = e->mb_qp || ext.mad_dqp[k] != 0;
 	fill_static_params(e);
 	Params &P = e->P;
 	const int S = ext.n_streams;
@@ -943,14 +953,15 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if ((rc = dalloc(e, &e->d_i4[i], ((size_t)P.n_mb * S + 1) * 16))) return rc;
 		if ((rc = dalloc(e, &e->d_nnz[i], ((size_t)P.n_mb * S + 1) * NNZ_PER_MB))) return rc;
 		if ((rc = dalloc(e, &e->d_coef[i], ((size_t)P.n_mb * S + 1) * COEF_PER_MB))) return rc;
-		if (ext.roi_count > 0) {
+		if (e->mb_qp) {
 			if ((rc = dalloc(e, &e->d_qp_eff[i], (size_t)P.n_mb * S))) return rc;
+			if ((rc = dalloc(e, &e->d_qp_t[i], (size_t)P.n_mb * S))) return rc;
 			if ((rc = dalloc(e, &e->d_dbrec[i], (size_t)P.n_mb * S))) return rc;
 		}
 	}
-	if (ext.roi_count > 0) {
-		// the offset of every macroblock (the first region that covers it), and one row of derived
-		// parameters per QP_Y
+	if (e->mb_qp) {
+		// the offset of every macroblock (the first region that covers it; all zero when only the MAD
+		// classes move QPs), and one row of derived parameters per QP_Y
 		std::vector<int8_t> off((size_t)P.n_mb, 0);
 		for (int my = 0; my < P.mb_h; my++)
 			for (int mx = 0; mx < P.mb_w; mx++)
@@ -984,6 +995,12 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		HIP_TRY(e, hipMemcpy(e->d_qtab, rows.data(), rows.size() * sizeof(QpRow), hipMemcpyHostToDevice));
 		P.roi_off = e->d_roi_off;
 		P.qtab = e->d_qtab;
+		for (int k = 0; k < 5; k++) {
+			P.mad_dqp[k] = ext.mad_dqp[k];
+			P.mad_on |= ext.mad_dqp[k] != 0;
+			if (k < 4)
+				P.mad_th[k] = ext.mad_th[k];
+		}
 	}
 	{
 		// A second entropy lane (frames alternating between two streams with scratch of their own)
@@ -1140,7 +1157,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * db_max <= cus / 2;
 		// regions of interest: QP_Y of a macroblock without coded blocks is its predecessor's in decoding
 		// order, and deblocking wants it -- a pass over the analysed picture between the two
-		if (ext.roi_count > 0)
+		if (e->mb_qp)
 			want = false;
 		if (want && !e->holds_pipe_token) {
 			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
@@ -1480,6 +1497,7 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	Q.mbi += m0;
 	if (Q.qp_eff) {
 		Q.qp_eff += m0;
+		Q.qp_t += m0;
 		Q.dbrec += m0;
 	}
 	Q.i4modes += m0 * 16;
@@ -1560,6 +1578,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.src_uv = e->d_src_uv[ds];
 	P.mbi = e->d_mbi[ds];
 	P.qp_eff = e->d_qp_eff[ds];
+	P.qp_t = e->d_qp_t[ds];
 	P.dbrec = e->d_dbrec[ds];
 	P.i4modes = e->d_i4[ds];
 	P.nnz = e->d_nnz[ds];

@@ -65,6 +65,9 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	ext.bitrate = env_int("H264ENC_BITRATE", 0);
 	ext.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
+	if (getenv("H264ENC_MAD")) /* "t0,t1,t2,t3:d0,d1,d2,d3,d4": thresholds and the QP offset of each class */
+		sscanf(getenv("H264ENC_MAD"), "%d,%d,%d,%d:%d,%d,%d,%d,%d", &ext.mad_th[0], &ext.mad_th[1], &ext.mad_th[2], &ext.mad_th[3],
+		       &ext.mad_dqp[0], &ext.mad_dqp[1], &ext.mad_dqp[2], &ext.mad_dqp[3], &ext.mad_dqp[4]);
 	if (getenv("H264ENC_ROI")) { /* "x,y,w,h,dqp;..." in macroblocks, up to 4 regions */
 		const char *r = getenv("H264ENC_ROI");
 

@@ -42,7 +42,8 @@ class _ConfigExt(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "roi_count")] + [("roi", (ctypes.c_int * 5) * 4)]
+        "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "roi_count")] + [
+        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5)]
 
 
 class _Stats(ctypes.Structure):
@@ -172,6 +173,8 @@ class EncoderConfig:
     bitrate: int = 0            # > 0: frame-level rate control towards this many bits per second
     intra_refresh: int = 0      # N >= 3: macroblocks with (x + 2*y + t) % N == 0 of the t-th P picture are coded intra
     roi: tuple = ()             # up to 4 regions of interest: (x, y, width, height in macroblocks, QP offset)
+    mad_th: tuple = (0, 0, 0, 0)       # MAD classes: ascending thresholds on luma SAD / 256 against the chosen prediction
+    mad_dqp: tuple = (0, 0, 0, 0, 0)   # ... and the QP offset of each of the five classes (all zero: off)
 
 
 class CedarEncoder:
@@ -205,6 +208,10 @@ class CedarEncoder:
         if len(cfg.roi) > 4:
             raise EncoderError(22, "at most 4 regions of interest")
         x.roi_count = len(cfg.roi)
+        for i, v in enumerate(cfg.mad_th):
+            x.mad_th[i] = int(v)
+        for i, v in enumerate(cfg.mad_dqp):
+            x.mad_dqp[i] = int(v)
         for i, r in enumerate(cfg.roi):
             for j in range(5):
                 x.roi[i][j] = int(r[j])

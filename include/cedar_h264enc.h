@@ -147,6 +147,15 @@ struct cedar_enc_config_ext {
 				clipped to 1..51, carried by mb_qp_delta. Frames of such a session run back
 				to back (a macroblock without coded blocks inherits QP_Y from its predecessor
 				in decoding order, which deblocking needs: known once the picture is analysed) */
+	int mad_th[4];       /* MAD classes -- the VE has four MAD thresholds and a MAD sum for its rate control
+				(cedar_regs.h:46-50 RC_MAD_TH0..3, RC_MAD_SUM, MAD), none of it programmed by
+				the reference. Four ascending thresholds 0..255 on the macroblock's mean absolute
+				difference against the prediction it chose (luma SAD / 256: the motion-compensated
+				block, the chosen intra kind in IDR pictures) make five classes ...            */
+	int mad_dqp[5];      /* ... and each class moves the macroblock's QP by this much (-12..12) on top of the
+				picture's QP and its region's: finer where prediction works (what the eye follows),
+				coarser where it fails anyway, or the other way round. Decisions (lambda) are taken
+				at the QP without it. All zero (default): off. Sessions run as with roi          */
 };
 
 typedef struct cedar_enc cedar_enc;

@@ -84,6 +84,9 @@ int main(int argc, char **argv)
 	cfg.bitrate = env_int("H264ENC_BITRATE", 0);
 	cfg.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	cfg.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
+	if (getenv("H264ENC_MAD")) /* "t0,t1,t2,t3:d0,d1,d2,d3,d4": thresholds and the QP offset of each class */
+		sscanf(getenv("H264ENC_MAD"), "%d,%d,%d,%d:%d,%d,%d,%d,%d", &cfg.mad_th[0], &cfg.mad_th[1], &cfg.mad_th[2], &cfg.mad_th[3],
+		       &cfg.mad_dqp[0], &cfg.mad_dqp[1], &cfg.mad_dqp[2], &cfg.mad_dqp[3], &cfg.mad_dqp[4]);
 	if (getenv("H264ENC_ROI")) { /* "x,y,w,h,dqp;..." in macroblocks, up to 4 regions */
 		const char *r = getenv("H264ENC_ROI");
 

@@ -64,6 +64,11 @@ typedef struct h264o_config {
 	int roi[4][5];        /* x, y, width, height in macroblocks and the QP offset (-24..24) of the macroblocks inside;
 	                       * where regions overlap the first one counts. QP of a macroblock = slice QP + offset,
 	                       * clipped to 1..51, carried by mb_qp_delta */
+	int mad_th[4];        /* MAD classes (the VE has four thresholds, cedar_regs.h:46-49 RC_MAD_TH0..3, and a MAD sum; the
+	                       * driver programs none of it): ascending thresholds 0..255 on the macroblock's mean absolute
+	                       * difference against its chosen prediction (luma SAD / 256) ... */
+	int mad_dqp[5];       /* ... and the QP offset (-12..12) of each of the five classes, on top of the picture's QP and
+	                       * the region's. All zero: off */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */

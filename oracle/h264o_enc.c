@@ -37,7 +37,8 @@ struct h264o_enc {
 	h264o_mb *mbs;
 	int last_idr;
 	int qp;          /* slice QP of the frame being coded: cfg.qp, or what the rate control picks */
-	int mbqp;        /* QP of the macroblock being analysed: qp + the offset of its region of interest */
+	int mbqp;        /* QP of the macroblock being analysed: qp + the offset of its region of interest (+ its MAD class) */
+	int mad_on;      /* cfg.mad_dqp has a non-zero entry */
 	uint8_t *qp_t;   /* [mb] QP every macroblock is quantised with (qp when no region covers it) */
 	uint8_t *qp_eff; /* [mb] QP_Y the decoder holds for it (7.4.5: a macroblock without mb_qp_delta keeps its predecessor's) */
 	int64_t rc_bits[64]; /* rate control history, index = frame number % 64: bits of the access unit ... */
@@ -780,6 +781,22 @@ static int chroma_qp_of(const h264o_enc *e)
 /* ------------------------------------------------------------------ */
 /* shared residual coding of chroma for intra and inter macroblocks    */
 
+/* MAD classes (cfg.mad_th / mad_dqp): the macroblock's mean absolute difference against the prediction its
+ * decision chose -- luma SAD / 256 -- falls into one of five classes, each with a QP offset on top of the
+ * picture's QP and the region's. The decision itself (lambda) is taken before, at the QP without it. */
+static void mad_qp(h264o_enc *e, int mx, int my, int sad)
+{
+	const int *th = e->cfg.mad_th, mad = sad >> 8;
+	const int cls = (mad >= th[0]) + (mad >= th[1]) + (mad >= th[2]) + (mad >= th[3]);
+	int q;
+
+	if (!e->mad_on)
+		return;
+	q = e->qp_t[my * e->mb_w + mx] + e->cfg.mad_dqp[cls];
+	e->qp_t[my * e->mb_w + mx] = (uint8_t)(q < 1 ? 1 : q > 51 ? 51 : q);
+	e->mbqp = e->qp_t[my * e->mb_w + mx];
+}
+
 static void chroma_residual(h264o_enc *e, h264o_mb *mb, int mx, int my,
 			    const uint8_t predc[2][64], int intra)
 {
@@ -959,6 +976,7 @@ static void intra_decide_mb(h264o_enc *e, int mx, int my, int row0)
 	}
 	mb->i16_mode = (int8_t)best16;
 	mb->type = (sum4 + 32 * h264o_lambda[e->mbqp] < best16_sad) ? H264O_MB_I4x4 : H264O_MB_I16x16;
+	mad_qp(e, mx, my, mb->type == H264O_MB_I4x4 ? sum4 : best16_sad);
 
 	bestc = -1;
 	for (mode = 0; mode < 4; mode++) {
@@ -1236,7 +1254,7 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 	int stride = e->cw, x0 = mx * 16, y0 = my * 16;
 	int R = e->cfg.search_range, lam = h264o_lambda[e->mbqp];
 	int dx, dy, idx, c, qx, qy;
-	long best_key = -1;
+	long best_key = -1, best_of_refine = 0;
 	int bdx = 0, bdy = 0;
 	uint8_t predc[2][64];
 
@@ -1295,7 +1313,10 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 					}
 				}
 		}
+		best_of_refine = best;
 	}
+	/* the SAD of the chosen prediction = its cost without the vector's share */
+	mad_qp(e, mx, my, (int)(best_of_refine - lam * (mv_bits_q(qx) + mv_bits_q(qy))));
 	mb->type = H264O_MB_P16x16;
 	mb->mvx = (int16_t)qx; /* quarter samples */
 	mb->mvy = (int16_t)qy;
@@ -1852,6 +1873,12 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 		if (cfg->roi[i][0] < 0 || cfg->roi[i][1] < 0 || cfg->roi[i][2] <= 0 || cfg->roi[i][3] <= 0 ||
 		    cfg->roi[i][4] < -24 || cfg->roi[i][4] > 24)
 			return NULL;
+	for (i = 0; i < 5; i++)
+		if (cfg->mad_dqp[i] < -12 || cfg->mad_dqp[i] > 12)
+			return NULL;
+	for (i = 0; i < 4; i++)
+		if (cfg->mad_th[i] < 0 || cfg->mad_th[i] > 255 || (i && cfg->mad_th[i] < cfg->mad_th[i - 1]))
+			return NULL;
 	if (cfg->intra_refresh < 0 || (cfg->intra_refresh > 0 && cfg->intra_refresh < 3) || cfg->intra_refresh > 65535)
 		return NULL;
 	if (cfg->search_range < 0 || cfg->search_range > 16)
@@ -1868,6 +1895,9 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 	if (!e)
 		return NULL;
 	e->cfg = *cfg;
+	for (i = 0; i < 5; i++)
+		if (cfg->mad_dqp[i])
+			e->mad_on = 1;
 	e->cw = ALIGN16(cfg->width);
 	e->ch = ALIGN16(cfg->height);
 	e->mb_w = e->cw / 16;
@@ -2087,6 +2117,14 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 					if (!refresh_mb(e, mx, my)) {
 						inter_mb(e, mx, my, r0, r1);
 						continue;
+					}
+					{
+						int sad128 = 0, x, y;
+
+						for (y = 0; y < 16; y++)
+							for (x = 0; x < 16; x++)
+								sad128 += abs(e->src_y[(my * 16 + y) * e->cw + mx * 16 + x] - 128);
+						mad_qp(e, mx, my, sad128);
 					}
 					mb->type = H264O_MB_I16x16;
 					mb->i16_mode = 2;    /* DC: the one mode that needs no neighbour */

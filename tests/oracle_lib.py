@@ -19,7 +19,8 @@ class Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
         "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
-        "subpel", "bitrate", "strict_mb_bits", "intra_refresh", "roi_count")] + [("roi", (ctypes.c_int * 5) * 4)]
+        "subpel", "bitrate", "strict_mb_bits", "intra_refresh", "roi_count")] + [
+        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5)]
 
 
 class MB(ctypes.Structure):
@@ -101,6 +102,9 @@ def default_config(width, height, **kw):
             for i, r in enumerate(v):
                 for j in range(5):
                     c.roi[i][j] = int(r[j])
+        elif k in ("mad_th", "mad_dqp"):
+            for i, x in enumerate(v):
+                getattr(c, k)[i] = int(x)
         else:
             setattr(c, k, v)
     return c

@@ -201,14 +201,15 @@ def test_hip_cli_gop_parallel_subpel_and_first_frame(tmp_path):
 
 @pytest.mark.gpu
 def test_hip_cli_intra_refresh_and_regions_of_interest(tmp_path):
-    """H264ENC_INTRA_REFRESH and H264ENC_ROI ("x,y,w,h,dqp;..." in macroblocks) through both command lines:
+    """H264ENC_INTRA_REFRESH, H264ENC_ROI ("x,y,w,h,dqp;..." in macroblocks) and H264ENC_MAD ("t0,t1,t2,t3:d0,..,d4")
+    through both command lines:
     the HIP one writes the file the scalar one writes."""
     w, h, frames = 320, 240, 12
     raw = _raw("B", w, h, frames)
     src = tmp_path / "in.nv12"
     src.write_bytes(raw)
     env = dict(os.environ, H264ENC_QP="29", H264ENC_KEYINT="25", H264ENC_INTRA_REFRESH="5",
-               H264ENC_ROI="2,1,6,4,-8;0,0,20,15,6", H264ENC_SUBPEL="1")
+               H264ENC_ROI="2,1,6,4,-8;0,0,20,15,6", H264ENC_SUBPEL="1", H264ENC_MAD="1,3,6,12:-3,-1,0,2,4")
     out_c, out_g = tmp_path / "cpu.264", tmp_path / "gpu.264"
     r = subprocess.run([SCALAR, str(src), str(w), str(h), str(out_c)], capture_output=True, env=env, timeout=200)
     assert r.returncode == 0, r.stderr[-500:]
@@ -216,5 +217,5 @@ def test_hip_cli_intra_refresh_and_regions_of_interest(tmp_path):
     assert r.returncode == 0, r.stderr[-500:]
     assert out_g.read_bytes() == out_c.read_bytes() and len(out_c.read_bytes()) > 1000
     enc = ol.OracleEncoder(ol.default_config(w, h, qp=29, keyint=25, intra_refresh=5, subpel=1,
-                                             roi=[(2, 1, 6, 4, -8), (0, 0, 20, 15, 6)]))
+                                             roi=[(2, 1, 6, 4, -8), (0, 0, 20, 15, 6)], mad_th=[1, 3, 6, 12], mad_dqp=[-3, -1, 0, 2, 4]))
     assert out_c.read_bytes() == b"".join(enc.encode(*ol.gen_frame("B", w, h, f)) for f in range(frames))

@@ -1036,7 +1036,13 @@ def test_cyclic_intra_refresh_equals_the_oracle(ce, w, h, qp, n, keyint, slices,
     (48, 48, 47, [(1, 1, 1, 1, -24)], 30, 1, 0, 1, 5, {}), (48, 48, 5, [(0, 0, 3, 3, -24)], 30, 1, 0, 1, 4, {}),
     (640, 368, 26, [(10, 5, 20, 12, -10), (0, 0, 40, 23, 6)], 25, 1, 2, 1, 4, {}),
     (1920, 1080, 30, [(40, 20, 40, 30, -8), (0, 60, 120, 8, 12)], 25, 1, 0, 1, 3, {}),
-    (160, 96, 30, [(2, 1, 5, 3, -9)], 5, 2, 0, 3, 8, dict(gop_parallel=2))])
+    (160, 96, 30, [(2, 1, 5, 3, -9)], 5, 2, 0, 3, 8, dict(gop_parallel=2)),
+    # MAD classes: the QP follows how well the chosen prediction fits (on their own, with regions, with refresh)
+    (96, 64, 30, [], 12, 1, 0, 1, 6, dict(mad_th=[2, 5, 10, 20], mad_dqp=[-4, -2, 0, 2, 4])),
+    (320, 240, 28, [(2, 1, 6, 4, 10)], 25, 2, 2, 2, 6, dict(mad_th=[1, 3, 6, 12], mad_dqp=[6, 3, 0, -3, -6])),
+    (112, 80, 24, [], 6, 1, 1, 1, 8, dict(mad_th=[4, 8, 16, 32], mad_dqp=[-12, 0, 0, 0, 12], intra_refresh=3)),
+    (640, 368, 26, [], 25, 1, 0, 1, 4, dict(mad_th=[1, 2, 4, 8], mad_dqp=[-3, -1, 0, 2, 5])),
+    (64, 48, 47, [], 8, 1, 0, 1, 4, dict(mad_th=[0, 0, 0, 0], mad_dqp=[0, 0, 0, 0, 5]))])
 def test_regions_of_interest_equal_the_oracle(ce, w, h, qp, roi, keyint, slices, subpel, streams, frames, extra):
     """roi: macroblocks of a region are quantised at the picture's QP + the region's offset. Every kernel that
     derives something from the QP looks it up per macroblock (k_intra_decide, k_intra_recon2<ROI>, k_inter),
@@ -1087,6 +1093,9 @@ def test_regions_of_interest_equal_the_oracle(ce, w, h, qp, roi, keyint, slices,
     for bad in ([(0, 0, 0, 1, 3)], [(-1, 0, 1, 1, 3)], [(0, 0, 1, 1, 25)], [(0, 0, 1, 1, 1)] * 5):
         with pytest.raises(ce.EncoderError):
             ce.CedarEncoder(width=w, height=h, roi=tuple(bad))
+    for bad in (dict(mad_th=(5, 4, 6, 7), mad_dqp=(1, 0, 0, 0, 0)), dict(mad_dqp=(13, 0, 0, 0, 0)), dict(mad_th=(0, 0, 0, 256))):
+        with pytest.raises(ce.EncoderError):
+            ce.CedarEncoder(width=w, height=h, **bad)
 
 
 @pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2", "refresh", "roi"])
@@ -1107,7 +1116,7 @@ def test_fuzz_sweep_against_oracle(mode):
     if mode == "refresh":   # ... and cyclic intra refresh on top of those
         env["FUZZ_R2"] = env["FUZZ_REFRESH"] = "1"
     if mode == "roi":       # ... and regions of interest on top of all of it
-        env["FUZZ_R2"] = env["FUZZ_REFRESH"] = env["FUZZ_ROI"] = "1"
+        env["FUZZ_R2"] = env["FUZZ_REFRESH"] = env["FUZZ_ROI"] = env["FUZZ_MAD"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "40"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=root)

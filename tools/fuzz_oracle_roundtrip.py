@@ -21,6 +21,8 @@ for case in range(n_cases):
     if os.environ.get("FUZZ_R2"):   # round 2's options (their own draws: the default sweep keeps its cases)
         kw.update(subpel=int(rng.choice([0, 1, 2])), intra_refresh=int(rng.choice([0, 3, 4, 11])))
         if rng.randint(0, 2):
+            kw.update(mad_th=sorted(int(x) for x in rng.randint(0, 40, 4)), mad_dqp=[int(x) for x in rng.randint(-12, 13, 5)])
+        if rng.randint(0, 2):
             kw.update(roi=[(int(rng.randint(0, 6)), int(rng.randint(0, 4)), int(rng.randint(1, 9)), int(rng.randint(1, 5)),
                             int(rng.randint(-24, 25))) for _ in range(int(rng.randint(1, 5)))])
     pat = str(rng.choice(["A", "B", "C"]))

@@ -63,6 +63,8 @@ for case in range(n_cases):
         mbw, mbh = (w + 15) // 16, (h + 15) // 16
         kw.update(roi=[(int(rng.randint(0, mbw)), int(rng.randint(0, mbh)), int(rng.randint(1, mbw + 1)), int(rng.randint(1, mbh + 1)),
                         int(rng.randint(-24, 25))) for _ in range(int(rng.randint(1, 5)))])
+    if os.environ.get("FUZZ_MAD") and rng.randint(0, 3):   # MAD classes on top
+        kw.update(mad_th=sorted(int(x) for x in rng.randint(0, 40, 4)), mad_dqp=[int(x) for x in rng.randint(-12, 13, 5)])
     if case < first_case:
         continue
     print("case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s n %d depth<=%d" % (case, w, h, qp, keyint, slices, S, pat, kw, n, depth_draw), flush=True)

@@ -24,6 +24,7 @@ CASES = [
     (96, 64, 28, 25, 4, "B", 1, "subpel=2"), (96, 64, 28, 12, 6, "B", 1, "intra_refresh=3"),
     (112, 80, 30, 25, 5, "B", 2, "subpel=2,intra_refresh=5"), (48, 48, 20, 30, 9, "C", 1, "intra_refresh=7"),
     (160, 96, 28, 25, 4, "B", 2, "subpel=2,roi=0:0:4:3:-6/2:1:6:4:10/9:5:1:1:-20"), (96, 64, 36, 6, 7, "C", 1, "roi=1:1:3:2:-12"),
+    (128, 96, 30, 25, 5, "B", 1, "mad_th=2:5:10:20,mad_dqp=-4:-2:0:2:4"), (112, 80, 27, 8, 6, "B", 2, "subpel=2,intra_refresh=4,roi=0:0:3:3:8,mad_th=1:3:6:12,mad_dqp=6:3:0:-3:-6"),
 ]
 
 
@@ -31,7 +32,12 @@ def case_options(case):
     """the optional 8th element as keyword arguments (the names are h264o_config's and CedarEncoder's)"""
     opts = {}
     for k, v in (kv.split("=") for kv in case[7].split(",")) if len(case) > 7 else ():
-        opts[k] = [tuple(int(t) for t in r.split(":")) for r in v.split("/")] if k == "roi" else int(v)   # roi=x:y:w:h:dqp/...
+        if k == "roi":                    # roi=x:y:w:h:dqp/...
+            opts[k] = [tuple(int(t) for t in r.split(":")) for r in v.split("/")]
+        elif k in ("mad_th", "mad_dqp"):  # mad_th=t0:t1:t2:t3
+            opts[k] = [int(t) for t in v.split(":")]
+        else:
+            opts[k] = int(v)
     return opts
 
 
