@@ -2384,6 +2384,10 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 	case CEDAR_ENC_DBG_SRC_Y: src = e->d_src_y[par] + (size_t)stream * P.plane_y_stride; n = (size_t)P.plane_y_stride; break;
 	case CEDAR_ENC_DBG_SRC_UV: src = e->d_src_uv[par] + (size_t)stream * P.plane_uv_stride; n = (size_t)P.plane_uv_stride; break;
 	case CEDAR_ENC_DBG_MB_BITS: src = e->d_mb_bits[e->last_lane] + (size_t)stream * P.n_mb; n = sizeof(uint32_t) * P.n_mb; break;
+	case CEDAR_ENC_DBG_MB_QP:
+		if (!e->mb_qp)
+			return fail(e, -ENOENT, "macroblocks of this session share the picture's QP");
+		src = e->d_qp_eff[par] + (size_t)stream * P.n_mb; n = (size_t)P.n_mb; break;
 	default: return -EINVAL;
 	}
 	if ((size_t)dst_size < n)

@@ -20,7 +20,7 @@ ENTROPY_CAVLC = 0
 ENTROPY_CABAC = 1
 STAGES = ("input", "intra_decide", "intra_recon", "inter", "deblock", "entropy")
 DBG = {"mbinfo": 0, "i4modes": 1, "nnz": 2, "coef": 3, "recon_y": 4, "recon_uv": 5, "src_y": 6,
-       "src_uv": 7, "mb_bits": 8}
+       "src_uv": 7, "mb_bits": 8, "mb_qp": 9}
 
 
 class EncoderError(OSError):
@@ -321,6 +321,7 @@ class CedarEncoder:
             "src_y": (np.dtype("u1"), (self.ch, self.cw)),
             "src_uv": (np.dtype("u1"), (self.ch // 2, self.cw)),
             "mb_bits": (np.dtype("<u4"), (n_mb,)),
+            "mb_qp": (np.dtype("u1"), (n_mb,)),
         }
         dt, shape = shapes[what]
         out = np.zeros(shape, dt)

@@ -273,7 +273,8 @@ enum cedar_enc_debug_buf {
 	CEDAR_ENC_DBG_RECON_UV,
 	CEDAR_ENC_DBG_SRC_Y,      /* padded source                                             */
 	CEDAR_ENC_DBG_SRC_UV,
-	CEDAR_ENC_DBG_MB_BITS     /* uint32 bits per MB                                        */
+	CEDAR_ENC_DBG_MB_BITS,    /* uint32 bits per MB                                        */
+	CEDAR_ENC_DBG_MB_QP       /* uint8 per MB: QP_Y the decoder holds for it (sessions with roi / mad_dqp; -ENOENT otherwise) */
 };
 int cedar_enc_debug_read(cedar_enc *enc, int what, int stream, void *dst, int dst_size);
 

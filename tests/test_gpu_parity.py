@@ -1073,6 +1073,7 @@ def test_regions_of_interest_equal_the_oracle(ce, w, h, qp, roi, keyint, slices,
             ge.encode()
             oe.encode(*src[f][0])
             _compare_state(oe, ge)   # stream 0: records, levels, reconstruction
+            assert np.array_equal(oe.mb_qp(), ge.debug_read("mb_qp")), f   # QP_Y as the decoder will hold it
             for s in range(streams):
                 assert ge.output(s) == want[s][f], "frame %d stream %d: bytestream differs" % (f, s)
             if dec:
