@@ -38,6 +38,7 @@ constexpr int SLOT_WORDS = SLOT_BYTES / 4;
 constexpr int ESC_CHUNK = 32;     // bytes of RBSP per emulation-prevention thread
 constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
+constexpr int IR_TRIPLES = 2;     // intra reconstruction: (luma, chroma, mover) wave triples per workgroup, one per band of 4 rows
 constexpr int DB2_XRING = 16;     // deblock: macroblocks of bottom rows a band keeps for the band below (power of two)
 constexpr int WF_MAX_SPLIT = 16;  // workgroups sharing one unit's wavefront
 constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress

@@ -926,7 +926,8 @@ __global__ __launch_bounds__(128 * PAIRS) void k_deblock2_planes(Params p, int p
 // The step is then the luma chain alone. Bottom rows travel between the groups of one
 // compute wave through LDS rings (boty / botc); band and workgroup boundaries as before.
 // ------------------------------------------------------------------------
-constexpr int IR_TRIPLES = 4; // 12 waves = 3 per SIMD: 168 VGPRs each, the same budget as 3 triples (9 waves) get
+// IR_TRIPLES (enc_internal.h) = 2: six waves, at most two on a SIMD, so each has 256 registers and nothing spills
+// (four triples = 12 waves = 3 per SIMD had 168 each and kept 33 registers in scratch on the chain)
 
 struct __attribute__((aligned(16))) Ir2GroupLds {
 	uint8_t t[17 * IT_STRIDE];  // luma wave's tile (persists: column 15 is the next left neighbour)
@@ -1043,8 +1044,9 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 		s_ptab[i] = w;
 	}
 	// waves land on SIMD wave%4: the three waves of a triple sit on three different SIMDs
-	static_assert(IR_TRIPLES == 4, "wave -> (role, triple) below assumes 4 SIMDs = 4 triples");
-	const int role = wave / IR_TRIPLES, trip = (wave - role) & 3; // 0 luma, 1 chroma, 2 mover: triple k on SIMDs k, k+1, k+2
+	static_assert(IR_TRIPLES == 2, "wave -> (role, triple) below is written for two triples on 4 SIMDs");
+	// the luma waves (the long pole) alone on SIMDs 2 and 3; chroma 0 + mover 0 share SIMD 0, chroma 1 + mover 1 SIMD 1
+	const int role = wave < 2 ? 1 : wave < 4 ? 0 : 2, trip = wave & 1; // 0 luma, 1 chroma, 2 mover
 	const int g = lane >> 4, l = lane & 15;
 	const int NWG = p.wf_split_intra;
 	uint32_t *sync = p.wf_sync; // region 0

@@ -1055,7 +1055,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// Measured on MI355X, 1080p (17 bands of 4 macroblock rows per unit), see DESIGN.md:
 		//   deblock (8 filter/mover pairs per workgroup): 1 unit 0.64 / 0.51 / 0.47 ms at 2 / 4 / 8
 		//   parts; 32 units 1.06 / 0.89 / 0.82 ms at 1 / 2 / 4 parts
-		//   intra recon (4 luma/chroma/mover triples per workgroup): a workgroup with more bands
+		//   intra recon (IR_TRIPLES luma/chroma/mover triples per workgroup): a workgroup with more bands
 		//   than triples serialises them (3 triples: 7.1 ms at 4 parts against 3.3 ms at 6, 1 unit)
 		int nb_max = 0;
 		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
@@ -1068,15 +1068,23 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// pipelined against 40 M with 8 parts back to back; x 8: 69 M (2 parts, pipelined) against
 		// 62-67 M; x 16: pipelining loses (80 M against 91 M), frames run back to back from there.
 		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
-		e->wf_split_intra = clamp_split(env_i ? atoi(env_i) : (nb_max + 3) / 4);
+		{ // every band a triple of its own where the split allows (a workgroup with more bands serialises them)
+			int si = env_i ? atoi(env_i) : (nb_max + IR_TRIPLES - 1) / IR_TRIPLES;
+			if (si > WF_MAX_SPLIT) si = WF_MAX_SPLIT;
+			if (si > nb_min) si = nb_min;
+			e->wf_split_intra = si < 1 ? 1 : si;
+		}
 		const char *env_p = getenv("CEDAR_DB_PAIRS");
 		// Deblock workgroups: 8 wave pairs (a whole CU: one unit's wavefront as fast as it goes, what the
 		// pipelined sessions of up to 8 units want) or 2 pairs -- a quarter of the LDS and of the waves,
 		// which finds room on a CU beside other kernels' workgroups. Above 8 units frames run back to back
-		// and the small form wins: 16 x 1080p 114 -> 120 M MB/s, 32: 134 -> 139, 64: 139 -> 146.
+		// and the small form wins: 16 x 1080p 114 -> 120 M MB/s, 32: 134 -> 139, 64: 139 -> 146. (Up to 8
+		// units the big form stays: 1 / 4 / 8 streams 36.0 / 82.6 / 99.9 M against 35.1 / 54.7 / 88.5 with 2
+		// pairs and 34.2 / 85.9 / 93.8 with 4; the kernel's own time is 0.38-0.39 ms per picture in every
+		// form -- its three spilled registers cost nothing measurable.)
 		e->db_pairs = env_p ? (atoi(env_p) == 2 ? 2 : 8) : n_units > 8 ? 2 : 8;
-		if (e->db_pairs == 2 && !env) { // small workgroups: as many as it takes to give every band a wave pair
-			const int want = (nb_min + 1) / 2;
+		if (e->db_pairs < 8 && !env && (n_units > 8 || env_p)) { // small workgroups: as many as it takes to give every band a wave pair
+			const int want = (nb_min + e->db_pairs - 1) / e->db_pairs;
 			e->wf_split = want > WF_MAX_SPLIT ? WF_MAX_SPLIT : want < 1 ? 1 : want;
 		}
 		// A band runs at most DB2_XRING (+3) macroblocks ahead of the band below it (the hand-off ring in
