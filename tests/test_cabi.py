@@ -113,3 +113,27 @@ def test_pattern_generators_agree():
             a = m.gen_pattern(p, 70, 50, f, 5)
             b = ol.gen_frame(p, 70, 50, f, 5)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_c_header(tmp_path):
+    """encoder.py's _ConfigExt / _Config / _Stats against include/cedar_h264enc.h as gcc lays it out: size and the
+    offset of every field (the library refuses a config_ext of another size, but only on a GPU box)."""
+    import ctypes
+    import subprocess
+    from cedarx_h264_encoder_amd import encoder as enc
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cedar_h264enc.h"', 'int main(void) {']
+    structs = (("cedar_enc_config_ext", enc._ConfigExt), ("cedar_enc_config", enc._Config), ("cedar_enc_stats", enc._Stats))
+    for cname, ct in structs:
+        lines.append('printf("%s %%zu\\n", sizeof(struct %s));' % (cname, cname))
+        for f in ct._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(struct %s, %s));' % (cname, f[0], cname, f[0]))
+    lines += ['return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, ct in structs:
+        assert int(got[cname]) == ctypes.sizeof(ct), cname
+        for f in ct._fields_:
+            assert int(got["%s.%s" % (cname, f[0])]) == getattr(ct, f[0]).offset, (cname, f[0])
