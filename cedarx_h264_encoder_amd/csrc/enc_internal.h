@@ -61,17 +61,6 @@ struct QpRow {
 	int32_t pad;
 };
 
-// What the deblock kernel needs of one macroblock when QPs differ: thresholds of its left edge, its
-// top edge (both from the mean QP with the neighbour, 8.7.2.2) and its inner edges, luma then chroma.
-// Written by k_qp_eff once the picture is analysed (QP_Y of a macroblock without mb_qp_delta is
-// its predecessor's, 7.4.5: known only then). 32 bytes.
-struct DbRec {
-	uint8_t y[3][5];            // [left, top, inner][alpha, beta, tc0 of bS 1, 2, 3]
-	uint8_t pad0;
-	uint8_t c[3][5];
-	uint8_t pad1;
-};
-
 // What one picture-slice header contributes in front of the macroblock data.
 struct SliceHdr {
 	uint64_t bits;   // right-aligned header bits (<= 64)
@@ -116,7 +105,6 @@ struct Params {
 	uint8_t *qp_t;                   // [n_streams][n_mb] QP_Y the macroblock is quantised with (k_intra_decide / k_inter)
 	int32_t mad_on, mad_th[4], mad_dqp[5]; // MAD classes: thresholds on luma SAD / 256 against the chosen prediction, QP offset per class
 	uint8_t *qp_eff;                 // [n_streams][n_mb] QP_Y the decoder holds for the macroblock (k_qp_eff)
-	DbRec *dbrec;                    // [n_streams][n_mb]
 	int8_t *i4modes;                 // [n_mb][16]
 	uint8_t *nnz;                    // [n_mb][24]
 	int16_t *coef;                   // [n_mb][COEF_PER_MB]
@@ -212,7 +200,7 @@ struct Launch {
 	static int intra_decide(const Params &p, void *stream);
 	static int intra_recon(const Params &p, void *stream);
 	static int inter(const Params &p, void *stream, int n_mbs); // n_mbs macroblocks: the picture, or the diagonals [stripe_s0, stripe_s1)
-	static int qp_eff(const Params &p, void *stream);           // regions of interest: QP_Y per macroblock + deblock thresholds, after the analysis
+	static int qp_eff(const Params &p, void *stream);           // macroblocks differ in QP: QP_Y per macroblock as the decoder holds it, for mb_qp_delta
 	// 1 wave: publish prog_inter = publish_d (if >= 0), then wait until every deblock band of the
 	// previous frame has written back all macroblocks with x + 2*y < need_d (if > 0)
 	static int gate(const Params &p, void *stream, int publish_d, int need_d);

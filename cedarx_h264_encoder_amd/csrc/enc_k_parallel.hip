@@ -714,6 +714,11 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	for (int qd = 0; qd < 4; qd++)
 		cbp |= ((nz_luma >> (4 * qd)) & 0xfu) ? (1 << qd) : 0;
 	cbp |= nz_cac ? 0x20 : (dcmask ? 0x10 : 0);
+	// macroblocks differ in QP: the first one of a row always carries an mb_qp_delta ("chroma DC" with two
+	// empty blocks when it has no coded block; it is then no P_Skip either), so that QP_Y is never
+	// inherited across a row boundary and deblocking can follow the chain left to right
+	if (MBQP && mx == 0 && !(REFRESH && refresh) && cbp == 0)
+		cbp = 0x10;
 	WAVE_LDS_SYNC();
 
 	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
@@ -740,9 +745,10 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 }
 
 // ------------------------------------------------------------------------
-// k_qp_eff (regions of interest only): QP_Y of every macroblock as the decoder will hold it, and
-// from it the deblocking thresholds of the macroblock's edges. One workgroup per unit (stream x
-// slice), after the unit's analysis. A macroblock changes QP_Y only if it carries mb_qp_delta --
+// k_qp_eff (sessions whose macroblocks differ in QP): QP_Y of every macroblock as the decoder will
+// hold it, for the mb_qp_delta of the one after it (the deblock kernel follows the same chain itself,
+// row by row). One workgroup per unit (stream x slice), after the unit's analysis, on the entropy
+// stream. A macroblock changes QP_Y only if it carries mb_qp_delta --
 // Intra16x16, or any coded block (7.3.5, 7.4.5); the others, P_Skip included, keep that of the
 // macroblock before them in decoding order (the slice's at its start): a max-scan over "index of
 // the last macroblock with an mb_qp_delta".
@@ -784,28 +790,9 @@ __global__ __launch_bounds__(1024) void k_qp_eff(Params p)
 		if (i < n) {
 			p.qp_eff[base + i] = (uint8_t)(v >= 0 ? (int)p.qp_t[base + v] : p.qp);
 		}
-		__syncthreads(); // (everybody has read s_carry and s_wave; the QPs of this chunk are visible to the workgroup)
+		__syncthreads(); // (everybody has read s_carry and s_wave)
 		if (tid == 1023)
 			s_carry = v;
-		if (i < n) {
-			const int my = i / p.mb_w, mx = i - my * p.mb_w;
-			const int qc = p.qp_eff[base + i];
-			const int ql = mx > 0 ? p.qp_eff[base + i - 1] : qc, qt = my > 0 ? p.qp_eff[base + i - p.mb_w] : qc;
-			const int cc = p.qtab[qc].qpc, cl = p.qtab[ql].qpc, ct = p.qtab[qt].qpc;
-			const int qy[3] = { (ql + qc + 1) >> 1, (qt + qc + 1) >> 1, qc };
-			const int qch[3] = { (cl + cc + 1) >> 1, (ct + cc + 1) >> 1, cc };
-			DbRec r;
-#pragma unroll
-			for (int k = 0; k < 3; k++) {
-				const QpRow &a = p.qtab[qy[k]], &b = p.qtab[qch[k]];
-				r.y[k][0] = (uint8_t)a.alpha; r.y[k][1] = (uint8_t)a.beta;
-				r.y[k][2] = (uint8_t)a.tc0[0]; r.y[k][3] = (uint8_t)a.tc0[1]; r.y[k][4] = (uint8_t)a.tc0[2];
-				r.c[k][0] = (uint8_t)b.alpha; r.c[k][1] = (uint8_t)b.beta;
-				r.c[k][2] = (uint8_t)b.tc0[0]; r.c[k][3] = (uint8_t)b.tc0[1]; r.c[k][4] = (uint8_t)b.tc0[2];
-			}
-			r.pad0 = r.pad1 = 0;
-			p.dbrec[base + i] = r;
-		}
 		__syncthreads();
 	}
 }

@@ -258,6 +258,7 @@ struct Db2Shared {
 	int staged[PAIRS], filtered[PAIRS], vdone[PAIRS]; // steps staged / filtered / through their vertical edges
 	int ticket;
 	int abort; // a wait of this workgroup ran out: stop waiting
+	uint64_t qdb[52]; // MODE 3: per QP alpha, beta, tc0 of bS 1..3, QP_C (one byte each), from the session's table
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -265,7 +266,8 @@ extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 // MODE 0: a P picture of inter macroblocks; 1: an IDR picture (all intra: bS 4 on macroblock edges, 3 inside);
 // 2: a P picture with intra macroblocks in it (cyclic intra refresh): the strengths of both, per edge;
 // 3: any picture of a session with regions of interest: as 2 (an IDR picture is the case "all intra"), and the
-//    thresholds alpha / beta / tc0 are the macroblock's own, per edge class (left, top, inner: DbRec)
+//    thresholds alpha / beta / tc0 are the macroblock's own, per edge class (left, top, inner): the mover
+//    follows QP_Y along the row from the records and qp_t
 template <int MODE, int PL, int PAIRS>
 DEVI void deblock2_body(const Params &p, const int wg)
 {
@@ -290,6 +292,11 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	if (threadIdx.x == 0) {
 		s_ticket = NWG > 1 ? (int)atomicAdd(&sync[0], 1u) : wg;
 		S.abort = 0;
+	}
+	if (QPM && threadIdx.x < 52) {
+		const QpRow &r = p.qtab[threadIdx.x];
+		S.qdb[threadIdx.x] = (uint64_t)(uint32_t)r.alpha | (uint64_t)(uint32_t)r.beta << 8 | (uint64_t)(uint32_t)r.tc0[0] << 16 |
+				     (uint64_t)(uint32_t)r.tc0[1] << 24 | (uint64_t)(uint32_t)r.tc0[2] << 32 | (uint64_t)(uint32_t)r.qpc << 40;
 	}
 	if (threadIdx.x < PAIRS) {
 		s_staged[threadIdx.x] = 0;
@@ -581,13 +588,14 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			// (x, y) changes all of it, row 15 and column 15 included, which intra (x+1, y),
 			// (x-1, y+1), (x, y+1) and (x+1, y+1) still need: in an intra picture the deblock
 			// wavefront stays behind the last of them, three more diagonals.
-			const uint32_t need = (uint32_t)(t + 3 + diag0 + (IDR ? 4 : 1)); // group 3 is 3 diagonals ahead of group 0
+			const bool idr_pic = IDR || (QPM && p.is_idr); // (mode 3 serves the IDR pictures of its sessions too)
+			const uint32_t need = (uint32_t)(t + 3 + diag0 + (idr_pic ? 4 : 1)); // group 3 is 3 diagonals ahead of group 0
 			if (inter_seen >= need)
 				return;
 			// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the
 			// intra wavefront publishes per band; this band's rows and the row above them count.
 			const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
-			if (IDR && p.prog_intra) { // the band itself, the one above (top rows) and the one below (its consumers)
+			if (idr_pic && p.prog_intra) { // the band itself, the one above (top rows) and the one below (its consumers)
 				w0 = p.prog_intra + unit * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1);
 				w1 = band > 0 ? w0 - 1 : w0;
 				w2 = band + 1 < nbands && band + 1 < PROG_BANDS ? w0 + 1 : w0;
@@ -639,7 +647,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			uint64_t topx;
 			uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
 			uint32_t ty, tyt; // MIXED: its first dword (type in the low byte)
-			u32x4 rec0, rec1; // MODE 3: the macroblock's DbRec
+			uint8_t qc, qt;   // MODE 3: QP the macroblock, and the one above it, is quantised with (qp_t)
 			uint8_t nz, nzt;
 			bool top_ok;
 		};
@@ -647,6 +655,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
 		int mvl = 0;
 		bool intra_left = false;
+		int eff_left = 0, teff_left = 0; // MODE 3: QP_Y the decoder holds for the macroblock staged last, and for the one above that
 		int pending_x = -1;
 
 		auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t into the r_* registers
@@ -683,8 +692,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					R.tyt = ((const uint32_t *)&p.mbi[at])[0];
 				}
 				if (QPM) {
-					R.rec0 = ((const u32x4 *)&p.dbrec[a])[0];
-					R.rec1 = ((const u32x4 *)&p.dbrec[a])[1];
+					R.qc = p.qp_t[a];
+					R.qt = p.qp_t[at];
 				}
 			}
 			if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
@@ -726,15 +735,27 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					// edge code by strength for the macroblock's left edge, top edge, inner edges (MODE 3: its own tc0)
 					uint32_t cyL = cod_y, cyT = cod_y, cyI = cod_y, ccL = cod_c, ccT = cod_c, ccI = cod_c;
 					if (QPM) {
-						const uint32_t r0w[4] = { R.rec0.x, R.rec0.y, R.rec0.z, R.rec0.w }, r1w[4] = { R.rec1.x, R.rec1.y, R.rec1.z, R.rec1.w };
-						auto yb = [&](int i) { return (r0w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
-						auto cb = [&](int i) { return (r1w[i >> 2] >> (8 * (i & 3))) & 0xffu; };
-						auto code3 = [](uint32_t t1, uint32_t t2, uint32_t t3) { return (0x80u | t1) << 8 | (0x80u | t2) << 16 | (0x80u | t3) << 24; };
-						cyL = code3(yb(2), yb(3), yb(4)); cyT = code3(yb(7), yb(8), yb(9)); cyI = code3(yb(12), yb(13), yb(14));
-						ccL = code3(cb(2), cb(3), cb(4)); ccT = code3(cb(7), cb(8), cb(9)); ccI = code3(cb(12), cb(13), cb(14));
+						// QP_Y as the decoder holds it: a macroblock without mb_qp_delta (no coded block, not
+						// Intra16x16) keeps that of the one before it -- in its row: the first macroblock of a row
+						// always has one (the encoder sees to it). Followed left to right, for this row and the
+						// row above; thresholds from the mean across a macroblock edge (8.7.2.2), per plane.
+						auto coded = [](uint32_t w0) { return (int)(int8_t)(w0 & 0xffu) == MB_I16x16 || ((w0 >> 24) & 0x3fu) != 0; };
+						const int eff = (mx == 0 || coded(R.ty)) ? (int)R.qc : eff_left;
+						const int teff = (mx == 0 || coded(R.tyt)) ? (int)R.qt : teff_left;
+						auto qpc_of = [&](int q) { return (int)((S.qdb[q] >> 40) & 0xffu); };
+						const int ce = qpc_of(eff);
+						const uint64_t yL = S.qdb[(eff_left + eff + 1) >> 1], yT = S.qdb[(teff + eff + 1) >> 1], yI = S.qdb[eff];
+						const uint64_t cL = S.qdb[(qpc_of(eff_left) + ce + 1) >> 1], cT = S.qdb[(qpc_of(teff) + ce + 1) >> 1], cI = S.qdb[ce];
+						auto code3 = [](uint64_t r) { // tc0 of bS 1..3 -> edge codes 0x80 | tc0 in bytes 1..3
+							return (uint32_t)((r >> 8) & 0xffffff00ull) | 0x80808000u;
+						};
+						cyL = code3(yL); cyT = code3(yT); cyI = code3(yI);
+						ccL = code3(cL); ccT = code3(cT); ccI = code3(cI);
 						if (l == 0)
-							*(u32x4 *)L.ab[slot] = u32x4{ yb(0) | yb(1) << 8 | yb(5) << 16 | yb(6) << 24, yb(10) | yb(11) << 8,
-										      cb(0) | cb(1) << 8 | cb(5) << 16 | cb(6) << 24, cb(10) | cb(11) << 8 };
+							*(u32x4 *)L.ab[slot] = u32x4{ (uint32_t)(yL & 0xffffu) | (uint32_t)(yT & 0xffffu) << 16, (uint32_t)(yI & 0xffffu),
+										      (uint32_t)(cL & 0xffffu) | (uint32_t)(cT & 0xffffu) << 16, (uint32_t)(cI & 0xffffu) };
+						eff_left = eff;
+						teff_left = teff;
 					}
 					const int k = l >> 2, ks = (l & 7) >> 1;
 					int bv[4], bh[4];
@@ -1622,7 +1643,12 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 			if (l < 8)
 				*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.outc[slot] + l * 16);
 			if (l == 15) { // the record, with the coded block pattern of both compute waves
-				const uint32_t cbp = (uint32_t)(L.cbp_y[slot] | L.cbp_yb[slot] | L.cbp_c[slot]) & 0xffu;
+				uint32_t cbp = (uint32_t)(L.cbp_y[slot] | L.cbp_yb[slot] | L.cbp_c[slot]) & 0xffu;
+				// macroblocks differ in QP: the first one of a row always carries an mb_qp_delta (an Intra4x4
+				// one without a coded block says "chroma DC" and codes two empty blocks), so that QP_Y never
+				// has to be inherited across a row boundary
+				if (ROI && mx == 0 && (int)(int8_t)(L.info[slot][0] & 0xffu) == MB_I4x4 && !(cbp & 0x3fu))
+					cbp = 0x10u;
 				const uint32_t w0 = (L.info[slot][0] & 0x00ffffffu) | cbp << 24;
 				*(uint64_t *)&p.mbi[mbaddr] = (uint64_t)w0 | (uint64_t)L.info[slot][1] << 32;
 			}

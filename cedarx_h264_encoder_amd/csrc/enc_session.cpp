@@ -241,7 +241,6 @@ struct cedar_enc {
 	QpRow *d_qtab = nullptr;
 	uint8_t *d_qp_eff[CEDAR_ENC_PIPELINE_DEPTH] = {}, *d_qp_t[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	bool mb_qp = false; // macroblocks differ in QP: regions of interest and / or MAD classes
-	DbRec *d_dbrec[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int8_t *d_i4[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint8_t *d_nnz[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	int16_t *d_coef[CEDAR_ENC_PIPELINE_DEPTH] = {};
@@ -355,7 +354,7 @@ void free_all(cedar_enc *e)
 	}
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
-		F(e->d_qp_eff[i]); F(e->d_qp_t[i]); F(e->d_dbrec[i]);
+		F(e->d_qp_eff[i]); F(e->d_qp_t[i]);
 		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
 	for (int l = 0; l < ENT_LANES; l++) {
@@ -956,7 +955,6 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if (e->mb_qp) {
 			if ((rc = dalloc(e, &e->d_qp_eff[i], (size_t)P.n_mb * S))) return rc;
 			if ((rc = dalloc(e, &e->d_qp_t[i], (size_t)P.n_mb * S))) return rc;
-			if ((rc = dalloc(e, &e->d_dbrec[i], (size_t)P.n_mb * S))) return rc;
 		}
 	}
 	if (e->mb_qp) {
@@ -1163,10 +1161,6 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// 2x3 15.8, 3x3 15.9, 1x3 12: the leanest set that overlaps two deblock kernels wins
 		const int db_max = envd ? atoi(envd) : 2;
 		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * db_max <= cus / 2;
-		// regions of interest: QP_Y of a macroblock without coded blocks is its predecessor's in decoding
-		// order, and deblocking wants it -- a pass over the analysed picture between the two
-		if (e->mb_qp)
-			want = false;
 		if (want && !e->holds_pipe_token) {
 			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
 				e->holds_pipe_token = true;
@@ -1506,7 +1500,6 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	if (Q.qp_eff) {
 		Q.qp_eff += m0;
 		Q.qp_t += m0;
-		Q.dbrec += m0;
 	}
 	Q.i4modes += m0 * 16;
 	Q.nnz += m0 * NNZ_PER_MB;
@@ -1587,7 +1580,6 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.mbi = e->d_mbi[ds];
 	P.qp_eff = e->d_qp_eff[ds];
 	P.qp_t = e->d_qp_t[ds];
-	P.dbrec = e->d_dbrec[ds];
 	P.i4modes = e->d_i4[ds];
 	P.nnz = e->d_nnz[ds];
 	P.coef = e->d_coef[ds];
@@ -1854,9 +1846,6 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			if (c == C - 1)
 				tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
 		}
-		// regions of interest: QP_Y as the decoder will hold it + the deblock thresholds of every edge
-		if (Pc.roi_off && Launch::qp_eff(Pc, s_ana))
-			return fail(e, -EIO, "k_qp_eff launch failed");
 		HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
 		t_main = now_ms();
 
@@ -1868,6 +1857,9 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		// words are left zeroed and the done flag raised by k_copy_out's last workgroup
 		if (!pipe)
 			HIP_TRY(e, hipMemsetAsync(Pc.stream_size, 0, sizeof(uint32_t) * (Pc.n_streams + 4), s_ent));
+		// macroblocks differ in QP: QP_Y as the decoder will hold it, for the mb_qp_delta of the next one
+		if (Pc.roi_off && Launch::qp_eff(Pc, s_ent))
+			return fail(e, -EIO, "k_qp_eff launch failed");
 		if (Launch::entropy(Pc, s_ent))
 			return fail(e, -EIO, "entropy launch failed");
 		if (c == C - 1)

@@ -144,9 +144,9 @@ struct cedar_enc_config_ext {
 	int roi[4][5];       /* x, y, width, height in macroblocks and the QP offset (-24..24) of the
 				macroblocks inside; where regions overlap the first counts. A macroblock's QP
 				= the picture's (qp, or what rate control / requantising make of it) + offset,
-				clipped to 1..51, carried by mb_qp_delta. Frames of such a session run back
-				to back (a macroblock without coded blocks inherits QP_Y from its predecessor
-				in decoding order, which deblocking needs: known once the picture is analysed) */
+				clipped to 1..51, carried by mb_qp_delta. In such a session the first
+				macroblock of every row always carries one (an empty chroma DC pair if it has
+				nothing else to code): QP_Y is then never inherited across a row boundary     */
 	int mad_th[4];       /* MAD classes -- the VE has four MAD thresholds and a MAD sum for its rate control
 				(cedar_regs.h:46-50 RC_MAD_TH0..3, RC_MAD_SUM, MAD), none of it programmed by
 				the reference. Four ascending thresholds 0..255 on the macroblock's mean absolute
@@ -155,7 +155,7 @@ struct cedar_enc_config_ext {
 	int mad_dqp[5];      /* ... and each class moves the macroblock's QP by this much (-12..12) on top of the
 				picture's QP and its region's: finer where prediction works (what the eye follows),
 				coarser where it fails anyway, or the other way round. Decisions (lambda) are taken
-				at the QP without it. All zero (default): off. Sessions run as with roi          */
+				at the QP without it. All zero (default): off. The row rule of roi applies          */
 };
 
 typedef struct cedar_enc cedar_enc;

@@ -784,6 +784,18 @@ static int chroma_qp_of(const h264o_enc *e)
 /* MAD classes (cfg.mad_th / mad_dqp): the macroblock's mean absolute difference against the prediction its
  * decision chose -- luma SAD / 256 -- falls into one of five classes, each with a QP offset on top of the
  * picture's QP and the region's. The decision itself (lambda) is taken before, at the QP without it. */
+/* Sessions whose macroblocks differ in QP: the first macroblock of every row always carries an mb_qp_delta.
+ * QP_Y of a macroblock without one is its predecessor's in decoding order -- across a row boundary the LAST
+ * macroblock of the row above, far away on the analysis / deblock diagonals x + 2y. With the row's first
+ * macroblock "coded" the chain never leaves the row, and deblocking can follow it left to right. A macroblock
+ * that has no coded block gets coded_block_pattern = "chroma DC", two empty chroma DC blocks (4 bits) and its
+ * mb_qp_delta; a would-be P_Skip becomes P_L0_16x16 with that. */
+static void force_row_start_coded(const h264o_enc *e, h264o_mb *mb, int mx)
+{
+	if ((e->cfg.roi_count > 0 || e->mad_on) && mx == 0 && mb->type != H264O_MB_I16x16 && !(mb->cbp & 0x3f))
+		mb->cbp = 0x10;
+}
+
 static void mad_qp(h264o_enc *e, int mx, int my, int sad)
 {
 	const int *th = e->cfg.mad_th, mad = sad >> 8;
@@ -2096,6 +2108,7 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					intra_decide_mb(e, mx, my, r0);
 					intra_recon_mb(e, mx, my, r0, 0);
+					force_row_start_coded(e, &e->mbs[my * e->mb_w + mx], mx);
 				}
 		} else if (idr) {
 			for (my = r0; my < r1; my++)
@@ -2107,6 +2120,7 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 				for (mx = 0; mx < e->mb_w; mx++) {
 					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					intra_recon_mb(e, mx, my, r0, 0);
+					force_row_start_coded(e, &e->mbs[my * e->mb_w + mx], mx);
 				}
 		} else {
 			for (my = r0; my < r1; my++)
@@ -2116,6 +2130,7 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 					e->mbqp = e->qp_t[my * e->mb_w + mx];
 					if (!refresh_mb(e, mx, my)) {
 						inter_mb(e, mx, my, r0, r1);
+						force_row_start_coded(e, mb, mx);
 						continue;
 					}
 					{
