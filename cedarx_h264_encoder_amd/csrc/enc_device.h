@@ -253,9 +253,15 @@ DEVI int mv_bits(int d)
 }
 
 // regions of interest: QP_Y the macroblock is quantised with (the picture's + its region's offset)
-DEVI int roi_qp(const Params &p, int mx, int my)
+// the picture's QP: one per launch, or -- rate control over several streams -- one per stream
+DEVI int pic_qp(const Params &p, int st)
 {
-	return min(max(p.qp + (int)p.roi_off[my * p.mb_w + mx], 1), 51);
+	return p.qp_s ? (int)p.qp_s[st] : p.qp;
+}
+
+DEVI int roi_qp(const Params &p, int st, int mx, int my)
+{
+	return min(max(pic_qp(p, st) + (int)p.roi_off[my * p.mb_w + mx], 1), 51);
 }
 
 // MAD classes: luma SAD / 256 of the macroblock against its chosen prediction -> one of five QP offsets
@@ -269,11 +275,11 @@ DEVI int mad_class_qp(const Params &p, int qp_base, int sad)
 
 // mb_qp_delta (7.4.5): against QP_Y of the macroblock before it in decoding order (k_qp_eff), the
 // slice's at its start; 0 without regions of interest
-DEVI int mb_qp_delta(const Params &p, int mx, int my, int row0, size_t mbaddr)
+DEVI int mb_qp_delta(const Params &p, int st, int mx, int my, int row0, size_t mbaddr)
 {
 	if (!p.roi_off)
 		return 0;
-	return (int)p.qp_t[mbaddr] - ((mx == 0 && my == row0) ? p.qp : (int)p.qp_eff[mbaddr - 1]);
+	return (int)p.qp_t[mbaddr] - ((mx == 0 && my == row0) ? pic_qp(p, st) : (int)p.qp_eff[mbaddr - 1]);
 }
 
 DEVI int median3(int a, int b, int c)

@@ -101,6 +101,8 @@ struct Params {
 	MbInfo *mbi;
 	// regions of interest (nullptr: every macroblock at the slice QP, all of the above holds)
 	const int8_t *roi_off;           // [n_mb] QP offset of every macroblock of the picture (same for all streams)
+	const uint8_t *qp_s;             // [n_streams] the picture's QP per stream (rate control over several streams); nullptr: qp
+	int32_t row_rule;                // QPs differ INSIDE a picture (regions, MAD classes): the first macroblock of a row always carries mb_qp_delta
 	const QpRow *qtab;               // [52]
 	uint8_t *qp_t;                   // [n_streams][n_mb] QP_Y the macroblock is quantised with (k_intra_decide / k_inter)
 	int32_t mad_on, mad_th[4], mad_dqp[5]; // MAD classes: thresholds on luma SAD / 256 against the chosen prediction, QP offset per class

@@ -300,12 +300,12 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 			bw_ue(b, (uint32_t)mi.chroma_mode);
 			bw_ue(b, kCbpCodeIntra[mi.cbp & 0x3f]);
 			if (mi.cbp & 0x3f)
-				bw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+				bw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 		} else {
 			const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
 			bw_ue(b, (uint32_t)t);
 			bw_ue(b, (uint32_t)mi.chroma_mode);
-			bw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+			bw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 		}
 		write_residual(b, mi, cf, nb);
 	} else if (mi.type == MB_I16x16) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 		const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
 		bw_ue(b, (uint32_t)(5 + t));
 		bw_ue(b, (uint32_t)mi.chroma_mode);
-		bw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+		bw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 		write_residual(b, mi, cf, nb);
 	} else {
 		// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1). An intra neighbour (a
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 			bw_se(b, mi.mvy - py);
 			bw_ue(b, kCbpCodeInter[mi.cbp & 0x3f]);
 			if (mi.cbp & 0x3f)
-				bw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+				bw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 			write_residual(b, mi, cf, nb);
 		}
 	}
@@ -606,19 +606,19 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 				lw_ue(b, (uint32_t)mi.chroma_mode);
 				lw_ue(b, kCbpCodeIntra[cbp]);
 				if (cbp)
-					lw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+					lw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 			} else {
 				const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
 				lw_ue(b, (uint32_t)t);
 				lw_ue(b, (uint32_t)mi.chroma_mode);
-				lw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+				lw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 			}
 		} else if (mi.type == MB_I16x16) {
 			// a refresh macroblock (Params::intra_refresh): intra in a P slice, mb_type 5 + the I slice's
 			const int t = 1 + mi.i16_mode + 4 * ((mi.cbp >> 4) & 3) + ((mi.cbp & 15) ? 12 : 0);
 			lw_ue(b, (uint32_t)(5 + t));
 			lw_ue(b, (uint32_t)mi.chroma_mode);
-			lw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+			lw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 		} else {
 			// motion vector prediction (8.4.1.3) and P_Skip inference (8.4.1.1). An intra neighbour (a
 			// refresh macroblock) is available with refIdx -1 and a zero vector; ra/rb/rc = "has refIdx 0".
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 				lw_se(b, mi.mvy - py);
 				lw_ue(b, kCbpCodeInter[cbp]);
 				if (cbp)
-					lw_se(b, mb_qp_delta(p, mx, my, r0, mbaddr));
+					lw_se(b, mb_qp_delta(p, st, mx, my, r0, mbaddr));
 			}
 		}
 	} else if (valid && hl == 1) {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// "not available" under constrained_intra_pred: the prediction is 128 everywhere, luma and chroma.
 	const bool refresh = REFRESH && (mx + 2 * my + p.refresh_t) % p.intra_refresh == 0; // wave-uniform
 	// everything that follows from the QP: the picture's, or this macroblock's (regions of interest)
-	const int qp_base = MBQP ? roi_qp(p, mx, my) : p.qp;
+	const int qp_base = MBQP ? roi_qp(p, st, mx, my) : p.qp;
 	QpSet qs = qp_set<MBQP>(p, qp_base);
 
 	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// macroblocks differ in QP: the first one of a row always carries an mb_qp_delta ("chroma DC" with two
 	// empty blocks when it has no coded block; it is then no P_Skip either), so that QP_Y is never
 	// inherited across a row boundary and deblocking can follow the chain left to right
-	if (MBQP && mx == 0 && !(REFRESH && refresh) && cbp == 0)
+	if (MBQP && p.row_rule && mx == 0 && !(REFRESH && refresh) && cbp == 0)
 		cbp = 0x10;
 	WAVE_LDS_SYNC();
 
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(1024) void k_qp_eff(Params p)
 			before = max(before, s_wave[w]);
 		v = max(v, before);
 		if (i < n) {
-			p.qp_eff[base + i] = (uint8_t)(v >= 0 ? (int)p.qp_t[base + v] : p.qp);
+			p.qp_eff[base + i] = (uint8_t)(v >= 0 ? (int)p.qp_t[base + v] : pic_qp(p, st));
 		}
 		__syncthreads(); // (everybody has read s_carry and s_wave)
 		if (tid == 1023)
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 		p.i4modes[mbaddr * 16 + lane] = (int8_t)best4;
 	if (lane == 0) {
 		MbInfo m;
-		const int qp_base = p.roi_off ? roi_qp(p, mx, my) : p.qp;
+		const int qp_base = p.roi_off ? roi_qp(p, st, mx, my) : p.qp;
 		m.type = (sum4 + 32 * (p.roi_off ? p.qtab[qp_base].lambda : p.lambda) < (int)(best16 >> 2)) ? MB_I4x4 : MB_I16x16;
 		if (p.roi_off) // the QP the macroblock is quantised with: its region's, moved by its MAD class (SAD of the chosen kind of prediction)
 			p.qp_t[mbaddr] = (uint8_t)(p.mad_on ? mad_class_qp(p, qp_base, m.type == MB_I4x4 ? sum4 : (int)(best16 >> 2)) : qp_base);

@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				// macroblocks differ in QP: the first one of a row always carries an mb_qp_delta (an Intra4x4
 				// one without a coded block says "chroma DC" and codes two empty blocks), so that QP_Y never
 				// has to be inherited across a row boundary
-				if (ROI && mx == 0 && (int)(int8_t)(L.info[slot][0] & 0xffu) == MB_I4x4 && !(cbp & 0x3fu))
+				if (ROI && p.row_rule && mx == 0 && (int)(int8_t)(L.info[slot][0] & 0xffu) == MB_I4x4 && !(cbp & 0x3fu))
 					cbp = 0x10u;
 				const uint32_t w0 = (L.info[slot][0] & 0x00ffffffu) | cbp << 24;
 				*(uint64_t *)&p.mbi[mbaddr] = (uint64_t)w0 | (uint64_t)L.info[slot][1] << 32;

@@ -165,6 +165,7 @@ struct InFlight {
 	int ds = 0; // device slot (frame number % depth) holding this frame's device-side state
 	SliceHdr *h_hdr = nullptr, *dv_hdr = nullptr;   // pinned + mapped per-frame slice headers, read by the kernels in place
 	uint32_t *h_prefix = nullptr, *dv_prefix = nullptr;
+	uint8_t *h_qp_s = nullptr, *dv_qp_s = nullptr;  // rate control over several streams: the picture's QP of every stream
 	uint32_t *h_wf_err = nullptr; // pinned word the wavefront kernels write an error code to
 	uint32_t *d_wf_err = nullptr; // the same word as the device sees it
 	// completion flags in pinned host memory, written by 1-thread kernels at the end of the
@@ -217,6 +218,9 @@ struct cedar_enc {
 	uint32_t fault_at = 0;       // tests (CEDAR_FAULT_INJECT_AT)
 	int64_t rc_bits[64] = {};    // rate control: bits of the access unit of frame (index % 64) ...
 	int rc_qp[64] = {};          // ... and the QP it was coded at
+	bool rc_multi = false;       // rate control over several lock-step streams: the law runs per stream, the
+	std::vector<int64_t> rc_bits_s; // kernels take the picture's QP per stream (Params::qp_s); [stream][64] as above
+	std::vector<int> rc_qp_s;
 	int64_t rc_target = 0;       // bits per frame (0: fixed QP)
 	int cohorts = 1;             // big batches go through the stages in this many groups of streams (submit_frame)
 	size_t stream_out_cap = 0;   // bytes of output per stream: cohort c packs its streams from (first stream) x this on
@@ -369,7 +373,7 @@ void free_all(cedar_enc *e)
 	}
 	H(e->h_luma); H(e->h_chroma);
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
-		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_wf_err); H((void *)e->fl[i].h_done);
+		H(e->h_out[i]); H(e->h_sizes[i]); H(e->fl[i].h_hdr); H(e->fl[i].h_prefix); H(e->fl[i].h_qp_s); H(e->fl[i].h_wf_err); H((void *)e->fl[i].h_done);
 		if (e->fl[i].done_main)
 			hipEventDestroy(e->fl[i].done_main);
 		if (e->fl[i].done_ent)
@@ -862,8 +866,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
 		return fail(e, -EINVAL, "requantising oversize pictures wants one stream, whole pictures, no GOP lanes (one QP per launch)");
-	if (ext.bitrate < 0 || (ext.bitrate > 0 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count)))
-		return fail(e, -EINVAL, "rate control wants one stream, whole pictures, no GOP lanes");
+	if (ext.bitrate < 0 || (ext.bitrate > 0 && (G != 1 || ext.slice_num != ext.slice_count)))
+		return fail(e, -EINVAL, "rate control wants whole pictures and no GOP lanes (its law looks back in frame order)");
 	if (mb_h > 512 * ext.slice_count)
 		return fail(e, -EINVAL, "picture too tall for one slice");
 	if (ext.first_frame_index < 0 || ext.first_frame_index % cfg->keyframe_interval)
@@ -879,6 +883,15 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	e->mb_qp = ext.roi_count > 0;
 	for (int k = 0; k < 5; k++)
 		e->mb_qp = e->mb_qp || ext.mad_dqp[k] != 0;
+	const bool row_rule = e->mb_qp;
+	// rate control over several streams: every stream its own QP per picture, i.e. the kernels that look the
+	// QP up per macroblock (but no QP differs inside a picture: no row rule)
+	e->rc_multi = ext.bitrate > 0 && ext.n_streams > 1;
+	e->mb_qp = e->mb_qp || e->rc_multi;
+	if (e->rc_multi) {
+		e->rc_bits_s.assign((size_t)ext.n_streams * 64, 0);
+		e->rc_qp_s.assign((size_t)ext.n_streams * 64, 0);
+	}
 	fill_static_params(e);
 	Params &P = e->P;
 	const int S = ext.n_streams;
@@ -926,6 +939,10 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_hdr, e->fl[i].h_hdr, 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_prefix, sizeof(uint32_t) * S, hipHostMallocMapped));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_prefix, e->fl[i].h_prefix, 0));
+		if (e->rc_multi) {
+			HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_qp_s, (size_t)S, hipHostMallocMapped));
+			HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].dv_qp_s, e->fl[i].h_qp_s, 0));
+		}
 		HIP_TRY(e, hipHostMalloc((void **)&e->fl[i].h_wf_err, sizeof(uint32_t), hipHostMallocMapped));
 		*e->fl[i].h_wf_err = 0;
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].d_wf_err, e->fl[i].h_wf_err, 0));
@@ -993,6 +1010,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		HIP_TRY(e, hipMemcpy(e->d_qtab, rows.data(), rows.size() * sizeof(QpRow), hipMemcpyHostToDevice));
 		P.roi_off = e->d_roi_off;
 		P.qtab = e->d_qtab;
+		P.row_rule = row_rule ? 1 : 0;
 		for (int k = 0; k < 5; k++) {
 			P.mad_dqp[k] = ext.mad_dqp[k];
 			P.mad_on |= ext.mad_dqp[k] != 0;
@@ -1497,6 +1515,8 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	Q.ref_y += (size_t)s0 * P.plane_y_stride;
 	Q.ref_uv += (size_t)s0 * P.plane_uv_stride;
 	Q.mbi += m0;
+	if (Q.qp_s)
+		Q.qp_s += s0;
 	if (Q.qp_eff) {
 		Q.qp_eff += m0;
 		Q.qp_t += m0;
@@ -1568,6 +1588,13 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 						   : e->cfg.qp) + f.qp_bump,
 			      e->chroma_qp_offset);
 	f.qp = P.qp;
+	if (e->rc_multi) { // the law per stream; the launch's own QP (Params::qp) is not used by the per-macroblock forms
+		for (int s = 0; s < S; s++)
+			f.h_qp_s[s] = (uint8_t)rc_pick_qp(e->cfg.qp, e->rc_target, &e->rc_bits_s[(size_t)s * 64], &e->rc_qp_s[(size_t)s * 64],
+							 e->frame_count, e->cfg.keyframe_interval);
+		P.qp_s = f.dv_qp_s;
+		f.qp = f.h_qp_s[0];
+	}
 	if (e->fault_at && seq != e->fault_at) // tests: lose the hand-off of one chosen submit only
 		P.fault_inject = 0;
 	P.rec_y = e->d_rec_y[e->cur];
@@ -1702,7 +1729,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		for (int k = 0; k < e->ext.slice_num; k++) {
 			int r0, r1;
 			slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
-			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, (int)(gop & 1), r0 * P.mb_w, P.qp - e->cfg.qp);
+			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, (int)(gop & 1), r0 * P.mb_w,
+									       (e->rc_multi ? (int)f.h_qp_s[s] : P.qp) - e->cfg.qp);
 		}
 		// cedar.c:1058-1061: SPS + PPS in front of the stream's first picture (the IDR picture of GOP 0)
 		f.with_ps[s] = idr && (gop == 0 || e->ext.repeat_headers) && e->ext.slice_first == 0;
@@ -2056,6 +2084,11 @@ static int collect_frame(cedar_enc *e)
 	e->last_total = total;
 	e->rc_bits[f.before.frame_count & 63] = (int64_t)total * 8;
 	e->rc_qp[f.before.frame_count & 63] = f.qp;
+	if (e->rc_multi)
+		for (int s = 0; s < S; s++) {
+			e->rc_bits_s[(size_t)s * 64 + (f.before.frame_count & 63)] = (int64_t)e->res_size[s] * 8;
+			e->rc_qp_s[(size_t)s * 64 + (f.before.frame_count & 63)] = f.h_qp_s[s];
+		}
 	e->stats.frame_qp = f.qp;
 	if (e->profiling) {
 		static const char *const stage_name[CEDAR_ENC_STAGE_COUNT] = { "input", "intra_decide", "intra_recon", "inter", "deblock", "entropy" };

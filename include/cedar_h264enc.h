@@ -128,8 +128,9 @@ struct cedar_enc_config_ext {
 				picture gets one QP, carried by slice_qp_delta, from a law that only looks at
 				frames at least CEDAR_ENC_PIPELINE_DEPTH + 1 back -- so the bytes do not
 				depend on how many frames the caller keeps in flight. qp is the starting
-				point. One stream, all slices, no gop_parallel. 0: fixed QP, as the reference
-				(cedar.c:1165-1168)                                                      */
+				point. With n_streams > 1 the law runs per stream (every stream towards this
+				target, its own QP per picture). All slices, no gop_parallel (the law looks
+				back in frame order). 0: fixed QP, as the reference (cedar.c:1165-1168)       */
 	int intra_refresh;   /* N >= 3: cyclic intra refresh -- the VE has a register for it that the reference
 				never writes (cedar_regs.h:43 CEDAR_H264ENC_CYCLICINTRAREFRESH, SURVEY
 				8(f)-4). In the t-th P picture after an IDR the macroblocks with

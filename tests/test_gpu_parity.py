@@ -700,8 +700,44 @@ def test_rate_control_follows_the_oracle_at_any_depth(ce, w, h, target):
     assert got == want
     with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target) as enc:
         assert [enc.encode_frame(y, uv) for y, uv in frames[:24]] == want[:24]
-    with pytest.raises(ce.EncoderError):     # one QP per launch: one stream, whole pictures
-        ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, n_streams=2)
+    with pytest.raises(ce.EncoderError):     # the law looks back in frame order: no GOP lanes
+        ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, gop_parallel=2)
+
+
+@pytest.mark.parametrize("w,h,S,target,extra", [(320, 240, 3, 500000, {}), (192, 112, 9, 150000, {}),
+                                                (320, 240, 2, 700000, dict(roi=((2, 2, 8, 6, -6),), subpel=1))])
+def test_rate_control_over_several_streams(ce, w, h, S, target, extra):
+    """bitrate > 0 with n_streams > 1: the law runs per stream (its own sizes, its own QP per picture, in its own
+    slice_qp_delta); the kernels take the picture's QP per stream where they otherwise take the launch's
+    (Params::qp_s, the per-macroblock-QP forms). Every stream equals the one-stream oracle with the same target."""
+    n = 44
+    pats = "BCA"
+    src = [[ol.gen_frame(pats[s % 3], w, h, f, s << 8) for s in range(S)] for f in range(n)]
+    okw = {k: (list(v) if k == "roi" else v) for k, v in extra.items()}
+    want, qps = [], []
+    for s in range(S):
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25, bitrate=target, **okw))
+        aus, q = [], []
+        for f in range(n):
+            aus.append(oe.encode(*src[f][s]))
+            q.append(oe.frame_qp())
+        want.append(aus)
+        qps.append(q)
+    assert len({tuple(q) for q in qps}) > 1      # the streams really go different ways
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, n_streams=S, **extra) as enc:
+        depth, got, q = enc.pipeline_depth, [], 0
+        for f in range(n):
+            if q == depth:
+                enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
+            for s in range(S):
+                enc.set_input(src[f][s][0], src[f][s][1], stream=s)
+            enc.submit(); q += 1
+        while q:
+            enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
+        assert enc.stats()["frame_qp"] == qps[0][-1]
+    for s in range(S):
+        bad = [f for f in range(n) if got[f][s] != want[s][f]]
+        assert not bad, (s, bad[:5])
 
 
 def test_macroblocks_above_3200_bits_are_counted_or_refused(ce):

@@ -48,7 +48,7 @@ for case in range(n_cases):
         pick = int(rng.randint(0, 4))
         if S == 1 and pick == 1:
             kw.update(strict_mb_bits=2)
-        elif S == 1 and pick == 2:
+        elif S <= 9 and pick == 2:   # (rate control runs per stream)
             n = int(rng.randint(19, 30))
             kw.update(bitrate=int(rng.choice([1, 4, 20])) * w * h)
         elif pick == 3 and S <= 3:
