@@ -190,14 +190,18 @@ DEVI int mv_far(int a, int b)
 
 constexpr int DB2_PAIRS_MAX = WF_WAVES / 2;
 
-struct Db2GroupLds {
-	uint8_t y[3][20 * DT_STRIDE];
-	uint8_t c[3][10 * DC_STRIDE];
-	uint8_t bot[4][4 * 16];
-	uint8_t botc[4][2 * 16];
-	uint32_t bsv[3][16];  // per lane (= sample row): edge codes of the 4 vertical luma edges, one byte each
-	uint32_t bsh[3][16];  // per lane (= sample column): the 4 horizontal luma edges
-	uint32_t bsc[3][16];  // chroma codes: bytes 0,1 vertical edges 0,2 (lane = plane, row); bytes 2,3 horizontal 0,2 (lane = column)
+// (PL: the planes a workgroup filters, 1 luma, 2 chroma, 3 both. A one-plane workgroup only carries its plane's
+// tiles: 2.6 KB resp. 1.3 KB per row group instead of 3.9 -- in the small form that is what lets it into the
+// room ONE retiring k_inter workgroup leaves on a full CU, 22 KB + the CU's 7.7 KB of slack)
+template <int PL>
+struct __attribute__((aligned(16))) Db2GroupLds {
+	uint8_t y[(PL & 1) ? 3 : 1][(PL & 1) ? 20 * DT_STRIDE : 16];
+	uint8_t c[(PL & 2) ? 3 : 1][(PL & 2) ? 10 * DC_STRIDE : 16];
+	uint8_t bot[4][(PL & 1) ? 4 * 16 : 16];
+	uint8_t botc[4][(PL & 2) ? 2 * 16 : 16];
+	uint32_t bsv[(PL & 1) ? 3 : 1][16];  // per lane (= sample row): edge codes of the 4 vertical luma edges, one byte each
+	uint32_t bsh[(PL & 1) ? 3 : 1][16];  // per lane (= sample column): the 4 horizontal luma edges
+	uint32_t bsc[(PL & 2) ? 3 : 1][16];  // chroma codes: bytes 0,1 vertical edges 0,2 (lane = plane, row); bytes 2,3 horizontal 0,2 (lane = column)
 	__attribute__((aligned(16))) uint32_t ab[3][4]; // MODE 3: alpha | beta << 8 of the left edge, the same << 16 of the top edge; of the inner edges; chroma likewise
 };
 
@@ -249,7 +253,7 @@ DEVI void lds_signal(int *word, int value, int lane)
 // or 2 (a workgroup small enough to find room beside the analysis of other units)
 template <int PL, int PAIRS>
 struct Db2Shared {
-	Db2GroupLds g[PAIRS * 4];
+	Db2GroupLds<PL> g[PAIRS * 4];
 	// bottom rows of a band's last macroblock row, for the pair that filters the band below
 	// (a pair with few partners is back at its ring while the band below its previous one still reads
 	// it: two rings, taken in turn)
@@ -275,7 +279,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
 
 	Db2Shared<PL, PAIRS> &S = *reinterpret_cast<Db2Shared<PL, PAIRS> *>(dyn_lds);
-	Db2GroupLds *s_g = S.g;
+	Db2GroupLds<PL> *s_g = S.g;
 	auto &s_xbot = S.xbot;
 	auto &s_xbotc = S.xbotc;
 	int *s_staged = S.staged, *s_filtered = S.filtered, *s_vdone = S.vdone;
@@ -317,8 +321,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
 
-	Db2GroupLds &L = s_g[pair * 4 + g];
-	const Db2GroupLds &LU = s_g[pair * 4 + (g > 0 ? g - 1 : 0)];
+	Db2GroupLds<PL> &L = s_g[pair * 4 + g];
+	const Db2GroupLds<PL> &LU = s_g[pair * 4 + (g > 0 ? g - 1 : 0)];
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	const int nbands = (r1 - r0 + 3) >> 2;
@@ -1721,15 +1725,19 @@ template <int PAIRS>
 static int launch_deblock(const Params &p, hipStream_t s, int planes)
 {
 	const int nwg = p.n_streams * p.slice_num * p.wf_split;
-	// 8 pairs: ~130 KiB of dynamic LDS, one workgroup per CU by construction; 2 pairs: ~33 KiB
-	const size_t lds = sizeof(Db2Shared<1, PAIRS>) > sizeof(Db2Shared<3, PAIRS>) ? sizeof(Db2Shared<1, PAIRS>) : sizeof(Db2Shared<3, PAIRS>);
-	static_assert(sizeof(Db2Shared<1, PAIRS>) <= 160 * 1024 && sizeof(Db2Shared<3, PAIRS>) <= 160 * 1024, "a CU has 160 KiB of LDS");
+	// dynamic LDS of what the workgroups of this launch filter (planes 4: luma workgroups and chroma workgroups,
+	// the bigger of the two). 8 pairs, both planes: ~134 KiB, one workgroup per CU by construction; 2 pairs:
+	// 37 KiB for both planes in one workgroup, 25 KiB for luma, 13 KiB for chroma
+	constexpr size_t l1 = sizeof(Db2Shared<1, PAIRS>), l2 = sizeof(Db2Shared<2, PAIRS>), l3 = sizeof(Db2Shared<3, PAIRS>);
+	const size_t lds = planes == 3 ? l3 : planes == 1 ? l1 : planes == 2 ? l2 : (l1 > l2 ? l1 : l2);
+	const size_t lds_max = l3 > l1 ? l3 : l1;
+	static_assert(l1 <= 160 * 1024 && l3 <= 160 * 1024 && l2 <= l3, "a CU has 160 KiB of LDS");
 	static bool attr_set = false;
 	if (!attr_set) {
-		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<1, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<3, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<1, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<3, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
 			return -1;
 		attr_set = true;
 	}

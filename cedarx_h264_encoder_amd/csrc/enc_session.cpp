@@ -1155,7 +1155,12 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	}
 	{
 		const char *env = getenv("CEDAR_DEBLOCK_PLANES");
-		e->split_planes = env ? atoi(env) != 0 : n_units <= 32; // two concurrent wavefronts while CUs are spare
+		// Luma and chroma as separate workgroups (two concurrent wavefronts) while CUs are spare; both planes
+		// in every wave pair from 32 units on, where the cohorts overlap deblocking with the other half's
+		// search: 32 x 1080p 152 M MB/s against 136-139 M with one-plane workgroups (twice as many of them
+		// waiting for room beside k_inter), 64: 161 against 156; 16 (no cohorts): 122 with one plane per
+		// workgroup against 112
+		e->split_planes = env ? atoi(env) != 0 : n_units < 32;
 	}
 	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_host_in, hipEventDisableTiming));
 	if (getenv("CEDAR_TRACE_TIMELINE")) {

@@ -254,7 +254,7 @@ struct cedar_enc_stats {
 	int      depth;                          /* frames in flight this session allows               */
 	int      deblock_streams;                /* deblock streams in use                             */
 	uint64_t oversize_frames;                /* frames with a macroblock above 3200 bits (A.3.1)   */
-	int      frame_qp;                       /* slice QP of the frame collected last (rate control) */
+	int      frame_qp;                       /* slice QP of the frame collected last (rate control; of stream 0 when several streams are steered) */
 	uint64_t requantised_frames;             /* re-encodes because of a macroblock above 3200 bits  */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
