@@ -1,0 +1,49 @@
+"""A discrete model of the one-stream frame pipeline (development aid): deblock kernels D(n) on
+nstreams streams, the P picture's analysis in K stripes on ONE in-order stream, each stripe gated on D(n-1) and
+published to D(n). Reproduces the measured 0.22-0.25 ms period of 1080p and its fast / slow alternation
+(e.g. 140 / 290 us between the ends of consecutive deblock kernels), for both ways of counting progress."""
+import sys
+def sim(metric, nstreams, K, tau=1.9, inter_us=None, gap=8.0, nframes=40, mbw=120, mbh=68):
+    nb=(mbh+3)//4
+    steps = mbw + 3 + 5*(nb-1)       # global steps of a deblock kernel
+    if metric=="x2y":
+        rng = mbw-1+2*(mbh-1)+1
+        need_of = lambda T: max(T - 5*b + 3 + 8*b + 1 for b in range(nb) if 0 <= T-5*b < mbw+3) if any(0 <= T-5*b < mbw+3 for b in range(nb)) else 0
+        gate_T = lambda s1: s1 + 5 + 1 + 4     # top band: D = T-1 >= s1+5, publish granularity ~4
+    else:
+        rng = mbw-1+(mbh-1)+1
+        need_of = lambda T: max(T - 5*b + 4*b + 1 for b in range(nb) if 0 <= T-5*b < mbw+3) if any(0 <= T-5*b < mbw+3 for b in range(nb)) else 0
+        gate_T = lambda s1: s1 + 4 + (nb-1) + 1 + 4   # bottom band: E = T-b-1 >= s1+4
+    s = [rng*k//K for k in range(K+1)]
+    inter = inter_us if inter_us else 100.0/K + 8
+    E=[0.0]*nframes; S=[0.0]*nframes
+    prog=[None]*nframes   # list of (time at which global step T completed)
+    ana_pub=[None]*nframes # list of (time, published value)
+    t_ana_free=0.0
+    for n in range(nframes):
+        # analysis of frame n
+        pubs=[]
+        t=t_ana_free
+        for k in range(K):
+            if n>0:
+                Tn = min(gate_T(s[k+1]), steps)      # step of D(n-1) that must be done
+                t=max(t, prog[n-1][Tn-1]+2.0)
+            t+=gap+inter
+            pubs.append((t+gap, s[k+1] if k<K-1 else 10**6))
+        t_ana_free=t+gap
+        ana_pub[n]=pubs
+        # deblock of frame n
+        start = E[n-nstreams] + 6 if n>=nstreams else 0.0
+        S[n]=start
+        times=[]; t=start
+        for T in range(steps):
+            nd=need_of(T)
+            # time when published >= nd
+            tp=next(tt for tt,v in pubs if v>=nd)
+            t=max(t,tp)+tau
+            times.append(t)
+        prog[n]=times; E[n]=t
+    return (E[-1]-E[-11])/10
+for metric in ("x2y","xy"):
+    for ns in (2,3,4):
+        print(metric, ns, [round(sim(metric,ns,K),1) for K in (3,5,8,12)])
