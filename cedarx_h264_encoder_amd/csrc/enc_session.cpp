@@ -15,7 +15,6 @@
 #include <time.h>
 
 #include <vector>
-#include <algorithm>
 
 #include <sched.h>
 
@@ -274,18 +273,6 @@ struct cedar_enc {
 	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
 	int wf_split = 1, wf_split_intra = 1;
 	int db_pairs = 8;
-	// Pipelined P pictures: the last stripes of a picture's analysis (from defer_from on), its final gate
-	// and its entropy launches are held back and enqueued BETWEEN the first stripes of the next picture:
-	// a picture's last stripe is gated on the END of the previous picture's deblocking, and on an in-order
-	// stream the next picture's first stripe -- which only needs that deblocking a quarter through -- would
-	// sit behind it. (submit_frame; emitted at the latest when the frame is collected.)
-	int defer_from = 0;          // first deferred stripe; inter_bands = nothing is deferred
-	struct DeferredTail {
-		bool active = false;
-		Params Pc{};
-		hipStream_t s_ana = nullptr, s_ent = nullptr;
-		int slot = 0, ei = 0, next = 0;
-	} deferred;
 	// pinned host memory
 	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
 	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = {}, *dv_out[CEDAR_ENC_PIPELINE_DEPTH] = {};     // pinned + mapped, and its device view
@@ -1327,11 +1314,10 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth, e->cohorts);
 	}
 	{
-		// diagonal stripes s = x + y of a P picture (the slope of the deblock sweep it follows and is
-		// followed by) and, per stripe, how many of its macroblocks lie in the rows before row r: k_inter
-		// enumerates a stripe without holes
+		// diagonal stripes s = x + 2*y of a P picture and, per stripe, how many of its macroblocks
+		// lie in the rows before row r: k_inter enumerates a stripe without holes
 		const int nb = e->inter_bands;
-		const int d_lo = P.row_first, d_hi = P.mb_w - 1 + (P.row_first + P.row_num - 1) + 1;
+		const int d_lo = 2 * P.row_first, d_hi = P.mb_w - 1 + 2 * (P.row_first + P.row_num - 1) + 1;
 		e->stripe_s.assign((size_t)nb + 1, 0);
 		e->stripe_n.assign((size_t)nb, 0);
 		std::vector<uint32_t> tab((size_t)nb * (P.row_num + 1), 0);
@@ -1343,39 +1329,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 				tab[(size_t)k * (P.row_num + 1) + r] = run;
 				const int y = P.row_first + r;
 				auto cl = [&](int v) { return v < 0 ? 0 : v > P.mb_w ? P.mb_w : v; };
-				run += (uint32_t)(cl(e->stripe_s[k + 1] - y) - cl(e->stripe_s[k] - y));
+				run += (uint32_t)(cl(e->stripe_s[k + 1] - 2 * y) - cl(e->stripe_s[k] - 2 * y));
 			}
 			e->stripe_n[k] = (int)tab[(size_t)k * (P.row_num + 1) + P.row_num];
-		}
-		// Which stripes may be held back (see DeferredTail). Own stripe j of the next picture is enqueued
-		// after this picture's stripes up to defer_from + j - 1; its gate waits for this picture's
-		// deblocking to have ALL bands at x + y >= s1(j) + 4, i.e. its top band nb - 1 + 5 steps further,
-		// plus the 8 steps between two publications, and that deblocking asks for its own analysis up to
-		// one diagonal more: everything below s1(j) + nb + 14 must already be in the queue, or the stream
-		// waits for itself.
-		{
-			const char *envd = getenv("CEDAR_DEFER");
-			int bands_max = 0;
-			for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
-				int a, b;
-				slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
-				bands_max = std::max(bands_max, (b - a + 3) / 4);
-			}
-			// (all of it assumes the deblock sweep of a unit is ONE front, every band 5 steps behind the band
-			// above: a workgroup with more bands than wave pairs starts band b + pairs when band b is through)
-			const bool one_front = (bands_max + e->wf_split - 1) / e->wf_split <= e->db_pairs;
-			// OFF unless asked for (CEDAR_DEFER = number of stripes to hold back): between two submits the
-			// device then holds kernels that wait for work only the NEXT submit enqueues, and a device-wide
-			// synchronisation by anybody in the process in between (hipDeviceSynchronize, torch.cuda.synchronize,
-			// an allocation that implies one) waits for them until their wall-clock bound. A caller that feeds
-			// frames from a loop of its own without such calls -- the command line, bench.py -- can take it.
-			int kd = nb;
-			if (envd && atoi(envd) > 0 && atoi(envd) < nb && nb >= 3 && one_front)
-				kd = nb - atoi(envd);
-			for (int j = 0; j < kd && kd < nb; j++)
-				if (e->stripe_s[j + 1] + bands_max + 14 > e->stripe_s[std::min(nb, kd + j)])
-					kd = nb;
-			e->defer_from = kd;
 		}
 		if (e->d_stripe_tab) { hipFree(e->d_stripe_tab); e->d_stripe_tab = nullptr; }
 		if ((rc = dalloc(e, &e->d_stripe_tab, tab.size()))) return rc;
@@ -1603,60 +1559,6 @@ struct ReplayIn {
 	int qp_bump = 0;
 };
 
-// The stripes [k0, k1) of a pipelined P picture's analysis: a gate (publish how far this picture's
-// analysis is, wait for the previous picture's deblocking) and the search of the stripe, each.
-static int emit_stripes(cedar_enc *e, Params &Pc, hipStream_t s_ana, int k0, int k1)
-{
-	const int S = e->ext.n_streams;
-	for (int k = k0; k < k1; k++) {
-		Pc.stripe_s0 = e->stripe_s[k];
-		Pc.stripe_s1 = e->stripe_s[k + 1];
-		Pc.stripe_tab = e->d_stripe_tab + (size_t)k * (Pc.row_num + 1);
-		if (Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 4))
-			return fail(e, -EIO, "k_gate launch failed");
-		if (e->stripe_n[k] > 0 && Launch::inter(Pc, s_ana, e->stripe_n[k] * S))
-			return fail(e, -EIO, "k_inter launch failed");
-	}
-	return 0;
-}
-
-// What follows the last stripe of a pipelined P picture: the gate that publishes "all of it", the
-// analysis event, the entropy launches behind it.
-static int emit_tail(cedar_enc *e, Params &Pc, hipStream_t s_ana, hipStream_t s_ent, int slot, int ei)
-{
-	InFlight &f = e->fl[slot];
-	if (Launch::gate(Pc, s_ana, PROG_ALL, 0))
-		return fail(e, -EIO, "k_gate launch failed");
-	Pc.stripe_s0 = Pc.stripe_s1 = 0;
-	tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
-	HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
-	HIP_TRY(e, hipStreamWaitEvent(s_ent, e->ev_analysis[ei], 0));
-	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
-	if (Pc.roi_off && Launch::qp_eff(Pc, s_ent))
-		return fail(e, -EIO, "k_qp_eff launch failed");
-	if (Launch::entropy(Pc, s_ent))
-		return fail(e, -EIO, "entropy launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
-	Pc.done_flag = f.d_done;
-	Pc.done_tag = f.done_tag;
-	if (Launch::copy_out(Pc, s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
-		return fail(e, -EIO, "k_copy_out launch failed");
-	return 0;
-}
-
-// the held-back part of the newest pipelined P picture, now (nothing will be enqueued in front of it)
-static int flush_deferred(cedar_enc *e)
-{
-	cedar_enc::DeferredTail &dt = e->deferred;
-	if (!dt.active)
-		return 0;
-	dt.active = false;
-	int rc = emit_stripes(e, dt.Pc, dt.s_ana, dt.next, e->inter_bands);
-	if (!rc)
-		rc = emit_tail(e, dt.Pc, dt.s_ana, dt.s_ent, dt.slot, dt.ei);
-	return rc;
-}
-
 static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 {
 	if (e->fl_count >= e->depth)
@@ -1870,14 +1772,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	// offset pointers; scratch that a launch counts or compacts in (tickets, size words, the packed
 	// output) is per cohort.
 	const int C = e->cohorts;
-	// a held-back tail only waits for the first stripes of a pipelined P picture; anything else: out with it
-	if (e->deferred.active && !(pipe && !idr && C == 1)) {
-		const int rc_f = flush_deferred(e);
-		if (rc_f)
-			return rc_f;
-	}
 	for (int c = 0; c < C; c++) {
-		bool tail_done = false;
 		Params Pc = cohort_params(e, P, c);
 		const int ei = ds * MAX_COHORTS + c, eprev = prev * MAX_COHORTS + c;
 		if (Launch::input(Pc, s_in))
@@ -1963,52 +1858,26 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			if (c == 0)
 				tm_begin(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
 			if (pipe) {
-				// diagonal stripes s = x + y: the order in which the deblock wavefront of the
-				// previous frame releases the reference and in which this frame's own can follow.
-				// The previous picture's held-back stripes go in between this picture's first ones
-				// (cedar_enc::DeferredTail), this picture's last ones are held back in turn.
-				const int nb = e->inter_bands, kd = e->defer_from;
-				cedar_enc::DeferredTail &dt = e->deferred;
-				int own = 0, rc_s = 0;
-				if (dt.active) {
-					dt.active = false;
-					while (!rc_s && dt.next < nb) {
-						if (own < kd) {
-							rc_s = emit_stripes(e, Pc, s_ana, own, own + 1);
-							own++;
-						}
-						if (!rc_s)
-							rc_s = emit_stripes(e, dt.Pc, dt.s_ana, dt.next, dt.next + 1);
-						dt.next++;
-					}
-					if (!rc_s)
-						rc_s = emit_tail(e, dt.Pc, dt.s_ana, dt.s_ent, dt.slot, dt.ei);
+				// diagonal stripes s = x + 2*y: the order in which the deblock wavefront of the
+				// previous frame releases the reference and in which this frame's own can follow
+				const int nb = e->inter_bands;
+				for (int k = 0; k < nb; k++) {
+					Pc.stripe_s0 = e->stripe_s[k];
+					Pc.stripe_s1 = e->stripe_s[k + 1];
+					Pc.stripe_tab = e->d_stripe_tab + (size_t)k * (Pc.row_num + 1);
+					if (Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 5))
+						return fail(e, -EIO, "k_gate launch failed");
+					if (e->stripe_n[k] > 0 && Launch::inter(Pc, s_ana, e->stripe_n[k] * S))
+						return fail(e, -EIO, "k_inter launch failed");
 				}
-				if (!rc_s && own < kd)
-					rc_s = emit_stripes(e, Pc, s_ana, own, kd);
-				if (rc_s)
-					return rc_s;
-				if (kd < nb) {
-					dt.active = true;
-					dt.Pc = Pc;
-					dt.s_ana = s_ana;
-					dt.s_ent = s_ent;
-					dt.slot = slot;
-					dt.ei = ei;
-					dt.next = kd;
-				} else if ((rc_s = emit_tail(e, Pc, s_ana, s_ent, slot, ei))) {
-					return rc_s;
-				}
-				tail_done = true;
+				if (Launch::gate(Pc, s_ana, PROG_ALL, 0))
+					return fail(e, -EIO, "k_gate launch failed");
+				Pc.stripe_s0 = Pc.stripe_s1 = 0;
 			} else if (Launch::inter(Pc, s_ana, Pc.mb_w * Pc.row_num * Pc.n_streams)) {
 				return fail(e, -EIO, "k_inter launch failed");
 			}
-			if (c == C - 1 && !tail_done)
+			if (c == C - 1)
 				tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
-		}
-		if (tail_done) { // a pipelined P picture: emit_tail has (or will have) done the rest
-			t_main = t_ent = now_ms();
-			continue;
 		}
 		HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
 		t_main = now_ms();
@@ -2078,7 +1947,6 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 // the failed frame, and encode the frames behind it again from the inputs the session still holds.
 static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again = nullptr)
 {
-	flush_deferred(e); // (the device must be able to drain; whatever this enqueues is dropped with the rest)
 	hipDeviceSynchronize();
 	std::vector<ReplayIn> later;
 	if (again) // the failed frame itself goes first (requantised, see collect_frame)
@@ -2133,11 +2001,6 @@ static int collect_frame(cedar_enc *e)
 	const int slot = e->fl_head;
 	InFlight &f = e->fl[slot];
 	HIP_TRY(e, hipSetDevice(e->device));
-	if (e->deferred.active && e->deferred.slot == slot) { // the newest frame is the one being waited for
-		const int rc_f = flush_deferred(e);
-		if (rc_f)
-			return rc_f;
-	}
 	bool hip_failed = false;
 	{
 		// poll the frame's own completion flags (see InFlight::h_done); fall back to the events
@@ -2435,8 +2298,7 @@ extern "C" int cedar_enc_flush(cedar_enc *e)
 		return -EINVAL;
 	if (e->mux)
 		e->mux->flushed = true;
-	hipSetDevice(e->device);
-	return flush_deferred(e); // no further submit will come to put its first stripes in front of the held-back ones
+	return 0;
 }
 
 extern "C" int cedar_enc_encode(cedar_enc *e)
@@ -2496,7 +2358,6 @@ extern "C" void cedar_enc_close(cedar_enc *e)
 		return;
 	if (e->configured) {
 		hipSetDevice(e->device);
-		flush_deferred(e); // (frames abandoned in flight: the device must still be able to drain)
 		hipDeviceSynchronize();
 	}
 	if (e->holds_pipe_token)

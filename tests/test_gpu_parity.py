@@ -175,26 +175,6 @@ def test_4k_single_slice_row_count_not_multiple_of_four(ce):
             assert np.array_equal(duv, ge.debug_read("recon_uv"))
 
 
-@pytest.mark.parametrize("w,h,keyint,defer,dbs", [(1920, 1080, 25, "2", "3"), (1920, 1080, 4, "2", "2"), (854, 480, 25, "3", "3"), (320, 240, 5, "2", "2")])
-def test_held_back_stripes_give_the_same_bytes(ce, monkeypatch, w, h, keyint, defer, dbs):
-    """CEDAR_DEFER (off by default): the last stripes of a pipelined P picture's analysis and its entropy launches are
-    enqueued between the first stripes of the NEXT picture, so that they do not sit in front of them on the in-order
-    analysis stream. Same bytes, with frames kept in flight and collected one by one, across IDR
-    pictures, with the tail flushed by collect when no further submit comes."""
-    monkeypatch.setenv("CEDAR_DEFER", defer)
-    monkeypatch.setenv("CEDAR_DEBLOCK_STREAMS", dbs)
-    n = 30
-    frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
-    oe = ol.OracleEncoder(ol.default_config(w, h, qp=27, keyint=keyint))
-    want = [oe.encode(y, uv) for y, uv in frames]
-    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=keyint) as enc:
-        got = _encode_pipelined(enc, frames)
-        assert got == want
-    # one at a time: every frame's held-back part is flushed by its own collect
-    with ce.CedarEncoder(width=w, height=h, qp=27, keyframe_interval=keyint) as enc:
-        assert [enc.encode_frame(y, uv) for y, uv in frames[:8]] == want[:8]
-
-
 @pytest.mark.parametrize("pairs", ["8", "2"])
 def test_wide_picture_with_more_bands_than_wave_pairs(ce, monkeypatch, pairs):
     """3840x592 (240 x 37 macroblocks, 10 deblock bands) asked to run as ONE deblock workgroup: a band
