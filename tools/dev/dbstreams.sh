@@ -1,3 +1,4 @@
+# sweeps behind DESIGN 5.2 (CEDAR_DEFER only exists with tools/dev/xy_defer.patch applied)
 cd $GRAFT_REPO_ROOT
 B="--cpu-frames 0 --batched-streams 0 --gop-parallel 0"
 one() { python3 -c "
