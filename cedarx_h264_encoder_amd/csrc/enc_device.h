@@ -279,7 +279,10 @@ DEVI int mb_qp_delta(const Params &p, int st, int mx, int my, int row0, size_t m
 {
 	if (!p.roi_off)
 		return 0;
-	return (int)p.qp_t[mbaddr] - ((mx == 0 && my == row0) ? pic_qp(p, st) : (int)p.qp_eff[mbaddr - 1]);
+	const int d = (int)p.qp_t[mbaddr] - ((mx == 0 && my == row0) ? pic_qp(p, st) : (int)p.qp_eff[mbaddr - 1]);
+	// 7.4.5: the syntax element lies in -26..+25, QP_Y = (QP_Y,pred + mb_qp_delta + 52) % 52: a larger
+	// step (two regions at +24 and -24 side by side) goes round the other way
+	return d > 25 ? d - 52 : d < -26 ? d + 52 : d;
 }
 
 DEVI int median3(int a, int b, int c)

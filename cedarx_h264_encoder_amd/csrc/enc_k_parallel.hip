@@ -111,6 +111,22 @@ int Launch::input(const Params &p, void *stream)
 // ------------------------------------------------------------------------
 #define REF_STRIDE 48
 #define REFC_STRIDE 64
+// per-wave LDS arena of k_inter (bytes)
+#define S8_STRIDE 96                       // bytes per row of the 8x8 box sums: 48 x u16
+#define IA_REF 0                           // 48 x 48 window + 64 bytes of slack
+#define IA_CUR (48 * REF_STRIDE + 64)      // 16 x 16 source samples
+#define IA_CURC (IA_CUR + 256)             // 8 rows x 8 CbCr pairs
+#define IA_U (IA_CURC + 128)               // the union: box sums (41 rows), then the survivor list and the cost tables ...
+#define IA_LIST 0                          //   u16[320]
+#define IA_LAMX 640                        //   u32[36]
+#define IA_LAMY (640 + 144)                //   u32[36]
+#define IA_REFC 0                          // ... then the chroma window, the levels, the reconstruction, the counts
+#define IA_COEF (25 * REFC_STRIDE)
+#define IA_RECY (IA_COEF + 816)
+#define IA_RECC (IA_RECY + 256)
+#define IA_NNZ (IA_RECC + 128)
+#define IA_BYTES (IA_U + 41 * S8_STRIDE)
+static_assert(IA_NNZ + 32 <= 41 * S8_STRIDE && (IA_U & 15) == 0 && (IA_COEF & 15) == 0 && (IA_BYTES & 15) == 0, "k_inter arena");
 
 // k_inter: macroblock number i of this launch -> (mx, my, st). A launch covers the whole
 // picture (stripe_s1 <= 0) or the diagonals stripe_s0 <= x + 2*y < stripe_s1 of every stream,
@@ -259,24 +275,21 @@ template <int SUBPEL, bool REFRESH, bool MBQP>
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
 	// one wave per macroblock, INTER_WAVES macroblocks per workgroup; each wave has its own
-	// slice of every array and never looks at another wave's
-	__shared__ __attribute__((aligned(16))) uint8_t sa_ref[INTER_WAVES][48 * REF_STRIDE + 64];
-	__shared__ __attribute__((aligned(16))) uint8_t sa_refc[INTER_WAVES][25 * REFC_STRIDE];
-	__shared__ __attribute__((aligned(16))) uint8_t sa_cur[INTER_WAVES][256];
-	__shared__ __attribute__((aligned(16))) uint8_t sa_curc[INTER_WAVES][128];
-	__shared__ __attribute__((aligned(16))) int16_t sa_coef[INTER_WAVES][COEF_PER_MB];
-	__shared__ __attribute__((aligned(16))) uint8_t sa_recy[INTER_WAVES][256];
-	__shared__ __attribute__((aligned(16))) uint8_t sa_recc[INTER_WAVES][128];
-	__shared__ __attribute__((aligned(8))) uint8_t sa_nnz[INTER_WAVES][NNZ_PER_MB];
+	// arena and never looks at another wave's. The box sums of the search and what the transform
+	// stage needs never live at the same time: one union (6 workgroups fit the CU's 160 KB).
+	__shared__ __attribute__((aligned(16))) uint8_t sa_arena[INTER_WAVES][IA_BYTES];
 	// half-sample planes b, h, j (18 rows each, 4 bytes of slack for the funnel-shift reads)
 	__shared__ __attribute__((aligned(16))) uint8_t sa_sub[SUBPEL ? INTER_WAVES : 1][SUBPEL ? 3 * 18 * SP_STRIDE + 16 : 16];
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows
-	uint8_t *const s_ref = sa_ref[wave], *const s_refc = sa_refc[wave], *const s_cur = sa_cur[wave], *const s_curc = sa_curc[wave];
-	int16_t *const s_coef = sa_coef[wave];
-	uint8_t *const s_recy = sa_recy[wave], *const s_recc = sa_recc[wave];
-	uint8_t *const s_nnz = sa_nnz[wave];
+	uint8_t *const arena = sa_arena[wave];
+	uint8_t *const s_ref = arena + IA_REF, *const s_cur = arena + IA_CUR, *const s_curc = arena + IA_CURC;
+	uint8_t *const s_s8 = arena + IA_U;                              // search only
+	uint8_t *const s_refc = arena + IA_U + IA_REFC;                  // from here on: after the search
+	int16_t *const s_coef = (int16_t *)(arena + IA_U + IA_COEF);
+	uint8_t *const s_recy = arena + IA_U + IA_RECY, *const s_recc = arena + IA_U + IA_RECC;
+	uint8_t *const s_nnz = arena + IA_U + IA_NNZ;
 	// XCD-aware workgroup order (see xcd_mb): workgroups sharing an XCD own one contiguous run
 	const uint32_t nb = gridDim.x, hb = blockIdx.x;
 	const uint32_t xcd = hb & 7u, bi = hb >> 3, q = nb >> 3, r = nb & 7u;
@@ -316,9 +329,13 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		*(u32x4 *)(s_cur + lane * 16) = *(const u32x4 *)(src_y + (uint32_t)(y0 + lane) * cw + (uint32_t)x0);
 	else if (lane < 24)
 		*(u32x4 *)(s_curc + (lane - 16) * 16) = *(const u32x4 *)(src_uv + (uint32_t)(my * 8 + lane - 16) * cw + (uint32_t)x0);
+	// Reference window. Samples outside the picture are never used (a candidate that touches them
+	// is not valid), so the loads are unconditional from clamped coordinates: no branches.
+	// chroma: 25 rows x 4 segments; lane -> (row = lane / 4 + 16 * pass, seg = lane % 4). It waits in
+	// registers until the search is over (its place in LDS holds the search's box sums until then).
+	const int crow = lane >> 2, cseg = lane & 3;
+	u32x4 cwin[2];
 	{
-		// Reference window. Samples outside the picture are never used (a candidate that touches them
-		// is not valid), so the loads are unconditional from clamped coordinates: no branches.
 		// luma: 48 rows x 3 segments of 16 bytes; lane -> (row = lane / 3 + 21 * pass, seg = lane % 3), 63 lanes
 		const int wrow = min(lane, 62) / 3, wseg = min(lane, 62) - 3 * wrow;
 		const uint32_t gx = (uint32_t)min(max(x0 - 16 + 16 * wseg, 0), p.cw - 16);
@@ -328,107 +345,200 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 			const int gy = min(max(y0 - 16 + wrow + 21 * pass, 0), p.ch - 1);
 			v[pass] = *(const u32x4 *)(ref_y + (uint32_t)gy * cw + gx);
 		}
-		// chroma: 25 rows x 4 segments; lane -> (row = lane / 4 + 16 * pass, seg = lane % 4)
-		const int crow = lane >> 2, cseg = lane & 3;
 		const uint32_t cgx = (uint32_t)min(max(x0 - 16 + 16 * cseg, 0), p.cw - 16);
-		u32x4 c[2];
 #pragma unroll
 		for (int pass = 0; pass < 2; pass++) {
 			const int gy = min(max(my * 8 - 8 + crow + 16 * pass, 0), (p.ch >> 1) - 1);
-			c[pass] = *(const u32x4 *)(ref_uv + (uint32_t)gy * cw + cgx);
+			cwin[pass] = *(const u32x4 *)(ref_uv + (uint32_t)gy * cw + cgx);
 		}
 		*(u32x4 *)(s_ref + wrow * REF_STRIDE + 16 * wseg) = v[0];
 		*(u32x4 *)(s_ref + (wrow + 21) * REF_STRIDE + 16 * wseg) = v[1];
 		if (wrow < 6) // rows 42..47 (lane 63 repeats lane 62's store)
 			*(u32x4 *)(s_ref + (wrow + 42) * REF_STRIDE + 16 * wseg) = v[2];
-		*(u32x4 *)(s_refc + crow * REFC_STRIDE + 16 * cseg) = c[0];
-		if (crow < 9) // rows 16..24
-			*(u32x4 *)(s_refc + (crow + 16) * REFC_STRIDE + 16 * cseg) = c[1];
 		// (the last dx group reads one dword past row 47: the 64 bytes of slack behind the window)
 	}
 	WAVE_LDS_SYNC();
 
-	// ---- motion search ----
-	// The current macroblock is the same for every lane: its 64 dwords live in scalar registers and
-	// enter v_qsad_pk_u16_u8 as the scalar operand. A lane owns the 4 horizontal offsets
-	// dx = 4 * g - 16 .. + 3 (g = lane % 9) and 5 consecutive vertical ones dy = d0 - 16 .. + 4
-	// (d0 = min(5 * (lane / 9), 28): the last ranges overlap, which a minimum does not mind). It walks
-	// down the 20 window rows its candidates touch ONCE: a row, fetched as four dword pairs at dword
-	// steps (ds_read2_b32: v_qsad wants an even-aligned register pair and gets one without moves),
-	// serves the up to 5 candidates rows it belongs to. 320 v_qsad and 80 LDS reads per lane, against
-	// 320 and 400 for one (dy, 4 dx) task at a time -- and 450 register moves fewer.
-	uint32_t curs[64];
+	// ---- motion search: exhaustive in its RESULT, successive elimination in its work ----
+	// For any candidate, sum over the four 8x8 quadrants |sum(cur quadrant) - sum(ref quadrant)| <= SAD
+	// (triangle inequality), so "bound + lambda * bits > the cost of some candidate already evaluated"
+	// proves that the candidate cannot be the minimum, nor tie with it. The bounds of all 33 x 33
+	// candidates cost about a tenth of their SADs: (A) 8x8 box sums of the window, once; (B) per
+	// candidate 2 v_sad_u16. (C) The quad of 4 horizontal neighbours with the least bound is evaluated
+	// exactly, its best cost is the threshold; (D) every quad holding a candidate whose bound does not
+	// exceed it is evaluated exactly (v_qsad_pk_u16_u8: 4 neighbours per instruction), 16 quads per pass, as many passes as it takes:
+	// noise keeps all 297 quads and costs about what summing everything did. The minimum of
+	// cost << 11 | index over the evaluated candidates IS the exhaustive search's (ties to the lowest
+	// index): nothing that could win or tie is ever dropped.
+	uint32_t cs0, cs1; // 8x8 sums of the current macroblock: {top left, top right}, {bottom left, bottom right} as u16 pairs
 	{
-		const uint32_t mine = ((const uint32_t *)s_cur)[lane];
-#pragma unroll
-		for (int i = 0; i < 64; i++)
-			curs[i] = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
+		// lane = (quadrant b = lane / 16, dword r of the quadrant): row 8 * (b / 2) + r / 2, dwords 2 * (b % 2) + r % 2
+		const int b = lane >> 4, r = lane & 15;
+		const uint32_t mine_q = ((const uint32_t *)s_cur)[(8 * (b >> 1) + (r >> 1)) * 4 + 2 * (b & 1) + (r & 1)];
+		int q = (int)__builtin_amdgcn_sad_u8(mine_q, 0u, 0u);
+		q += dpp_xor1(q);
+		q += __builtin_amdgcn_update_dpp(0, q, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+		q += __builtin_amdgcn_update_dpp(0, q, 0x141, 0xf, 0xf, true); // row_half_mirror
+		q += __builtin_amdgcn_update_dpp(0, q, 0x140, 0xf, 0xf, true); // row_mirror
+		cs0 = (uint32_t)__builtin_amdgcn_readlane(q, 0) | (uint32_t)__builtin_amdgcn_readlane(q, 16) << 16;
+		cs1 = (uint32_t)__builtin_amdgcn_readlane(q, 32) | (uint32_t)__builtin_amdgcn_readlane(q, 48) << 16;
 	}
-	const int R = p.search_range;
-	const int g9 = lane % 9, j7 = lane / 9;
-	const int d0 = min(5 * j7, 28);
-	uint64_t acc[5] = { 0, 0, 0, 0, 0 };
 	{
-		// Written as volatile asm: left to itself the scheduler hoists all 20 rows to the top (160
-		// registers, two waves per SIMD instead of four) and strings each accumulator's 64 v_qsad into
-		// one dependent chain. Here the next row is in flight while this one is summed, and
-		// consecutive v_qsad feed different accumulators.
-		const uint32_t la = (uint32_t)(uintptr_t)(s_ref + d0 * REF_STRIDE + 4 * g9); // LDS byte address of the lane's first row
-		uint64_t wa[4], wb[4];
-#define INTER_RD(dst, t, k)                                                                         \
-	asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(la), "n"(12 * (t) + (k)), "n"(12 * (t) + (k) + 1))
-#define INTER_RD4(dst, t) INTER_RD(dst[0], t, 0); INTER_RD(dst[1], t, 1); INTER_RD(dst[2], t, 2); INTER_RD(dst[3], t, 3)
-#define INTER_QS(i, src, t, k)                                                                      \
-	if ((t) - (i) >= 0 && (t) - (i) <= 15)                                                      \
-		asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(src[k]), "s"(curs[4 * ((t) - (i)) + (k)]))
-#define INTER_QS5(src, t, k) INTER_QS(0, src, t, k); INTER_QS(1, src, t, k); INTER_QS(2, src, t, k); INTER_QS(3, src, t, k); INTER_QS(4, src, t, k)
-#define INTER_SUM(src, t) INTER_QS5(src, t, 0); INTER_QS5(src, t, 1); INTER_QS5(src, t, 2); INTER_QS5(src, t, 3)
-// rows t (in cur_) and t + 1 (loaded into nxt_ meanwhile); the waits count LDS reads still in flight
-#define INTER_STEP(cur_, nxt_, t)                                                                   \
-	INTER_RD4(nxt_, (t) + 1);                                                                   \
-	asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                         \
-	INTER_SUM(cur_, t)
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // nothing of the compiler's own is in flight from here on
-		INTER_RD4(wa, 0);
-		INTER_STEP(wa, wb, 0); INTER_STEP(wb, wa, 1); INTER_STEP(wa, wb, 2); INTER_STEP(wb, wa, 3);
-		INTER_STEP(wa, wb, 4); INTER_STEP(wb, wa, 5); INTER_STEP(wa, wb, 6); INTER_STEP(wb, wa, 7);
-		INTER_STEP(wa, wb, 8); INTER_STEP(wb, wa, 9); INTER_STEP(wa, wb, 10); INTER_STEP(wb, wa, 11);
-		INTER_STEP(wa, wb, 12); INTER_STEP(wb, wa, 13); INTER_STEP(wa, wb, 14); INTER_STEP(wb, wa, 15);
-		INTER_STEP(wa, wb, 16); INTER_STEP(wb, wa, 17); INTER_STEP(wa, wb, 18);
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		INTER_SUM(wb, 19);
-#undef INTER_STEP
-#undef INTER_SUM
-#undef INTER_QS5
-#undef INTER_QS
-#undef INTER_RD4
-#undef INTER_RD
-	}
-	// per-u16 sums cannot carry: a full 16x16 SAD is at most 65280
-	uint32_t best = 0xffffffffu;
-	{
-		// key = cost << 11 | candidate index, index = (dy+16)*33 + dx+16; a candidate that is not
-		// allowed gets 2^30 on top per axis (a valid key stays below 2^28), so no selects, no branches
-		const int dx0 = 4 * g9 - 16;
-		uint32_t cost_x[4];
+		// (A) S8[y][x] = sum of the 8x8 block of the window at (x, y), y in [0, 41), x in [0, 48) (x > 40
+		// holds junk that only candidates beyond the range read), u16. A lane owns 4 neighbouring x (g)
+		// and 11 rows (seg): per window row one v_qsad against zero gives the four 4-sample sums, the
+		// lane to the right has the next four (DPP), a running sum of 8 rows does the rest. u16 pairs
+		// are added as dwords: no sum reaches 2^16.
+		const int seg = lane >> 4, g = min(lane & 15, 11);
+		const uint8_t *hp = s_ref + (10 * seg) * REF_STRIDE + 4 * g;
+		uint8_t *wp = s_s8 + (10 * seg) * S8_STRIDE + 8 * g;
+		uint32_t hlo[8], hhi[8], slo = 0, shi = 0;
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const int dx = dx0 + k;
-			const bool ok = dx >= -R && dx <= R && x0 + dx >= 0 && x0 + dx + 16 <= p.cw;
-			cost_x[k] = ((uint32_t)(qs.lambda * mv_bits(dx)) << 11 | (uint32_t)(dx + 16)) + (ok ? 0u : 0x40000000u);
+		for (int t = 0; t < 18; t++) {
+			const uint64_t w = *(const u64_a4 *)(hp + t * REF_STRIDE);
+			const uint64_t h4 = __builtin_amdgcn_qsad_pk_u16_u8(w, 0u, 0ull);
+			uint32_t lo = (uint32_t)h4, hi = (uint32_t)(h4 >> 32);
+			lo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x101, 0xf, 0xf, true); // row_shl:1: the lane to the right
+			hi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x101, 0xf, 0xf, true);
+			if (t >= 8) {
+				slo -= hlo[t & 7];
+				shi -= hhi[t & 7];
+			}
+			slo += lo;
+			shi += hi;
+			hlo[t & 7] = lo;
+			hhi[t & 7] = hi;
+			if (t >= 7)
+				*(uint64_t *)(wp + (t - 7) * S8_STRIDE) = (uint64_t)slo | (uint64_t)shi << 32;
 		}
+	}
+	WAVE_LDS_SYNC();
+	const int R = p.search_range;
+	const int g9 = min(lane, 62) % 9, j7 = min(lane, 62) / 9;
+	const int d0 = min(5 * j7, 28);
+	uint32_t bnd[5][4];
+	{
+		// (B) a lane owns the quads dx = 4 * g9 - 16 .. + 3 at dy = d0 - 16 .. + 4 (as the exhaustive loop
+		// did). Row Y of the sums serves candidate row Y (upper quadrants) and Y - 8 (lower ones).
+		const uint8_t *bp = s_s8 + d0 * S8_STRIDE + 8 * g9;
+#pragma unroll
+		for (int t = 0; t < 13; t++) {
+			if (t >= 5 && t < 8)
+				continue;
+			const uint64_t a = *(const uint64_t *)(bp + t * S8_STRIDE), b = *(const uint64_t *)(bp + t * S8_STRIDE + 16);
+			const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+			uint32_t pr[4];
+			pr[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u); // {S8[Y][X], S8[Y][X + 8]}
+			pr[1] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+			pr[2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+			pr[3] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				bnd[t < 5 ? t : t - 8][k] = t < 5 ? __builtin_amdgcn_sad_u16(pr[k], cs0, 0u) : __builtin_amdgcn_sad_u16(pr[k], cs1, bnd[t - 8][k]);
+		}
+	}
+	WAVE_LDS_SYNC(); // the sums are dead: their place takes the cost tables and the list
+	uint32_t *const s_lamx = (uint32_t *)(s_s8 + IA_LAMX), *const s_lamy = (uint32_t *)(s_s8 + IA_LAMY);
+	uint16_t *const s_list = (uint16_t *)(s_s8 + IA_LIST);
+	{
+		// lambda * bits of a vector component; a component that is not allowed costs 2^19 (any valid
+		// cost stays below 2^17; the sum of both still fits cost << 11)
+		const int d = lane - 16;
+		const bool xok = d >= -R && d <= R && x0 + d >= 0 && x0 + d + 16 <= p.cw;
+		const bool yok = d >= -R && d <= R && y0 + d >= band_y0 && y0 + d + 16 <= band_y1;
+		const uint32_t lb = (uint32_t)(qs.lambda * mv_bits(d));
+		if (lane < 36) {
+			s_lamx[lane] = lb + (xok ? 0u : 0x80000u);
+			s_lamy[lane] = lb + (yok ? 0u : 0x80000u);
+		}
+	}
+	WAVE_LDS_SYNC();
+	uint32_t best;
+	int n_list;
+	{
+		// (C) bound cost of a quad = min over its four candidates; key = cost << 9 | quad (row * 9 + g)
+		const u32x4 lx = *(const u32x4 *)(s_lamx + 4 * g9);
+		uint32_t qb[5], kmin = 0xffffffffu;
 #pragma unroll
 		for (int i = 0; i < 5; i++) {
-			const int dy = d0 + i - 16;
-			const bool yok = dy >= -R && dy <= R && y0 + dy >= band_y0 && y0 + dy + 16 <= band_y1;
-			const uint32_t key_y = ((uint32_t)(qs.lambda * mv_bits(dy)) << 11) + (uint32_t)((dy + 16) * 33) + (yok ? 0u : 0x40000000u);
-			const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
-			best = min(best, ((lo & 0xffffu) << 11) + (key_y + cost_x[0]));
-			best = min(best, ((lo >> 16) << 11) + (key_y + cost_x[1]));
-			best = min(best, ((hi & 0xffffu) << 11) + (key_y + cost_x[2]));
-			best = min(best, ((hi >> 16) << 11) + (key_y + cost_x[3]));
+			const uint32_t m = min(min(bnd[i][0] + lx.x, bnd[i][1] + lx.y), min(bnd[i][2] + lx.z, bnd[i][3] + lx.w));
+			qb[i] = m + s_lamy[d0 + i];
+			kmin = min(kmin, (qb[i] << 9) + (uint32_t)((d0 + i) * 9 + g9));
+		}
+		kmin = wave_min_u32(kmin);
+		const int q0 = (int)(kmin & 511u), qy0 = q0 / 9, qg0 = q0 - 9 * qy0; // wave-uniform
+		// that quad exactly: 16 lanes = its 16 rows, summed across the lanes of a DPP row
+		uint32_t thr_key;
+		{
+			const int r = lane & 15;
+			const uint8_t *rp = s_ref + (qy0 + r) * REF_STRIDE + 4 * qg0;
+			const u32x4 cv = *(const u32x4 *)(s_cur + 16 * r);
+			uint64_t a = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp), cv.x, 0ull);
+			a = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + 4), cv.y, a);
+			a = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + 8), cv.z, a);
+			a = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + 12), cv.w, a);
+			int lo = (int)(uint32_t)a, hi = (int)(uint32_t)(a >> 32); // u16 pairs: a 16x16 SAD is at most 65280, no carry
+			lo += dpp_xor1(lo); hi += dpp_xor1(hi);
+			lo += __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true); hi += __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true);
+			lo += __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true); hi += __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true);
+			lo += __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, true); hi += __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, true);
+			const u32x4 l0 = *(const u32x4 *)(s_lamx + 4 * qg0);
+			const uint32_t ly = s_lamy[qy0], ib = (uint32_t)(qy0 * 33 + 4 * qg0);
+			thr_key = min(min(((((uint32_t)lo & 0xffffu) + l0.x + ly) << 11) + ib, ((((uint32_t)lo >> 16) + l0.y + ly) << 11) + ib + 1u),
+				      min(((((uint32_t)hi & 0xffffu) + l0.z + ly) << 11) + ib + 2u, ((((uint32_t)hi >> 16) + l0.w + ly) << 11) + ib + 3u));
+			thr_key = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_key);
+		}
+		best = thr_key;
+		const uint32_t thr = thr_key >> 11;
+		// survivors -> list (lane 63 mirrors lane 62 and the last range of rows overlaps the one before
+		// it by two: neither enters twice; the quad already done stays out)
+		int base = 0;
+#pragma unroll
+		for (int i = 0; i < 5; i++) {
+			const bool f = qb[i] <= thr && lane < 63 && !(j7 == 6 && i < 2) && (d0 + i) * 9 + g9 != q0;
+			const uint64_t m = __ballot(f);
+			const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			if (f)
+				s_list[pos] = (uint16_t)(((d0 + i) << 4) | g9);
+			base += __popcll(m);
+		}
+		n_list = base;
+	}
+	WAVE_LDS_SYNC();
+	{
+		// (D) four lanes per quad (4 rows each: 16 v_qsad), 16 quads per pass, as many passes as it takes
+		// (slots past the end redo the last quad)
+		const int slot = lane >> 2, part = lane & 3;
+		u32x4 cv[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+			cv[r] = *(const u32x4 *)(s_cur + 16 * (4 * part + r));
+		for (int base = 0; base < n_list; base += 16) {
+			const int e = (int)s_list[min(base + slot, n_list - 1)];
+			const int qy = e >> 4, qg = e & 15;
+			const uint8_t *rp = s_ref + (qy + 4 * part) * REF_STRIDE + 4 * qg;
+			uint64_t a0 = 0, a1 = 0;
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				a0 = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + r * REF_STRIDE), cv[r].x, a0);
+				a1 = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + r * REF_STRIDE + 4), cv[r].y, a1);
+				a0 = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + r * REF_STRIDE + 8), cv[r].z, a0);
+				a1 = __builtin_amdgcn_qsad_pk_u16_u8(*(const u64_a4 *)(rp + r * REF_STRIDE + 12), cv[r].w, a1);
+			}
+			// per-u16 sums cannot carry: a full 16x16 SAD is at most 65280
+			int lo = (int)((uint32_t)a0 + (uint32_t)a1), hi = (int)((uint32_t)(a0 >> 32) + (uint32_t)(a1 >> 32));
+			lo += dpp_xor1(lo); hi += dpp_xor1(hi);
+			lo += __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true); hi += __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true);
+			const u32x4 lx = *(const u32x4 *)(s_lamx + 4 * qg);
+			const uint32_t ly = s_lamy[qy], ib = (uint32_t)(qy * 33 + 4 * qg);
+			best = min(best, min(min(((((uint32_t)lo & 0xffffu) + lx.x + ly) << 11) + ib, ((((uint32_t)lo >> 16) + lx.y + ly) << 11) + ib + 1u),
+					     min(((((uint32_t)hi & 0xffffu) + lx.z + ly) << 11) + ib + 2u, ((((uint32_t)hi >> 16) + lx.w + ly) << 11) + ib + 3u)));
 		}
 	}
+	WAVE_LDS_SYNC(); // list and tables are dead: the chroma window takes their place
+	*(u32x4 *)(s_refc + crow * REFC_STRIDE + 16 * cseg) = cwin[0];
+	if (crow < 9) // rows 16..24
+		*(u32x4 *)(s_refc + (crow + 16) * REFC_STRIDE + 16 * cseg) = cwin[1];
 	best = wave_min_u32(best);
 	const int bidx = (int)(best & 2047u);
 	const int bdy = bidx / 33 - 16, bdx = bidx - (bidx / 33) * 33 - 16;

@@ -202,6 +202,7 @@ struct GopMux {
 struct cedar_enc {
 	bool configured = false; // cedar.c:744-747
 	int device = 0;
+	bool device_set = false; // CONFIG got as far as hipSetDevice(device): only then is there anything of ours on a device
 	struct cedar_enc_config cfg{};
 	struct cedar_enc_config_ext ext{};
 	Params P{};
@@ -300,7 +301,8 @@ struct cedar_enc {
 	// per device slot: source planes + sync words ready (s_main), records complete (s_main),
 	// reconstruction deblocked (s_db)
 	// (x MAX_COHORTS: index slot * MAX_COHORTS + cohort)
-	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH * 4] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH * 4] = {}, ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH * 4] = {};
+	hipEvent_t ev_input[CEDAR_ENC_PIPELINE_DEPTH * MAX_COHORTS] = {}, ev_analysis[CEDAR_ENC_PIPELINE_DEPTH * MAX_COHORTS] = {},
+		   ev_deblocked[CEDAR_ENC_PIPELINE_DEPTH * MAX_COHORTS] = {};
 
 	InFlight fl[CEDAR_ENC_PIPELINE_DEPTH];
 	int fl_head = 0, fl_count = 0; // ring of frames in flight
@@ -378,10 +380,11 @@ void free_all(cedar_enc *e)
 			hipEventDestroy(e->fl[i].done_main);
 		if (e->fl[i].done_ent)
 			hipEventDestroy(e->fl[i].done_ent);
-		for (int c = 0; c < 4; c++) {
-			if (e->ev_input[4 * i + c]) hipEventDestroy(e->ev_input[4 * i + c]);
-			if (e->ev_analysis[4 * i + c]) hipEventDestroy(e->ev_analysis[4 * i + c]);
-			if (e->ev_deblocked[4 * i + c]) hipEventDestroy(e->ev_deblocked[4 * i + c]);
+		for (int c = 0; c < MAX_COHORTS; c++) {
+			const int k = i * MAX_COHORTS + c;
+			if (e->ev_input[k]) hipEventDestroy(e->ev_input[k]);
+			if (e->ev_analysis[k]) hipEventDestroy(e->ev_analysis[k]);
+			if (e->ev_deblocked[k]) hipEventDestroy(e->ev_deblocked[k]);
 		}
 		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
 			for (int k = 0; k < 2; k++)
@@ -787,7 +790,8 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		// cedar_buffers_init had got): the session is as freshly opened and may be configured again
 		char msg[sizeof(e->err)];
 		memcpy(msg, e->err, sizeof(msg));
-		hipDeviceSynchronize();
+		if (e->device_set) // (a parameter refused before that must not touch whatever device the caller has current)
+			hipDeviceSynchronize();
 		if (e->holds_pipe_token)
 			g_pipelined_sessions[e->device & 63].fetch_sub(1);
 		free_all(e);
@@ -878,6 +882,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -ENODEV, "HIP device %d not available", ext.device);
 	HIP_TRY(e, hipSetDevice(ext.device));
 	e->device = ext.device;
+	e->device_set = true;
 	e->cfg = *cfg;
 	e->ext = ext;
 	e->mb_qp = ext.roi_count > 0;
@@ -1968,8 +1973,12 @@ static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again =
 	e->frame_count = b.frame_count;
 	e->frame_p_count = b.frame_p_count;
 	e->cur = b.cur;
-	e->prev_slot = b.prev_slot;
-	e->prev2_slot = b.prev2_slot;
+	// The device has drained: the reconstruction the first replayed frame searches is final, so it waits
+	// for no deblock progress at all. (It must not: with the ring full the frame depth - 1 behind the
+	// failed one has taken the slot -- and the progress tag -- of the frame before it, and a gate asked to
+	// wait for that newer tag on words that still hold the older one would spin until its time-out.)
+	e->prev_slot = -1;
+	e->prev2_slot = -1;
 	e->idr_count = b.idr_count;
 	e->fl_count = 0;
 	e->fl_head = 0;

@@ -65,22 +65,29 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	ext.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	ext.bitrate = env_int("H264ENC_BITRATE", 0);
 	ext.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);
-	if (getenv("H264ENC_MAD")) /* "t0,t1,t2,t3:d0,d1,d2,d3,d4": thresholds and the QP offset of each class */
-		sscanf(getenv("H264ENC_MAD"), "%d,%d,%d,%d:%d,%d,%d,%d,%d", &ext.mad_th[0], &ext.mad_th[1], &ext.mad_th[2], &ext.mad_th[3],
-		       &ext.mad_dqp[0], &ext.mad_dqp[1], &ext.mad_dqp[2], &ext.mad_dqp[3], &ext.mad_dqp[4]);
+	if (getenv("H264ENC_MAD")) { /* "t0,t1,t2,t3:d0,d1,d2,d3,d4": thresholds and the QP offset of each class */
+		if (sscanf(getenv("H264ENC_MAD"), "%d,%d,%d,%d:%d,%d,%d,%d,%d", &ext.mad_th[0], &ext.mad_th[1], &ext.mad_th[2], &ext.mad_th[3],
+			   &ext.mad_dqp[0], &ext.mad_dqp[1], &ext.mad_dqp[2], &ext.mad_dqp[3], &ext.mad_dqp[4]) != 9) {
+			fprintf(stderr, "%s(): H264ENC_MAD wants \"t0,t1,t2,t3:d0,d1,d2,d3,d4\", got \"%s\"\n", __func__, getenv("H264ENC_MAD"));
+			return -EINVAL;
+		}
+	}
 	if (getenv("H264ENC_ROI")) { /* "x,y,w,h,dqp;..." in macroblocks, up to 4 regions */
 		const char *r = getenv("H264ENC_ROI");
 
-		while (*r && ext.roi_count < 4) {
-			int *v = ext.roi[ext.roi_count];
+		while (r && *r) {
+			int *v = ext.roi[ext.roi_count < 4 ? ext.roi_count : 0], n = 0;
 
-			if (sscanf(r, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5)
-				break;
+			if (ext.roi_count >= 4 || sscanf(r, "%d,%d,%d,%d,%d%n", &v[0], &v[1], &v[2], &v[3], &v[4], &n) != 5 ||
+			    (r[n] != ';' && r[n] != 0)) {
+				fprintf(stderr, "%s(): H264ENC_ROI wants up to 4 regions \"x,y,w,h,dqp;...\", got \"%s\"\n", __func__,
+					getenv("H264ENC_ROI"));
+				return -EINVAL;
+			}
 			ext.roi_count++;
-			r = strchr(r, ';');
-			if (!r)
-				break;
-			r++;
+			r += n;
+			if (*r == ';')
+				r++;
 		}
 	}
 	ext.subpel = env_int("H264ENC_SUBPEL", 0);

@@ -1808,8 +1808,15 @@ static int pred_i4_mode(const h264o_enc *e, int mx, int my, int row0, int idx)
 static int qp_delta_of(const h264o_enc *e, int mx, int my, int row0)
 {
 	const int i = my * e->mb_w + mx;
+	int d = e->qp_t[i] - (i == row0 * e->mb_w ? e->qp : e->qp_eff[i - 1]);
 
-	return e->qp_t[i] - (i == row0 * e->mb_w ? e->qp : e->qp_eff[i - 1]);
+	/* 7.4.5: mb_qp_delta lies in -26..+25 and QP_Y = (QP_Y,pred + mb_qp_delta + 52) % 52: a step of
+	 * more than that (two regions at +24 and -24 side by side) goes round the other way */
+	if (d > 25)
+		d -= 52;
+	else if (d < -26)
+		d += 52;
+	return d;
 }
 
 static void write_intra_mb(const h264o_enc *e, bitw *b, const h264o_mb *mb, int mx, int my,

@@ -329,8 +329,22 @@ class MB:
         self.pcm = False
 
 
+# Table A-1 (level limits), the columns this decoder checks: level_idc -> (MaxMBPS macroblocks/s, MaxFS macroblocks,
+# MaxVmvR: vertical vector components lie in [-MaxVmvR, MaxVmvR - 0.25] luma samples). Level 1b shares 11's code
+# in the baseline profile with constraint_set3_flag; these streams never use it.
+LEVEL_LIMITS = {
+    10: (1485, 99, 64), 11: (3000, 396, 128), 12: (6000, 396, 128), 13: (11880, 396, 128),
+    20: (11880, 396, 128), 21: (19800, 792, 256), 22: (20250, 1620, 256),
+    30: (40500, 1620, 256), 31: (108000, 3600, 512), 32: (216000, 5120, 512),
+    40: (245760, 8192, 512), 41: (245760, 8192, 512), 42: (522240, 8704, 512),
+    50: (589824, 22080, 512), 51: (983040, 36864, 512), 52: (2073600, 36864, 512),
+}
+MAX_MB_BITS = 3200   # A.3.1: bits of macroblock_layer() of any macroblock (I_PCM: 3072 + its header fits)
+
+
 class Decoder:
     def __init__(self):
+        self.max_abs_mv = [0, 0]   # largest |mvx|, |mvy| seen, quarter samples
         self.sps = None
         self.pps = None
         self.cur = None
@@ -366,8 +380,88 @@ class Decoder:
         if b.u(1):
             s["crop"] = (b.ue(), b.ue(), b.ue(), b.ue())  # left, right, top, bottom, in units of 2 samples
         s["vui"] = b.u(1)
+        s["fps"] = None
+        if s["vui"]:
+            self._parse_vui(b, s)
         self.sps = s
         self.cover["sps"] += 1
+
+    def _parse_vui(self, b, s):
+        """E.1.1 vui_parameters(); what is kept: the frame rate and the bitstream restrictions"""
+        if b.u(1):                       # aspect_ratio_info_present_flag
+            if b.u(8) == 255:            # Extended_SAR
+                b.u(16), b.u(16)
+        if b.u(1):                       # overscan_info_present_flag
+            b.u(1)
+        if b.u(1):                       # video_signal_type_present_flag
+            b.u(3), b.u(1)
+            if b.u(1):                   # colour_description_present_flag
+                b.u(8), b.u(8), b.u(8)
+        if b.u(1):                       # chroma_loc_info_present_flag
+            b.ue(), b.ue()
+        if b.u(1):                       # timing_info_present_flag
+            num_units_in_tick, time_scale = b.u(32), b.u(32)
+            s["fixed_frame_rate"] = b.u(1)
+            if num_units_in_tick == 0 or time_scale == 0:
+                raise SyntaxError264("timing_info with a zero")
+            s["fps"] = (time_scale, 2 * num_units_in_tick)   # a frame is two ticks (E.2.1)
+            self.cover["vui_timing"] += 1
+
+        def hrd():
+            cpb_cnt = b.ue() + 1
+            b.u(4), b.u(4)
+            for _ in range(cpb_cnt):
+                b.ue(), b.ue(), b.u(1)
+            b.u(5), b.u(5), b.u(5), b.u(5)
+        nal_hrd = b.u(1)
+        if nal_hrd:
+            hrd()
+        vcl_hrd = b.u(1)
+        if vcl_hrd:
+            hrd()
+        if nal_hrd or vcl_hrd:
+            b.u(1)                       # low_delay_hrd_flag
+        b.u(1)                           # pic_struct_present_flag
+        if b.u(1):                       # bitstream_restriction_flag
+            r = {"mv_over_pic_boundaries": b.u(1), "max_bytes_per_pic_denom": b.ue(), "max_bits_per_mb_denom": b.ue(),
+                 "log2_max_mv_length_horizontal": b.ue(), "log2_max_mv_length_vertical": b.ue(),
+                 "max_num_reorder_frames": b.ue(), "max_dec_frame_buffering": b.ue()}
+            if r["max_bits_per_mb_denom"] > 16 or r["log2_max_mv_length_horizontal"] > 16 or r["log2_max_mv_length_vertical"] > 16:
+                raise SyntaxError264("bitstream_restriction out of range")
+            s["restriction"] = r
+            self.cover["vui_restriction"] += 1
+
+    def level_violations(self):
+        """A.3.1 for the stream decoded so far, as a list of sentences (empty: within its level). Checked: frame size
+        and shape (MaxFS), macroblock rate at the VUI frame rate (MaxMBPS), bits per macroblock (3200), the vertical
+        and horizontal vector range, and the VUI's own promises (log2_max_mv_length_*, max_bits_per_mb_denom)."""
+        s, out = self.sps, []
+        if s is None:
+            return ["no sequence parameter set"]
+        lim = LEVEL_LIMITS.get(s["level_idc"])
+        if lim is None:
+            return ["level_idc %d is not in Table A-1" % s["level_idc"]]
+        mbps, fs, vmvr = lim
+        n = s["mb_w"] * s["mb_h"]
+        if n > fs:
+            out.append("PicSizeInMbs %d > MaxFS %d" % (n, fs))
+        if s["mb_w"] ** 2 > 8 * fs or s["mb_h"] ** 2 > 8 * fs:
+            out.append("picture %dx%d macroblocks is wider or taller than sqrt(8 MaxFS)" % (s["mb_w"], s["mb_h"]))
+        if s["fps"] and n * s["fps"][0] > mbps * s["fps"][1]:
+            out.append("%d macroblocks at %d/%d frames/s > MaxMBPS %d" % (n, s["fps"][0], s["fps"][1], mbps))
+        if self.max_mb_bits > MAX_MB_BITS:
+            out.append("a macroblock of %d bits > %d" % (self.max_mb_bits, MAX_MB_BITS))
+        if self.max_abs_mv[1] > 4 * vmvr:   # (+MaxVmvR itself is out: the range ends at MaxVmvR - 0.25; |v| == 4 MaxVmvR only passes for v < 0)
+            out.append("vertical vector component %d/4 outside +-%d" % (self.max_abs_mv[1], vmvr))
+        if self.max_abs_mv[0] > 4 * 2048:
+            out.append("horizontal vector component %d/4 outside +-2048" % self.max_abs_mv[0])
+        r = s.get("restriction")
+        if r:
+            if self.max_abs_mv[0] >= 1 << r["log2_max_mv_length_horizontal"] or self.max_abs_mv[1] >= 1 << r["log2_max_mv_length_vertical"]:
+                out.append("a vector of (%d, %d)/4 breaks the VUI's log2_max_mv_length" % tuple(self.max_abs_mv))
+            if r["max_bits_per_mb_denom"] and self.max_mb_bits > (128 + 3072) // r["max_bits_per_mb_denom"]:
+                out.append("a macroblock of %d bits breaks the VUI's max_bits_per_mb_denom" % self.max_mb_bits)
+        return out
 
     def _parse_pps(self, b):
         p = {"id": b.ue(), "sps_id": b.ue(), "cabac": b.u(1), "bottom_field_pic_order": b.u(1)}
@@ -583,6 +677,7 @@ class Decoder:
             mvdx, mvdy = b.se(), b.se()
             px, py = self._mv_pred_16x16(mx, my)
             m.mv = (px + mvdx, py + mvdy)
+            self.max_abs_mv = [max(self.max_abs_mv[0], abs(m.mv[0])), max(self.max_abs_mv[1], abs(m.mv[1]))]
             self.cover["mvd_zero" if (mvdx, mvdy) == (0, 0) else "mvd_nonzero"] += 1
         if i16:
             i16_mode = (mb_type - 1) & 3

@@ -62,6 +62,9 @@ def test_scalar_cli_config0_320x240_intra_only(tmp_path):
 
 
 def test_scalar_cli_usage_and_errors(tmp_path):
+    for env in (dict(H264ENC_MAD="1,2,3:4"), dict(H264ENC_ROI="1,1,2,2,-4;3,3,x"), dict(H264ENC_ROI="0,0,1,1,1;" * 5)):
+        r = subprocess.run([SCALAR, "-", "64", "48", str(tmp_path / "o.264")], input=b"", capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode != 0 and (b"H264ENC_MAD wants" in r.stderr or b"H264ENC_ROI wants" in r.stderr), env
     r = subprocess.run([SCALAR, "-", "320"], capture_output=True)
     assert r.returncode == 255 and b"Usage:" in r.stdout      # return -1 (h264enc.c:141-144)
     r = subprocess.run([SCALAR, str(tmp_path / "missing.yuv"), "320", "240", str(tmp_path / "o.264")], capture_output=True)
@@ -156,6 +159,10 @@ def test_hip_cli_usage_and_config_error(tmp_path):
     assert r.returncode == 255 and b"Usage:" in r.stdout
     r = subprocess.run([HIPCLI, "-", "321", "240", str(tmp_path / "o.264")], input=b"", capture_output=True)
     assert r.returncode != 0 and b"CEDAR_IOCTL_CONFIG failed" in r.stderr
+    # malformed option strings are refused with their format, not half-applied
+    for env in (dict(H264ENC_MAD="1,2,3:4"), dict(H264ENC_ROI="1,1,2,2,-4;3,3,x"), dict(H264ENC_ROI="0,0,1,1,1;" * 5)):
+        r = subprocess.run([HIPCLI, "-", "64", "48", str(tmp_path / "o.264")], input=b"", capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode != 0 and (b"H264ENC_MAD wants" in r.stderr or b"H264ENC_ROI wants" in r.stderr), env
 
 
 @pytest.mark.gpu
@@ -163,8 +170,10 @@ def test_hip_cli_skips_exactly_the_failed_frame(tmp_path):
     """h264enc.c:189-192: a failed ENCODE is reported, that frame is not written, the loop goes on and
     the driver's GOP counter and reference frames are as before it (cedar.c:1182-1201). The pipelined
     pump does the same with frames in flight: the file is the oracle's encode of the input WITHOUT the
-    failed frame, the process ends with 0 like the reference."""
-    w, h, frames, bad = 640, 368, 12, 4
+    failed frame, the process ends with 0 like the reference. More frames than the session's ring holds,
+    the failure past the first ring-full: the pump keeps the ring full, so the frame depth - 1 behind the
+    failed one has reused the device slot of the frame before it."""
+    w, h, frames, bad = 640, 368, 44, 21
     raw = _raw("B", w, h, frames)
     out = tmp_path / "out.264"
     env = dict(os.environ, H264ENC_QP="26", H264ENC_KEYINT="5", CEDAR_FAULT_INJECT="1", CEDAR_FAULT_INJECT_AT=str(bad + 1))

@@ -805,6 +805,14 @@ def test_oversize_pictures_are_requantised_until_every_macroblock_fits(ce, qp, k
         assert enc.stats()["requantised_frames"] > 0 and dec.max_mb_bits <= 3200
     with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
         assert _encode_pipelined(enc, frames) == want
+    # the ring really full: more frames than the session takes in flight, all of its depth in flight
+    n2 = ce.load_library().cedar_enc_pipeline_depth() + 9
+    frames2 = [ol.gen_frame("CB"[f % 5 == 4], w, h, f) for f in range(n2)]
+    oe2 = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, strict_mb_bits=2))
+    want2 = [oe2.encode(y, uv) for y, uv in frames2]
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
+        assert _encode_pipelined(enc, frames2) == want2
+        assert enc.stats()["requantised_frames"] > 0
 
 
 def test_failed_encode_is_retryable_on_the_same_session(ce, monkeypatch):
@@ -833,21 +841,24 @@ def test_failed_encode_is_retryable_on_the_same_session(ce, monkeypatch):
         assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
 
 
-@pytest.mark.parametrize("at,keyint", [(3, 25), (1, 4), (5, 4)], ids=["p-picture", "first-idr", "later-idr"])
-def test_pipelined_failure_drops_exactly_that_frame(ce, monkeypatch, at, keyint):
+@pytest.mark.parametrize("at,keyint,full", [(3, 25, False), (1, 4, False), (5, 4, False), (20, 25, True), (6, 7, True)],
+                         ids=["p-picture", "first-idr", "later-idr", "ring-full", "ring-full-short-gops"])
+def test_pipelined_failure_drops_exactly_that_frame(ce, monkeypatch, at, keyint, full):
     """The reference's loop goes on with the next frame after a failed ENCODE, with the GOP counter
     and the reference frames untouched (h264enc.c:189-192, cedar.c:1182-1201). With frames in flight
     the session does the same: the failed collect drops that frame, the frames submitted behind it
     are coded again on the state from before it. The stream equals the oracle's encode of the
-    sequence WITHOUT the failed frame."""
+    sequence WITHOUT the failed frame. "ring-full": as many frames in flight as the session takes
+    (cedar_enc_session_depth) and more frames than that in all, so that the frame depth - 1 behind the
+    failed one has reused the device slot of the frame before it."""
     w, h = 640, 368
-    n = 9
+    n = 9 if not full else at + ce.load_library().cedar_enc_pipeline_depth() + 6
     frames = [ol.gen_frame("B", w, h, f) for f in range(n)]
-    monkeypatch.setenv("CEDAR_FAULT_INJECT", "1" if keyint == 25 else "2" if at in (1, 5) else "1")
+    monkeypatch.setenv("CEDAR_FAULT_INJECT", "1" if keyint in (25, 7) else "2" if at in (1, 5) else "1")
     monkeypatch.setenv("CEDAR_FAULT_INJECT_AT", str(at))
     got, failed = [], []
     with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=keyint) as enc:
-        depth, q, nxt = min(enc.pipeline_depth, 6), 0, 0
+        depth, q, nxt = enc.pipeline_depth if full else min(enc.pipeline_depth, 6), 0, 0
         def take():
             nonlocal nxt
             try:
@@ -1073,6 +1084,9 @@ def test_cyclic_intra_refresh_equals_the_oracle(ce, w, h, qp, n, keyint, slices,
     (640, 368, 26, [(10, 5, 20, 12, -10), (0, 0, 40, 23, 6)], 25, 1, 2, 1, 4, {}),
     (1920, 1080, 30, [(40, 20, 40, 30, -8), (0, 60, 120, 8, 12)], 25, 1, 0, 1, 3, {}),
     (160, 96, 30, [(2, 1, 5, 3, -9)], 5, 2, 0, 3, 8, dict(gop_parallel=2)),
+    # steps of 48 between neighbours and of 36 against the slice QP: mb_qp_delta goes round modulo 52 (7.4.5)
+    (64, 48, 26, [(0, 0, 1, 1, 24), (1, 0, 1, 1, -24), (2, 1, 1, 2, 24)], 3, 1, 0, 1, 5, {}),
+    (64, 48, 14, [(0, 0, 2, 1, 24)], 30, 2, 0, 1, 4, dict(mad_th=[0, 0, 0, 0], mad_dqp=[0, 0, 0, 0, 12])),
     # MAD classes: the QP follows how well the chosen prediction fits (on their own, with regions, with refresh)
     (96, 64, 30, [], 12, 1, 0, 1, 6, dict(mad_th=[2, 5, 10, 20], mad_dqp=[-4, -2, 0, 2, 4])),
     (320, 240, 28, [(2, 1, 6, 4, 10)], 25, 2, 2, 2, 6, dict(mad_th=[1, 3, 6, 12], mad_dqp=[6, 3, 0, -3, -6])),

@@ -64,7 +64,7 @@ def decoded():
 def test_oracle_streams_decode_to_the_oracle_reconstruction(decoded):
     golden = {tuple(c["case"]): c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "indep_decode.json")))["cases"]}
     assert len(golden) == len(gen.CASES)
-    for case, (stream_sha, pics_sha, same, _) in decoded:
+    for case, (stream_sha, pics_sha, same, _, _) in decoded:
         assert same, "case %s: independent decode != oracle reconstruction" % (case,)
         assert golden[case]["stream_sha1"] == stream_sha, "case %s: the oracle's bytes changed" % (case,)
         assert golden[case]["pictures_sha1"] == pics_sha, case
@@ -73,7 +73,7 @@ def test_oracle_streams_decode_to_the_oracle_reconstruction(decoded):
 def test_the_streams_reach_every_part_of_the_standard_the_encoders_use(decoded):
     from collections import Counter
     cover = Counter()
-    for _, (_, _, _, c) in decoded:
+    for _, (_, _, _, c, _) in decoded:
         cover.update(c)
     want = (["i4_mode_%d" % i for i in range(9)] + ["i16_mode_%d" % i for i in range(4)] + ["chroma_mode_%d" % i for i in range(4)] +
             ["deblock_luma_bs%d" % i for i in range(1, 5)] + ["deblock_chroma_bs%d" % i for i in range(1, 5)] +
@@ -88,6 +88,48 @@ def test_the_streams_reach_every_part_of_the_standard_the_encoders_use(decoded):
             ["coeff_token/" + n for n in rd.vlc_tables() if n.startswith("coeff_token")])
     missing = [k for k in want if not cover[k]]
     assert not missing, missing
+
+
+def test_golden_streams_stay_within_their_level(decoded):
+    """A.3.1 as the independent decoder checks it (Decoder.level_violations: MaxFS and the picture's shape, MaxMBPS
+    at the VUI frame rate, 3200 bits per macroblock, the vector ranges, the VUI's own restrictions): every golden
+    stream is a conforming stream of the level its SPS names."""
+    oversize = []
+    for case, (_, _, _, _, violations) in decoded:
+        other = [v for v in violations if "bits > 3200" not in v]
+        assert not other, (case, other)
+        if len(other) != len(violations):
+            oversize.append(case)
+    # noise at QP <= 5 passes 3200 bits per macroblock where strict_mb_bits is left at 0 (DESIGN.md section 3)
+    assert all(c[5] == "C" and (c[2] <= 5 or len(c) > 7) for c in oversize), oversize
+
+
+def test_level_limits_are_noticed():
+    """the checks themselves: a 1080p stream that claims 60 frames/s at level 4.1, and level 1 for 320x240"""
+    w, h = 1920, 1080
+    for fps, level, want in ((30, 41, None), (60, 41, "MaxMBPS"), (30, 40, None), (30, 32, "MaxFS")):
+        d = rd.Decoder()
+        d.decode(ol_sps(w, h, level, fps))
+        v = d.level_violations()
+        assert (not v) if want is None else any(want in x for x in v), (fps, level, v)
+    d = rd.Decoder()
+    d.decode(ol_sps(320, 240, 10, 0))
+    assert any("MaxFS" in x for x in d.level_violations())
+    d = rd.Decoder()
+    d.decode(ol_sps(3840, 2160, 51, 30))
+    assert not d.level_violations()
+    d.max_mb_bits, d.max_abs_mv = 3201, [0, 4 * 512 + 1]
+    v = d.level_violations()
+    assert any("3200" in x for x in v) and any("vertical" in x for x in v)
+
+
+def ol_sps(w, h, level, fps):
+    import ctypes
+    cfg = ol.default_config(w, h, level_idc=level, fps_num=fps, fps_den=1 if fps else 0)
+    buf = np.zeros(64, np.uint8)
+    n = ol.lib().h264o_write_sps(ctypes.byref(cfg), buf.ctypes.data, 64)
+    assert n > 0
+    return buf[:n].tobytes()
 
 
 def test_oracle_c_decoder_agrees_with_the_independent_one():

@@ -25,6 +25,7 @@ CASES = [
     (112, 80, 30, 25, 5, "B", 2, "subpel=2,intra_refresh=5"), (48, 48, 20, 30, 9, "C", 1, "intra_refresh=7"),
     (160, 96, 28, 25, 4, "B", 2, "subpel=2,roi=0:0:4:3:-6/2:1:6:4:10/9:5:1:1:-20"), (96, 64, 36, 6, 7, "C", 1, "roi=1:1:3:2:-12"),
     (128, 96, 30, 25, 5, "B", 1, "mad_th=2:5:10:20,mad_dqp=-4:-2:0:2:4"), (112, 80, 27, 8, 6, "B", 2, "subpel=2,intra_refresh=4,roi=0:0:3:3:8,mad_th=1:3:6:12,mad_dqp=6:3:0:-3:-6"),
+    (64, 48, 26, 3, 5, "C", 1, "roi=0:0:1:1:24/1:0:1:1:-24/2:1:1:2:24"),   # mb_qp_delta of +-48 goes round modulo 52
 ]
 
 
@@ -57,13 +58,13 @@ def encode_and_decode(case):
         pics.update(lc)
         ry, ruv = oe.recon()
         same = same and ly == ry.tobytes() and lc == ruv.tobytes()
-    return stream.hexdigest(), pics.hexdigest(), same, dec.cover
+    return stream.hexdigest(), pics.hexdigest(), same, dec.cover, dec.level_violations()
 
 
 def main():
     out = []
     for case in CASES:
-        s, p, same, _ = encode_and_decode(case)
+        s, p, same, _, _ = encode_and_decode(case)
         if not same:
             raise SystemExit("case %s: the independent decoder and the oracle's reconstruction differ" % (case,))
         out.append({"case": list(case), "stream_sha1": s, "pictures_sha1": p})
