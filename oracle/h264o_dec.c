@@ -792,7 +792,16 @@ static int decode_residual_and_recon(h264o_dec *d, br *b, dmb *m, int mx, int my
 					tr = bx < 3 ? Bi != NULL : mb_at_intra(d, mx + 1, my - 1, m->slice, addr) != NULL;
 				else
 					tr = tri[idx];
-				/* modes 4..6 read the corner sample: of macroblock D for block 0 */
+				/* 8.3.1.2: every mode but DC is only allowed with the samples it reads (modes 4..6 read the
+				 * corner: of macroblock D for block 0, of A / B along the macroblock's edges) */
+				{
+					const int mode = m->i4[bx + 4 * by];
+					const int need_t = mode == 0 || mode == 3 || mode == 7 || (mode >= 4 && mode <= 6);
+					const int need_l = mode == 1 || mode == 8 || (mode >= 4 && mode <= 6);
+
+					if ((need_t && !top) || (need_l && !left))
+						return fail(d, "Intra4x4 mode needs an unavailable neighbour");
+				}
 				if (idx == 0 && m->i4[0] >= 4 && m->i4[0] <= 6 && !mb_at_intra(d, mx - 1, my - 1, m->slice, addr))
 					return fail(d, "Intra4x4 mode needs an unavailable corner");
 				intra4x4(d->cur_y, d->cw, mx * 16 + 4 * bx, my * 16 + 4 * by, m->i4[bx + 4 * by],
@@ -1295,7 +1304,7 @@ static int decode_slice(h264o_dec *d, br *b, int nal_type, int nal_ref_idc)
 			return r;
 		qp = m->qp;
 		addr++;
-		if (b->err)
+		if (b->err || b->pos > b->nbits) /* (the reader lets the stop bit itself be read: no syntax element may hold it) */
 			return fail(d, "slice data truncated");
 		if (!br_more(b))
 			break;
@@ -1332,6 +1341,8 @@ int h264o_dec_decode(h264o_dec *d, const uint8_t *data, int size)
 
 		/* find start code 00 00 01 */
 		if (!(data[i] == 0 && data[i + 1] == 0 && data[i + 2] == 1)) {
+			if (data[i] != 0) /* Annex B: only zero bytes lie between NAL units (leading_zero_8bits, trailing_zero_8bits) */
+				return fail(d, "bytes that belong to no NAL unit");
 			i++;
 			continue;
 		}

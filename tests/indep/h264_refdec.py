@@ -252,6 +252,8 @@ def split_nals(data):
             i += 3
         else:
             i += 1
+    if any(data[:starts[0] - 3] if starts else data):
+        raise SyntaxError264("bytes in front of the first start code")   # (Annex B: leading_zero_8bits only)
     for k, s in enumerate(starts):
         e = starts[k + 1] - 3 if k + 1 < len(starts) else n
         while e > s and data[e - 1] == 0:  # trailing_zero_8bits / the zero_byte of the next start code
@@ -265,6 +267,8 @@ def split_nals(data):
             if z >= 2 and b == 3:  # emulation_prevention_three_byte
                 z = 0
                 continue
+            if z >= 2 and b < 3:   # 7.4.1: 00 00 00, 00 00 01 and 00 00 02 never occur inside a NAL unit
+                raise SyntaxError264("bytes 00 00 %02x inside a NAL unit" % b)
             rbsp.append(b)
             z = z + 1 if b == 0 else 0
         out.append(((nal[0] >> 5) & 3, nal[0] & 31, bytes(rbsp)))
@@ -553,6 +557,8 @@ class Decoder:
             # a new picture (the streams here always start pictures with first_mb_in_slice = 0)
             if first_mb != 0:
                 raise SyntaxError264("picture does not start at macroblock 0")
+            if self.pending:
+                raise SyntaxError264("a new picture starts before the previous one is complete")
             self.cur = Picture(mb_w * 16, mb_h * 16)
             self.mbs = [MB() for _ in range(mb_w * mb_h)]
             self.slice_no = 0
@@ -585,7 +591,8 @@ class Decoder:
                         raise SyntaxError264("mb_skip_run runs past the picture")
                     self._p_skip(addr)
                     addr += 1
-                more = b.more_rbsp_data()
+                if run > 0:        # 7.3.4: moreDataFlag is only looked at again after a run of skipped macroblocks
+                    more = b.more_rbsp_data()
                 if not more:
                     break
             if addr >= n_mb:
@@ -593,6 +600,8 @@ class Decoder:
             pos0 = b.pos
             self._macroblock(b, addr, is_p)
             self.max_mb_bits = max(self.max_mb_bits, b.pos - pos0)   # A.3.1: macroblock_layer() <= 3200 bits
+            if b.pos > b.stop:
+                raise SyntaxError264("macroblock data runs into rbsp_trailing_bits")
             addr += 1
             more = b.more_rbsp_data()
         self.next_mb = addr
@@ -849,7 +858,7 @@ class Decoder:
             prefix = 0
             while b.u(1) == 0:
                 prefix += 1
-                if prefix > 31:
+                if prefix > 15:    # (9.2.2.1: more than 15 only in the High profiles, which are outside this decoder)
                     raise SyntaxError264("level_prefix too long")
             code = min(15, prefix) << suffix_len
             if suffix_len > 0 or prefix >= 14:
