@@ -299,6 +299,8 @@ struct cedar_enc {
 	// leave most of the chip idle; on one stream the cohorts' chains queued behind each other and that
 	// stream set the step time (32 x 1080p: deblock stream 82 %, entropy stream 87 % busy).
 	hipStream_t s_db_c[MAX_COHORTS] = {}, s_ent_c[MAX_COHORTS] = {};
+	bool batch_self_reset = false; // CEDAR_BATCH_SELF_RESET=1 (development): no memset / k_flag launches around the kernels of frames that run
+	                               // back to back, the kernels reset and flag themselves as for pipelined frames. Measured 32 x 1080p: 166 M MB/s against 170 M.
 	hipEvent_t ev_entropy[CEDAR_ENC_PIPELINE_DEPTH * MAX_COHORTS] = {};
 	unsigned idr_count = 0;
 	bool split_planes = true;
@@ -1326,8 +1328,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			// CEDAR_COHORT_STREAMS (development): bit 0 the deblocking, bit 1 the entropy chain of cohort c > 0 on a
 			// stream of its own. Off by default: measured at 32 x 1080p, both on 162.7 M MB/s against 168.9 M on the
 			// shared streams -- more queues holding resident kernels slow each other's launches.
-			const char *envs = getenv("CEDAR_COHORT_STREAMS");
+			const char *envs = getenv("CEDAR_COHORT_STREAMS"), *envr = getenv("CEDAR_BATCH_SELF_RESET");
 			const int cs = envs ? atoi(envs) : 0;
+			e->batch_self_reset = envr && atoi(envr) != 0;
 			if (C > 1 && cs) {
 				for (int c = 1; c < C; c++) {
 					if ((cs & 1) && c < DB_STREAMS)
@@ -1803,6 +1806,10 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	// offset pointers; scratch that a launch counts or compacts in (tickets, size words, the packed
 	// output) is per cohort.
 	const int C = e->cohorts;
+	// frames back to back: sync words and size words are left zeroed, the completion flags raised, by the kernels
+	// themselves as for pipelined frames (not with cohorts on streams of their own: the last cohort's kernel
+	// would speak for kernels of other streams)
+	const bool self_reset = !pipe && e->batch_self_reset && !e->s_db_c[1] && !e->s_ent_c[1];
 	for (int c = 0; c < C; c++) {
 		Params Pc = cohort_params(e, P, c);
 		const int ei = ds * MAX_COHORTS + c, eprev = prev * MAX_COHORTS + c;
@@ -1831,10 +1838,13 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			// Pipelined: ONE packet on the deblock stream per frame -- every packet queued behind a
 			// resident kernel costs the hardware pipe ~20 us. The kernel's last workgroup zeroes the
 			// sync words for the slot's next frame and raises the frame's done flag itself.
-			Pc.db_self_reset = pipe ? 1 : 0;
-			Pc.done_flag = f.d_done + 1;
+			// Frames back to back do the same (a memset or a 1-thread kernel that meets a chip full of k_inter
+			// workgroups waits for a CU like everybody else: 32 x 1080p showed the wf_sync memset take 377 us
+			// in front of a deblock kernel). Cohorts follow each other on one stream: the last one's flag says all.
+			Pc.db_self_reset = pipe || self_reset ? 1 : 0;
+			Pc.done_flag = pipe || c == C - 1 ? f.d_done + 1 : nullptr;
 			Pc.done_tag = f.done_tag;
-			if (!pipe && e->wf_split > 1)
+			if (!Pc.db_self_reset && e->wf_split > 1)
 				HIP_TRY(e, hipMemsetAsync(Pc.wf_sync + WF_SYNC_WORDS, 0,
 							  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)Pc.n_streams * e->ext.slice_num * WF_MAX_SPLIT), s_dbc));
 			if (c == 0)
@@ -1854,7 +1864,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 					if ((!ahead && e->s_db_c[c2] ? e->s_db_c[c2] : s_db) != s_dbc)
 						HIP_TRY(e, hipStreamWaitEvent(s_dbc, e->ev_deblocked[ds * MAX_COHORTS + c2], 0));
 				HIP_TRY(e, hipEventRecord(f.done_main, s_dbc));
-				if (Launch::flag(s_dbc, f.d_done + 1, f.done_tag))
+				if (!self_reset && Launch::flag(s_dbc, f.d_done + 1, f.done_tag))
 					return fail(e, -EIO, "k_flag launch failed");
 			}
 			return 0;
@@ -1925,7 +1935,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_entc);
 		// Pipelined: as few packets on the entropy stream as possible (see launch_deblock): the size
 		// words are left zeroed and the done flag raised by k_copy_out's last workgroup
-		if (!pipe)
+		if (!pipe && !self_reset)
 			HIP_TRY(e, hipMemsetAsync(Pc.stream_size, 0, sizeof(uint32_t) * (Pc.n_streams + 4), s_entc));
 		// macroblocks differ in QP: QP_Y as the decoder will hold it, for the mb_qp_delta of the next one
 		if (Pc.roi_off && Launch::qp_eff(Pc, s_entc))
@@ -1934,7 +1944,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			return fail(e, -EIO, "entropy launch failed");
 		if (c == C - 1)
 			tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_entc);
-		Pc.done_flag = pipe ? f.d_done : nullptr;
+		// (frames back to back: every cohort's k_copy_out leaves its size words zeroed, the last one raises the flag)
+		Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done : self_reset ? e->d_abort_all + 8 : nullptr;
 		Pc.done_tag = f.done_tag;
 		if (Launch::copy_out(Pc, s_entc, e->dv_out[f.host_out] + (size_t)(S * c / C) * (C > 1 ? e->stream_out_cap : 0),
 				     e->dv_sizes[slot] + (size_t)c * (S + 2)))
@@ -1946,7 +1957,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 				if (e->ev_entropy[ds * MAX_COHORTS + c2] && (e->s_ent_c[c2] ? e->s_ent_c[c2] : s_ent) != s_entc)
 					HIP_TRY(e, hipStreamWaitEvent(s_entc, e->ev_entropy[ds * MAX_COHORTS + c2], 0));
 			HIP_TRY(e, hipEventRecord(f.done_ent, s_entc));
-			if (Launch::flag(s_entc, f.d_done, f.done_tag))
+			if (!self_reset && Launch::flag(s_entc, f.d_done, f.done_tag))
 				return fail(e, -EIO, "k_flag launch failed");
 		}
 		t_ent = now_ms();

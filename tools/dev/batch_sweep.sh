@@ -9,8 +9,11 @@ run() { # label, env...
       python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%-40s %.1f M MB/s  %.3f ms/step' % ('$label', d['value']/1e6, d['ms_per_step']))" )
 }
 run "default"
-run "cohort deblock streams" CEDAR_COHORT_STREAMS=1
-run "cohort entropy streams" CEDAR_COHORT_STREAMS=2
+run "memset + flag launches" CEDAR_BATCH_SELF_RESET=0
 run "planes split" CEDAR_DEBLOCK_PLANES=1
-run "planes split + deblock streams" CEDAR_DEBLOCK_PLANES=1 CEDAR_COHORT_STREAMS=1
+run "3 cohorts" CEDAR_COHORTS=3
 run "default again"
+STREAMS=8 run "8 streams"
+STREAMS=16 run "16 streams"
+STREAMS=16 run "16 streams, 2 cohorts" CEDAR_COHORTS=2
+STREAMS=64 run "64 streams"
