@@ -137,8 +137,10 @@ struct Params {
 	int32_t wf_split_intra;          // workgroups per unit: intra recon
 	int32_t db_pairs;                // filter/mover wave pairs per deblock workgroup: 8 (a whole CU) or 2
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
-	// picture along diagonals s = x + 2*y (absolute macroblock coordinates), so progress is
-	// counted in diagonals: "every macroblock with x + 2*y < D is through". Words live in device
+	// picture along diagonals (absolute macroblock coordinates), so progress is counted in
+	// diagonals: "every macroblock with s < D is through" -- s = x + y for the deblock kernel and
+	// the P picture's analysis between two of them (one macroblock of lag per row), s = x + 2*y
+	// for the intra wavefront and the IDR picture's deblocking behind it. Words live in device
 	// memory, are written with agent-scope release and polled by kernels of other streams.
 	// A value is (frame tag << 16 | D), compared modulo 2^32: a slot's words never need zeroing
 	// and the stale value of the frame that used the slot before reads as "nothing yet".
@@ -147,7 +149,7 @@ struct Params {
 	uint32_t *prog_intra;            // [n_units][PROG_BANDS] D of every intra-reconstruction band written back (IDR pictures)
 	const uint32_t *prev_db;         // the previous frame's prog_db (what k_gate waits for)
 	uint32_t prog_tag, prev_tag;
-	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + 2*y < s1 (stripe_s1 <= 0: the whole picture)
+	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + y < s1 (stripe_s1 <= 0: the whole picture)
 	const uint32_t *stripe_tab;      // [row_num + 1] macroblocks of the stripe in the rows before row r (per stream)
 	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
 	int64_t dummy_mb;                // ... and the macroblock record they fill: one past the session's last stream
@@ -204,7 +206,7 @@ struct Launch {
 	static int inter(const Params &p, void *stream, int n_mbs); // n_mbs macroblocks: the picture, or the diagonals [stripe_s0, stripe_s1)
 	static int qp_eff(const Params &p, void *stream);           // macroblocks differ in QP: QP_Y per macroblock as the decoder holds it, for mb_qp_delta
 	// 1 wave: publish prog_inter = publish_d (if >= 0), then wait until every deblock band of the
-	// previous frame has written back all macroblocks with x + 2*y < need_d (if > 0)
+	// previous frame has written back all macroblocks with x + y < need_d (if > 0)
 	static int gate(const Params &p, void *stream, int publish_d, int need_d);
 	// d_out[0 .. stream_size[n_streams]) and the size words -> pinned host memory, by the GPU itself
 	// (coalesced 16-byte stores over PCIe): no hipMemcpyAsync on the per-frame path

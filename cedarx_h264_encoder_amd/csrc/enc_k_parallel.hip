@@ -153,7 +153,7 @@ DEVI bool inter_mb(const Params &p, uint32_t i, int &mx, int &my, int &st)
 			hi = mid;
 	}
 	my = p.row_first + lo;
-	const int xs = p.stripe_s0 - 2 * my;
+	const int xs = p.stripe_s0 - my; // stripes of x + y
 	mx = (xs > 0 ? xs : 0) + (int)(m - p.stripe_tab[lo]);
 	return st < p.n_streams;
 }
@@ -937,9 +937,11 @@ int Launch::inter(const Params &p, void *stream, int n_mbs)
 // analysed in a few diagonal stripes; in front of stripe [s0, s1) this kernel (1) publishes
 // how far this frame's analysis has come (the deblock kernel of this frame, already running
 // on another stream, polls that word) and (2) spins until every deblock band of the previous
-// frame has written back the macroblocks with x + 2*y < need_d: the motion search of (x, y)
-// reads the final samples of (x-1..x+1, y-1..y+1), final once their right and lower
-// neighbours are filtered, i.e. need_d = s1 + 5.
+// frame has written back the macroblocks with x + y < need_d (the deblock kernel's own measure of
+// progress: one macroblock of lag per row): the motion search of (x, y) reads the final samples of
+// (x-1..x+1, y-1..y+1); a macroblock is final once its right and its lower neighbour are filtered and
+// written back, for (x+1, y+1) those are on x + y + 3, i.e. need_d = s1 + 3 for the stripe's last
+// diagonal s1 - 1 (one more is asked for).
 // Spins are bounded: a time-out leaves an error code and lets the stream drain.
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d)
@@ -958,8 +960,8 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 			const int band = e % PROG_BANDS, unit = (e / PROG_BANDS) % n_units;
 			int r0, r1;
 			slice_rows(p.mb_h, p.slice_count, p.slice_first + unit % p.slice_num, &r0, &r1);
-			// a band owns the diagonals from 2*(r0 + 4*band) on: nothing of it is below that
-			pending = band < ((r1 - r0 + 3) >> 2) && 2 * (r0 + 4 * band) < need_d;
+			// a band owns the diagonals x + y from r0 + 4*band on: nothing of it is below that
+			pending = band < ((r1 - r0 + 3) >> 2) && r0 + 4 * band < need_d;
 		}
 		uint32_t spins = 0;
 		uint64_t t0 = 0;

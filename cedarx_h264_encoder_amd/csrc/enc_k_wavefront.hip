@@ -583,8 +583,16 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		// ============================== mover wave ==============================
 		// Frame pipelining: this frame's analysis runs ahead of us on another stream in diagonal
 		// stripes (prog_inter), and the next frame's analysis follows OUR write-back (prog_db).
-		// All four rows of the band are on the same diagonal at every step: x + 2*y = t + diag0.
-		const int diag0 = 2 * (r0 + 4 * band);
+		// Two ways of counting progress. This kernel sweeps with ONE macroblock of lag per row: at step t
+		// the four rows of the band are at x + y = t + y0 (y0 = the band's first row), and "everything
+		// with x + y < E is through" says exactly how far it is -- that is what it publishes and what a
+		// P picture's analysis (stripes of x + y, published by k_gate) is asked for. The intra wavefront
+		// needs TWO macroblocks of lag per row (x + 2*y) and publishes in that measure: an IDR picture's
+		// deblocking waits for it in x + 2*y, where the band's rows are at t + 2*y0 .. t + 2*y0 + 3.
+		// (Counting everything in x + 2*y is true too, but it asks the analysis of a P picture to be 3
+		// diagonals per band AHEAD of where the band is -- 52 for the bottom band of a 1080p picture.)
+		const int y0b = r0 + 4 * band;
+		const int diag0 = 2 * y0b;
 		uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
 		uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
 		auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
@@ -593,7 +601,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			// (x-1, y+1), (x, y+1) and (x+1, y+1) still need: in an intra picture the deblock
 			// wavefront stays behind the last of them, three more diagonals.
 			const bool idr_pic = IDR || (QPM && p.is_idr); // (mode 3 serves the IDR pictures of its sessions too)
-			const uint32_t need = (uint32_t)(t + 3 + diag0 + (idr_pic ? 4 : 1)); // group 3 is 3 diagonals ahead of group 0
+			const uint32_t need = idr_pic ? (uint32_t)(t + 3 + diag0 + 4)  // x + 2*y: group 3 is 3 diagonals ahead of group 0
+						      : (uint32_t)(t + y0b + 1);       // x + y: all four rows are on t + y0
 			if (inter_seen >= need)
 				return;
 			// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the
@@ -869,7 +878,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 				lds_wait_ge(&s_filtered[pair], base + t, xw); // step t-1 filtered
 			publish();
 			if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
-				publish_diag((uint32_t)(t - 1 + diag0));
+				publish_diag((uint32_t)(t - 1 + y0b)); // every macroblock of the band with x + y < that
 			if (t + 1 < nsteps) {
 				if (!R.top_ok)
 					load_step(t + 1, true, R);

@@ -15,10 +15,15 @@
 #include <time.h>
 
 #include <vector>
+#include <algorithm>
 
 #include <sched.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include <hip/hip_runtime.h>
 
@@ -199,6 +204,25 @@ struct GopMux {
 
 } // namespace
 
+// Sessions that hold back the tail of a pipelined P picture (cedar_enc::DeferredTail) leave kernels on the
+// device that wait for work only the NEXT submit enqueues. The caller only ever blocks in ENCODE
+// (cedar.c:1178-1180), and between two calls it may do anything -- a device-wide synchronisation
+// included, which would then wait for those kernels until their wall-clock bound. So the tail never stays
+// held back for long: a thread of the session enqueues it `us` microseconds after the submit that held it
+// back unless the next submit (or a collect / flush / close) has done so by then. Every entry point of such
+// a session takes `mu`; sessions without a held-back tail have no thread and take no lock.
+struct cedar_enc;
+struct Flusher {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::thread th;
+	bool stop = false, armed = false;
+	std::chrono::steady_clock::time_point deadline;
+	long us = 100;
+	int rc = 0;           // what a flush from the thread returned, reported by the next collect
+	uint64_t flushes = 0; // tails the thread enqueued (cedar_enc_stats would show a caller that pauses between submits)
+};
+
 struct cedar_enc {
 	bool configured = false; // cedar.c:744-747
 	int device = 0;
@@ -274,6 +298,20 @@ struct cedar_enc {
 	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
 	int wf_split = 1, wf_split_intra = 1;
 	int db_pairs = 8;
+	// Pipelined P pictures: the last stripes of a picture's analysis (from defer_from on), its final gate
+	// and its entropy launches are held back and enqueued BETWEEN the first stripes of the next picture:
+	// a picture's last stripe is gated on the END of the previous picture's deblocking, and on an in-order
+	// stream the next picture's first stripe -- which only needs that deblocking a quarter through -- would
+	// sit behind it. (submit_frame; emitted at the latest when the frame is collected.)
+	Flusher *flusher = nullptr;  // only sessions that hold tails back (defer_from < inter_bands)
+	int defer_default = 0;       // stripes held back unless CEDAR_DEFER says otherwise (set with the stripe count)
+	int defer_from = 0;          // first deferred stripe; inter_bands = nothing is deferred
+	struct DeferredTail {
+		bool active = false;
+		Params Pc{};
+		hipStream_t s_ana = nullptr, s_ent = nullptr;
+		int slot = 0, ei = 0, next = 0;
+	} deferred;
 	// pinned host memory
 	uint8_t *h_luma = nullptr, *h_chroma = nullptr;
 	uint8_t *h_out[CEDAR_ENC_PIPELINE_DEPTH] = {}, *dv_out[CEDAR_ENC_PIPELINE_DEPTH] = {};     // pinned + mapped, and its device view
@@ -329,6 +367,9 @@ struct cedar_enc {
 	char err[256] = { 0 };
 };
 
+static void flusher_main(cedar_enc *e);
+static void flusher_stop(cedar_enc *e);
+
 namespace {
 
 int fail(cedar_enc *e, int code, const char *fmt, ...)
@@ -359,6 +400,7 @@ int dalloc(cedar_enc *e, T **p, size_t count)
 
 void free_all(cedar_enc *e)
 {
+	flusher_stop(e); // (before anything the thread could touch goes away)
 	auto F = [](void *p) { if (p) hipFree(p); };
 	auto H = [](void *p) { if (p) hipHostFree(p); };
 	F(e->d_in_y); F(e->d_in_uv); F((void *)e->d_in_ptrs);
@@ -751,10 +793,8 @@ void build_pred4_table(uint8_t tab[9 * 16])
 
 } // namespace cedar
 
-// ======================================================================
-// C-ABI
-// ======================================================================
-
+// ===============================================================// C-ABI
+// ===============================================================
 extern "C" const char *cedar_enc_version(void)
 {
 	return "cedar_h264enc 0.1 (gfx950, HIP)";
@@ -1165,8 +1205,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (int i = 1; i < AN_STREAMS; i++)
 		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ana[i], hipStreamNonBlocking));
 	if (e->depth > 4) {
-		const char *envd3 = getenv("CEDAR_DEBLOCK_STREAMS");
-		const int rc_roles = assign_stream_roles(e, envd3 ? atoi(envd3) : 2);
+		const char *envd3 = getenv("CEDAR_DEBLOCK_STREAMS"), *envdf = getenv("CEDAR_DEFER");
+		const int rc_roles = assign_stream_roles(e, envd3 ? atoi(envd3) : (n_units == 1 && !(envdf && atoi(envdf) == 0)) ? 3 : 2);
 		if (rc_roles)
 			return rc_roles;
 	}
@@ -1199,7 +1239,14 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		const char *envd = getenv("CEDAR_DEBLOCK_STREAMS");
 		// measured (1080p, 1 stream, M MB/s): analysis x deblock streams 1x2 16.8, 2x2 15.3-16.7,
 		// 2x3 15.8, 3x3 15.9, 1x3 12: the leanest set that overlaps two deblock kernels wins
-		const int db_max = envd ? atoi(envd) : 2;
+		// One stream, one slice: the last stripes of a P picture are held back and go out between the first ones
+		// of the next (DeferredTail), which wants a third deblock stream -- a picture's deblocking may then start
+		// while the one two frames back is still resident. 1080p, M MB/s over 4-6 runs each: 5 stripes / 2 streams
+		// 36.0; 8 stripes none held, 3 streams 36.4-36.5; 8 stripes 3 held, 2 streams 37.4-37.8; 6 stripes 2 held,
+		// 3 streams 42.1-42.4; 8 stripes 3 held, 3 streams 42.1-43.6. CEDAR_DEFER=0 switches it off.
+		const char *envdf = getenv("CEDAR_DEFER");
+		const bool defer_wanted = n_units == 1 && !e->mux && !(envdf && atoi(envdf) == 0);
+		const int db_max = envd ? atoi(envd) : defer_wanted ? 3 : 2;
 		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * db_max <= cus / 2;
 		if (want && !e->holds_pipe_token) {
 			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
@@ -1256,6 +1303,12 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// (every stripe costs a gate and two dependent launches: small pictures take fewer; 854x480
 		// 13.1 -> 13.5 M MB/s with 3, 1080p equal from 3 to 8)
 		int nb = envb ? atoi(envb) : (P.mb_w * P.row_num >= 4000 ? 5 : 3);
+		e->defer_default = 0;
+		if (defer_wanted && e->db_streams >= 3 && P.mb_w * P.row_num >= 4000) {
+			if (!envb)
+				nb = 8;
+			e->defer_default = nb >= 8 ? 3 : nb >= 6 ? 2 : 0;
+		}
 		if (nb > 64) nb = 64;
 		e->inter_bands = e->row_pipe ? (nb < 1 ? 1 : nb) : 1;
 		// Look-ahead for IDR pictures: two more streams -- the IDR picture's analysis (busy for
@@ -1348,10 +1401,11 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth, e->cohorts);
 	}
 	{
-		// diagonal stripes s = x + 2*y of a P picture and, per stripe, how many of its macroblocks
-		// lie in the rows before row r: k_inter enumerates a stripe without holes
+		// diagonal stripes s = x + y of a P picture (the slope of the deblock sweep it follows and is
+		// followed by) and, per stripe, how many of its macroblocks lie in the rows before row r: k_inter
+		// enumerates a stripe without holes
 		const int nb = e->inter_bands;
-		const int d_lo = 2 * P.row_first, d_hi = P.mb_w - 1 + 2 * (P.row_first + P.row_num - 1) + 1;
+		const int d_lo = P.row_first, d_hi = P.mb_w - 1 + (P.row_first + P.row_num - 1) + 1;
 		e->stripe_s.assign((size_t)nb + 1, 0);
 		e->stripe_n.assign((size_t)nb, 0);
 		std::vector<uint32_t> tab((size_t)nb * (P.row_num + 1), 0);
@@ -1363,9 +1417,45 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 				tab[(size_t)k * (P.row_num + 1) + r] = run;
 				const int y = P.row_first + r;
 				auto cl = [&](int v) { return v < 0 ? 0 : v > P.mb_w ? P.mb_w : v; };
-				run += (uint32_t)(cl(e->stripe_s[k + 1] - 2 * y) - cl(e->stripe_s[k] - 2 * y));
+				run += (uint32_t)(cl(e->stripe_s[k + 1] - y) - cl(e->stripe_s[k] - y));
 			}
 			e->stripe_n[k] = (int)tab[(size_t)k * (P.row_num + 1) + P.row_num];
+		}
+		// Which stripes may be held back (see DeferredTail). Own stripe j of the next picture is enqueued
+		// after this picture's stripes up to defer_from + j - 1; its gate waits for this picture's
+		// deblocking to have ALL bands at x + y >= s1(j) + 4, i.e. its top band nb - 1 + 5 steps further,
+		// plus the 8 steps between two publications, and that deblocking asks for its own analysis up to
+		// one diagonal more: everything below s1(j) + nb + 14 must already be in the queue, or the stream
+		// waits for itself.
+		{
+			const char *envd = getenv("CEDAR_DEFER");
+			int bands_max = 0;
+			for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
+				int a, b;
+				slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
+				bands_max = std::max(bands_max, (b - a + 3) / 4);
+			}
+			// (all of it assumes the deblock sweep of a unit is ONE front, every band 5 steps behind the band
+			// above: a workgroup with more bands than wave pairs starts band b + pairs when band b is through)
+			const bool one_front = (bands_max + e->wf_split - 1) / e->wf_split <= e->db_pairs;
+			// CEDAR_DEFER = number of stripes to hold back (0: none). Between two submits the device then holds
+			// kernels that wait for work only the NEXT submit enqueues; a device-wide synchronisation by anybody in
+			// the process in between would wait for them, so the session's flush thread enqueues the tail itself
+			// CEDAR_DEFER_FLUSH_US (100) after the submit unless the next submit has come (Flusher).
+			const int want = envd ? atoi(envd) : e->defer_default;
+			int kd = nb;
+			if (e->row_pipe && e->cohorts == 1 && !e->mux && want > 0 && want < nb && nb >= 3 && one_front)
+				kd = nb - want;
+			for (int j = 0; j < kd && kd < nb; j++)
+				if (e->stripe_s[j + 1] + bands_max + 14 > e->stripe_s[std::min(nb, kd + j)])
+					kd = nb;
+			e->defer_from = kd;
+			if (kd < nb) {
+				const char *envu = getenv("CEDAR_DEFER_FLUSH_US");
+				e->flusher = new Flusher();
+				e->flusher->us = envu && atol(envu) > 0 ? atol(envu) : 100;
+				e->flusher->th = std::thread(flusher_main, e);
+			}
 		}
 		if (e->d_stripe_tab) { hipFree(e->d_stripe_tab); e->d_stripe_tab = nullptr; }
 		if ((rc = dalloc(e, &e->d_stripe_tab, tab.size()))) return rc;
@@ -1593,6 +1683,122 @@ struct ReplayIn {
 	int qp_bump = 0;
 };
 
+// The stripes [k0, k1) of a pipelined P picture's analysis: a gate (publish how far this picture's
+// analysis is, wait for the previous picture's deblocking) and the search of the stripe, each.
+static int emit_stripes(cedar_enc *e, Params &Pc, hipStream_t s_ana, int k0, int k1)
+{
+	const int S = e->ext.n_streams;
+	for (int k = k0; k < k1; k++) {
+		Pc.stripe_s0 = e->stripe_s[k];
+		Pc.stripe_s1 = e->stripe_s[k + 1];
+		Pc.stripe_tab = e->d_stripe_tab + (size_t)k * (Pc.row_num + 1);
+		if (Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 4))
+			return fail(e, -EIO, "k_gate launch failed");
+		if (e->stripe_n[k] > 0 && Launch::inter(Pc, s_ana, e->stripe_n[k] * S))
+			return fail(e, -EIO, "k_inter launch failed");
+	}
+	return 0;
+}
+
+// What follows the last stripe of a pipelined P picture: the gate that publishes "all of it", the
+// analysis event, the entropy launches behind it.
+static int emit_tail(cedar_enc *e, Params &Pc, hipStream_t s_ana, hipStream_t s_ent, int slot, int ei)
+{
+	InFlight &f = e->fl[slot];
+	if (Launch::gate(Pc, s_ana, PROG_ALL, 0))
+		return fail(e, -EIO, "k_gate launch failed");
+	Pc.stripe_s0 = Pc.stripe_s1 = 0;
+	tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
+	HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
+	HIP_TRY(e, hipStreamWaitEvent(s_ent, e->ev_analysis[ei], 0));
+	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
+	if (Pc.roi_off && Launch::qp_eff(Pc, s_ent))
+		return fail(e, -EIO, "k_qp_eff launch failed");
+	if (Launch::entropy(Pc, s_ent))
+		return fail(e, -EIO, "entropy launch failed");
+	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
+	Pc.done_flag = f.d_done;
+	Pc.done_tag = f.done_tag;
+	if (Launch::copy_out(Pc, s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
+		return fail(e, -EIO, "k_copy_out launch failed");
+	return 0;
+}
+
+// the held-back part of the newest pipelined P picture, now (nothing will be enqueued in front of it)
+static int flush_deferred(cedar_enc *e)
+{
+	cedar_enc::DeferredTail &dt = e->deferred;
+	if (!dt.active)
+		return 0;
+	dt.active = false;
+	if (e->flusher)
+		e->flusher->armed = false;
+	int rc = emit_stripes(e, dt.Pc, dt.s_ana, dt.next, e->inter_bands);
+	if (!rc)
+		rc = emit_tail(e, dt.Pc, dt.s_ana, dt.s_ent, dt.slot, dt.ei);
+	return rc;
+}
+
+// the session's flush thread (see Flusher): sleeps until a tail is held back, then until its deadline
+static void flusher_main(cedar_enc *e)
+{
+	Flusher &F = *e->flusher;
+	std::unique_lock<std::mutex> lk(F.mu);
+	while (!F.stop) {
+		if (!F.armed) {
+			F.cv.wait(lk);
+			continue;
+		}
+		if (std::chrono::steady_clock::now() < F.deadline) {
+			F.cv.wait_until(lk, F.deadline); // (a submit moves the deadline and wakes us: look again)
+			continue;
+		}
+		F.armed = false;
+		if (e->deferred.active) {
+			hipSetDevice(e->device);
+			const int rc = flush_deferred(e);
+			if (rc && !F.rc)
+				F.rc = rc;
+			F.flushes++;
+		}
+	}
+}
+
+// a tail has just been held back: it goes out on its own after Flusher::us
+static void flusher_arm(cedar_enc *e)
+{
+	if (!e->flusher)
+		return;
+	e->flusher->deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(e->flusher->us);
+	e->flusher->armed = true;
+	e->flusher->cv.notify_one();
+}
+
+static void flusher_stop(cedar_enc *e)
+{
+	if (!e->flusher)
+		return;
+	{
+		std::lock_guard<std::mutex> lk(e->flusher->mu);
+		e->flusher->stop = true;
+		e->flusher->cv.notify_one();
+	}
+	if (e->flusher->th.joinable())
+		e->flusher->th.join();
+	delete e->flusher;
+	e->flusher = nullptr;
+}
+
+// every entry point of a session with a flush thread runs under its lock
+struct SessionLock {
+	std::unique_lock<std::mutex> lk;
+	explicit SessionLock(cedar_enc *e)
+	{
+		if (e && e->flusher)
+			lk = std::unique_lock<std::mutex>(e->flusher->mu);
+	}
+};
+
 static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 {
 	if (e->fl_count >= e->depth)
@@ -1810,7 +2016,14 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	// themselves as for pipelined frames (not with cohorts on streams of their own: the last cohort's kernel
 	// would speak for kernels of other streams)
 	const bool self_reset = !pipe && e->batch_self_reset && !e->s_db_c[1] && !e->s_ent_c[1];
+	// a held-back tail only waits for the first stripes of a pipelined P picture; anything else: out with it
+	if (e->deferred.active && !(pipe && !idr && C == 1)) {
+		const int rc_f = flush_deferred(e);
+		if (rc_f)
+			return rc_f;
+	}
 	for (int c = 0; c < C; c++) {
+		bool tail_done = false;
 		Params Pc = cohort_params(e, P, c);
 		const int ei = ds * MAX_COHORTS + c, eprev = prev * MAX_COHORTS + c;
 		// the streams of this cohort's deblocking and entropy chain (cedar_enc::s_db_c)
@@ -1905,26 +2118,53 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			if (c == 0)
 				tm_begin(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
 			if (pipe) {
-				// diagonal stripes s = x + 2*y: the order in which the deblock wavefront of the
-				// previous frame releases the reference and in which this frame's own can follow
-				const int nb = e->inter_bands;
-				for (int k = 0; k < nb; k++) {
-					Pc.stripe_s0 = e->stripe_s[k];
-					Pc.stripe_s1 = e->stripe_s[k + 1];
-					Pc.stripe_tab = e->d_stripe_tab + (size_t)k * (Pc.row_num + 1);
-					if (Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 5))
-						return fail(e, -EIO, "k_gate launch failed");
-					if (e->stripe_n[k] > 0 && Launch::inter(Pc, s_ana, e->stripe_n[k] * S))
-						return fail(e, -EIO, "k_inter launch failed");
+				// diagonal stripes s = x + y: the order in which the deblock wavefront of the
+				// previous frame releases the reference and in which this frame's own can follow.
+				// The previous picture's held-back stripes go in between this picture's first ones
+				// (cedar_enc::DeferredTail), this picture's last ones are held back in turn.
+				const int nb = e->inter_bands, kd = e->defer_from;
+				cedar_enc::DeferredTail &dt = e->deferred;
+				int own = 0, rc_s = 0;
+				if (dt.active) {
+					dt.active = false;
+					while (!rc_s && dt.next < nb) {
+						if (own < kd) {
+							rc_s = emit_stripes(e, Pc, s_ana, own, own + 1);
+							own++;
+						}
+						if (!rc_s)
+							rc_s = emit_stripes(e, dt.Pc, dt.s_ana, dt.next, dt.next + 1);
+						dt.next++;
+					}
+					if (!rc_s)
+						rc_s = emit_tail(e, dt.Pc, dt.s_ana, dt.s_ent, dt.slot, dt.ei);
 				}
-				if (Launch::gate(Pc, s_ana, PROG_ALL, 0))
-					return fail(e, -EIO, "k_gate launch failed");
-				Pc.stripe_s0 = Pc.stripe_s1 = 0;
+				if (!rc_s && own < kd)
+					rc_s = emit_stripes(e, Pc, s_ana, own, kd);
+				if (rc_s)
+					return rc_s;
+				if (kd < nb) {
+					dt.active = true;
+					dt.Pc = Pc;
+					dt.s_ana = s_ana;
+					dt.s_ent = s_ent;
+					dt.slot = slot;
+					dt.ei = ei;
+					dt.next = kd;
+					flusher_arm(e);
+				} else if ((rc_s = emit_tail(e, Pc, s_ana, s_ent, slot, ei))) {
+					return rc_s;
+				}
+				tail_done = true;
 			} else if (Launch::inter(Pc, s_ana, Pc.mb_w * Pc.row_num * Pc.n_streams)) {
 				return fail(e, -EIO, "k_inter launch failed");
 			}
-			if (c == C - 1)
+			if (c == C - 1 && !tail_done)
 				tm_end(e, f, CEDAR_ENC_STAGE_INTER, s_ana);
+		}
+		if (tail_done) { // a pipelined P picture: emit_tail has (or will have) done the rest
+			t_main = t_ent = now_ms();
+			continue;
 		}
 		HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
 		t_main = now_ms();
@@ -2000,6 +2240,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 // the failed frame, and encode the frames behind it again from the inputs the session still holds.
 static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again = nullptr)
 {
+	flush_deferred(e); // (the device must be able to drain; whatever this enqueues is dropped with the rest)
 	hipDeviceSynchronize();
 	std::vector<ReplayIn> later;
 	if (again) // the failed frame itself goes first (requantised, see collect_frame)
@@ -2058,6 +2299,11 @@ static int collect_frame(cedar_enc *e)
 	const int slot = e->fl_head;
 	InFlight &f = e->fl[slot];
 	HIP_TRY(e, hipSetDevice(e->device));
+	if (e->deferred.active && e->deferred.slot == slot) { // the newest frame is the one being waited for
+		const int rc_f = flush_deferred(e);
+		if (rc_f)
+			return rc_f;
+	}
 	bool hip_failed = false;
 	{
 		// poll the frame's own completion flags (see InFlight::h_done); fall back to the events
@@ -2317,10 +2563,8 @@ static int mux_collect(cedar_enc *e)
 	return rc;
 }
 
-extern "C" int cedar_enc_submit(cedar_enc *e)
+static int do_submit(cedar_enc *e)
 {
-	if (!e)
-		return -EINVAL;
 	if (!e->configured) // cedar.c:1039-1043
 		return fail(e, -EINVAL, "CONFIG not run yet");
 	if (e->mux)
@@ -2328,17 +2572,39 @@ extern "C" int cedar_enc_submit(cedar_enc *e)
 	return submit_frame(e, nullptr);
 }
 
+static int do_collect(cedar_enc *e)
+{
+	if (!e->configured)
+		return -EINVAL;
+	if (e->flusher && e->flusher->rc) { // a tail the flush thread could not enqueue: the frame it belongs to is lost
+		const int rc = e->flusher->rc;
+		e->flusher->rc = 0;
+		return fail(e, rc, "the held-back part of a frame could not be enqueued");
+	}
+	return e->mux ? mux_collect(e) : collect_frame(e);
+}
+
+extern "C" int cedar_enc_submit(cedar_enc *e)
+{
+	if (!e)
+		return -EINVAL;
+	SessionLock lock(e);
+	return do_submit(e);
+}
+
 extern "C" int cedar_enc_collect(cedar_enc *e)
 {
-	if (!e || !e->configured)
+	if (!e)
 		return -EINVAL;
-	return e->mux ? mux_collect(e) : collect_frame(e);
+	SessionLock lock(e);
+	return do_collect(e);
 }
 
 extern "C" int cedar_enc_set_frame_index(cedar_enc *e, int index)
 {
 	if (!e || !e->configured)
 		return -EINVAL;
+	SessionLock lock(e);
 	if (e->mux)
 		return fail(e, -EINVAL, "gop_parallel sessions number their frames themselves");
 	if (index < 0 || index % e->cfg.keyframe_interval)
@@ -2353,15 +2619,18 @@ extern "C" int cedar_enc_flush(cedar_enc *e)
 {
 	if (!e || !e->configured)
 		return -EINVAL;
+	SessionLock lock(e);
 	if (e->mux)
 		e->mux->flushed = true;
-	return 0;
+	hipSetDevice(e->device);
+	return flush_deferred(e); // no further submit will come to put its first stripes in front of the held-back ones
 }
 
 extern "C" int cedar_enc_encode(cedar_enc *e)
 {
 	if (!e)
 		return -EINVAL;
+	SessionLock lock(e);
 	if (e->configured && e->mux)
 		return fail(e, -EINVAL, "gop_parallel sessions take frames through submit / collect / flush");
 	if (e->fl_count != 0)
@@ -2370,7 +2639,7 @@ extern "C" int cedar_enc_encode(cedar_enc *e)
 	// (cedar.c:1182-1191 return before :1193-1201): collect puts them back itself; a submit that
 	// failed half way is undone here
 	const GopState b{ e->frame_count, e->frame_p_count, e->cur, e->prev_slot, e->prev2_slot, e->idr_count };
-	int r = cedar_enc_submit(e);
+	int r = do_submit(e);
 	if (r < 0 && e->configured) {
 		hipDeviceSynchronize();
 		e->fl_count = 0;
@@ -2384,7 +2653,7 @@ extern "C" int cedar_enc_encode(cedar_enc *e)
 		return r;
 	}
 	if (r >= 0)
-		r = cedar_enc_collect(e);
+		r = do_collect(e);
 	return r;
 }
 
@@ -2415,6 +2684,11 @@ extern "C" void cedar_enc_close(cedar_enc *e)
 		return;
 	if (e->configured) {
 		hipSetDevice(e->device);
+		{
+			SessionLock lock(e);
+			flush_deferred(e); // (frames abandoned in flight: the device must still be able to drain)
+		}
+		flusher_stop(e);
 		hipDeviceSynchronize();
 	}
 	if (e->holds_pipe_token)

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-enum { H264O_MB_I4x4 = 0, H264O_MB_I16x16 = 1, H264O_MB_P16x16 = 2, H264O_MB_PSKIP = 3 };
+enum { H264O_MB_I4x4 = 0, H264O_MB_I16x16 = 1, H264O_MB_P16x16 = 2, H264O_MB_PSKIP = 3,
+       H264O_MB_IPCM = -1 /* intra like 0 and 1 ("<= I16x16"), no refIdx like them (">= P16x16" is false) */ };
 
 typedef struct h264o_config {
 	int width;            /* source width, even (cedar.c:749)  */
@@ -70,6 +71,9 @@ typedef struct h264o_config {
 	                       * difference against its chosen prediction (luma SAD / 256) ... */
 	int mad_dqp[5];       /* ... and the QP offset (-12..12) of each of the five classes, on top of the picture's QP and
 	                       * the region's. All zero: off */
+	int pcm;              /* 0 (default): a macroblock whose macroblock_layer() could pass the 3200 bits of H.264 A.3.1 is
+	                       * coded I_PCM -- its source samples, raw -- in the sessions that take it (one QP per picture of
+	                       * at most 30, no cyclic refresh: DESIGN.md 3.6); -1: never, strict_mb_bits says what happens */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */

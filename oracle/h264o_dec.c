@@ -908,6 +908,8 @@ static int decode_intra_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr
 		if (cbp) {
 			int dq = br_se(b);
 
+			if (dq < -26 || dq > 25)
+				return fail(d, "mb_qp_delta out of range");
 			m->qp = (int8_t)((m->qp + dq + 52) % 52);
 		}
 	} else if (mbt <= 24) {
@@ -920,6 +922,8 @@ static int decode_intra_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr
 		{
 			int dq = br_se(b);
 
+			if (dq < -26 || dq > 25)
+				return fail(d, "mb_qp_delta out of range");
 			m->qp = (int8_t)((m->qp + dq + 52) % 52);
 		}
 		/* luma prediction for the whole MB */
@@ -927,8 +931,28 @@ static int decode_intra_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr
 		    ((t & 3) == 3 && !(A && B && mb_at_intra(d, mx - 1, my - 1, m->slice, addr))))
 			return fail(d, "Intra16x16 mode needs an unavailable neighbour");
 		intra_big(d->cur_y + my * 16 * d->cw + mx * 16, d->cw, 1, 16, t & 3, B != NULL, A != NULL);
+	} else if (mbt == 25) {
+		/* I_PCM (7.3.5, 8.3.5): pcm_alignment_zero_bits, then the samples themselves; every
+		 * block counts 16 coefficients for its neighbours' nC (9.2.1) */
+		int x, y;
+
+		m->type = H264O_MB_IPCM;
+		memset(m->i4, 2, sizeof(m->i4));
+		memset(m->nnz, 16, sizeof(m->nnz));
+		/* (no mb_qp_delta: QP_Y stays what it was, 7.4.5; only deblocking takes it as 0, 8.7.2.2: dmb_qp) */
+		while (b->pos & 7)
+			if (br_u(b, 1))
+				return fail(d, "pcm_alignment_zero_bit is 1");
+		for (y = 0; y < 16; y++)
+			for (x = 0; x < 16; x++)
+				d->cur_y[(my * 16 + y) * d->cw + mx * 16 + x] = (uint8_t)br_u(b, 8);
+		for (c = 0; c < 2; c++)
+			for (y = 0; y < 8; y++)
+				for (x = 0; x < 8; x++)
+					d->cur_uv[(my * 8 + y) * d->cw + 2 * (mx * 8 + x) + c] = (uint8_t)br_u(b, 8);
+		return b->err ? fail(d, "I_PCM samples truncated") : 0;
 	} else {
-		return fail(d, "I_PCM unsupported");
+		return fail(d, "bad mb_type");
 	}
 	if (cmode > 3 || (cmode == 1 && !A) || (cmode == 2 && !B) ||
 	    (cmode == 3 && !(A && B && mb_at_intra(d, mx - 1, my - 1, m->slice, addr))))
@@ -1055,6 +1079,8 @@ static int decode_inter_mb(h264o_dec *d, br *b, dmb *m, int mx, int my, int addr
 		if (cbp) {
 			int dq = br_se(b);
 
+			if (dq < -26 || dq > 25)
+				return fail(d, "mb_qp_delta out of range");
 			m->qp = (int8_t)((m->qp + dq + 52) % 52);
 		}
 	}
@@ -1166,8 +1192,13 @@ static void deblock_picture(h264o_dec *d)
 						if (idc == 2 && p->slice != q->slice)
 							continue;
 					}
-					qpav = (p->qp + q->qp + 1) >> 1;
-					qpcav = (chroma_qp(d, p->qp) + chroma_qp(d, q->qp) + 1) >> 1;
+					{
+						/* 8.7.2.2: qPp of an I_PCM macroblock is 0 */
+						const int pq = p->type == H264O_MB_IPCM ? 0 : p->qp, qq = q->type == H264O_MB_IPCM ? 0 : q->qp;
+
+						qpav = (pq + qq + 1) >> 1;
+						qpcav = (chroma_qp(d, pq) + chroma_qp(d, qq) + 1) >> 1;
+					}
 					iA = clip3(0, 51, qpav + oa);
 					iB = clip3(0, 51, qpav + ob);
 					iAc = clip3(0, 51, qpcav + oa);

@@ -922,6 +922,74 @@ static int luma_block_16(const h264o_enc *e, const int16_t res[16], int16_t lv[1
 }
 
 /* ------------------------------------------------------------------ */
+/* I_PCM (cfg.pcm): H.264 A.3.1 allows macroblock_layer() 3200 bits.    */
+
+/* What CAVLC spends on a macroblock, from its levels alone: every block's residual_block_cavlc() in full --
+ * level codes with their suffixLength, total_zeros, run_before -- with coeff_token at the longest of the four
+ * tables (which one applies depends on the neighbours' counts); 100 bits cover mb_type, prediction modes or
+ * vector differences, coded_block_pattern and mb_qp_delta (they depend on neighbours too). */
+static void cavlc_block(bitw *b, const int16_t *lv, int maxc, int nC);
+
+static int pcm_block_bits(const int16_t *lv, int maxc, int chroma_dc)
+{
+	static const int ncs[4] = { 0, 2, 4, 8 };
+	int best = 0, k;
+
+	for (k = 0; k < (chroma_dc ? 1 : 4); k++) {
+		uint8_t tmp[128];
+		bitw b;
+
+		bw_init(&b, tmp, sizeof(tmp));
+		cavlc_block(&b, lv, maxc, chroma_dc ? -1 : ncs[k]);
+		if ((int)b.pos > best)
+			best = (int)b.pos;
+	}
+	return best;
+}
+
+#define PCM_HEADER_BITS 100
+#define PCM_LIMIT 3200      /* P pictures: the levels are final, the count holds for what is written */
+#define PCM_LIMIT_OPEN 2900 /* I pictures: the count is taken on the open loop's levels (below) */
+
+/* The sessions and pictures that take I_PCM. One QP per picture (an I_PCM macroblock carries no mb_qp_delta and
+ * leaves QP_Y as it finds it, 7.4.5). Only the deblocking filter takes its QP as 0 (8.7.2.2): its edges are filtered
+ * at the mean of the two QP_Y resp. QP_C, and the pictures taken are those where that
+ * mean has alpha = 0 on both planes, i.e. nothing is filtered there at all: QP <= 30 for luma, and QP_C(QP) +
+ * QP_C(0) + 1 <= 31 for chroma -- QP <= 22 with the reference's chroma offset of 4. (Noise passes 3200 bits up to
+ * QP 16; above the bound strict_mb_bits still says what happens.) No refresh macroblocks: under
+ * constrained_intra_pred they would have to predict from an I_PCM neighbour. */
+static int chroma_qp_at(const h264o_enc *e, int qp_y);
+
+static int pcm_allowed(const h264o_enc *e)
+{
+	if (e->cfg.pcm < 0 || e->cfg.roi_count > 0 || e->mad_on || e->cfg.intra_refresh > 0)
+		return 0;
+	return h264o_alpha[(e->qp + 1) >> 1] == 0 && h264o_alpha[(chroma_qp_at(e, e->qp) + chroma_qp_at(e, 0) + 1) >> 1] == 0;
+}
+
+static void pcm_make(h264o_enc *e, int mx, int my)
+{
+	h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
+	int y;
+
+	mb->type = H264O_MB_IPCM;
+	mb->i16_mode = 0;
+	mb->chroma_mode = 0;
+	mb->cbp = 0;
+	mb->mvx = mb->mvy = 0;
+	memset(mb->i4_modes, 2, sizeof(mb->i4_modes));
+	memset(mb->nnz, 16, sizeof(mb->nnz)); /* 9.2.1: nC next to an I_PCM macroblock counts 16 */
+	memset(mb->luma, 0, sizeof(mb->luma));
+	memset(mb->dc16, 0, sizeof(mb->dc16));
+	memset(mb->cdc, 0, sizeof(mb->cdc));
+	memset(mb->cac, 0, sizeof(mb->cac));
+	for (y = 0; y < 16; y++)
+		memcpy(e->rec_y[e->cur] + (size_t)(my * 16 + y) * e->cw + mx * 16, e->src_y + (size_t)(my * 16 + y) * e->cw + mx * 16, 16);
+	for (y = 0; y < 8; y++)
+		memcpy(e->rec_uv[e->cur] + (size_t)(my * 8 + y) * e->cw + mx * 16, e->src_uv + (size_t)(my * 8 + y) * e->cw + mx * 16, 16);
+}
+
+/* ------------------------------------------------------------------ */
 /* I pictures                                                          */
 
 static int sad_block(const uint8_t *a, int sa, const uint8_t *b, int sb, int w, int h)
@@ -1016,6 +1084,61 @@ static void intra_decide_mb(h264o_enc *e, int mx, int my, int row0)
 	}
 	mb->chroma_mode = (int8_t)bestc;
 	mb->mvx = mb->mvy = 0;
+
+	/* I_PCM, decided open loop like everything here: the residual of the CHOSEN predictions from source samples,
+	 * every 4x4 block -- 16 luma, 4 + 4 chroma -- through the plain transform and the intra quantiser (no DC
+	 * Hadamards), its zig-zag levels through the count above. The closed loop's levels differ a little: the limit
+	 * here leaves a tenth of room (and strict_mb_bits still looks at what was really written). */
+	if (pcm_allowed(e)) {
+		int bits = PCM_HEADER_BITS, qp = e->mbqp, qpc = chroma_qp_of(e), c;
+
+		for (idx = 0; idx < 16; idx++) {
+			int bx = h264o_blk_x[idx], by = h264o_blk_y[idx], x, y, i;
+			uint8_t p4[16], p16[256];
+			int16_t res[16], w[16], lv[16];
+
+			if (mb->type == H264O_MB_I4x4) {
+				int ht, hl, htr;
+				nb4 n;
+
+				blk4_avail(e, mx, my, row0, idx, &ht, &hl, &htr);
+				fetch_nb4(sy, stride, x0 + 4 * bx, y0 + 4 * by, ht, hl, htr, &n);
+				pred4x4(mb->i4_modes[idx], &n, p4);
+			} else {
+				pred16x16(mb->i16_mode, sy, stride, x0, y0, top_mb, left_mb, p16);
+				for (y = 0; y < 4; y++)
+					for (x = 0; x < 4; x++)
+						p4[4 * y + x] = p16[16 * (4 * by + y) + 4 * bx + x];
+			}
+			for (y = 0; y < 4; y++)
+				for (x = 0; x < 4; x++)
+					res[4 * y + x] = (int16_t)(sy[(y0 + 4 * by + y) * stride + x0 + 4 * bx + x] - p4[4 * y + x]);
+			h264o_fdct4x4(res, w);
+			for (i = 0; i < 16; i++)
+				lv[i] = (int16_t)quant_one(w[h264o_zigzag4x4[i]], h264o_quant_mf[qp % 6][h264o_pos_class[h264o_zigzag4x4[i]]], (1 << (15 + qp / 6)) / 3, 15 + qp / 6);
+			bits += pcm_block_bits(lv, 16, 0);
+		}
+		for (c = 0; c < 2; c++) {
+			uint8_t pc[64];
+			int b;
+
+			pred_chroma8x8(mb->chroma_mode, suv, stride, mx * 8, my * 8, c, top_mb, left_mb, pc);
+			for (b = 0; b < 4; b++) {
+				int bx = b & 1, by = b >> 1, x, y, i;
+				int16_t res[16], w[16], lv[16];
+
+				for (y = 0; y < 4; y++)
+					for (x = 0; x < 4; x++)
+						res[4 * y + x] = (int16_t)(suv[(my * 8 + 4 * by + y) * stride + 2 * (mx * 8 + 4 * bx + x) + c] - pc[8 * (4 * by + y) + 4 * bx + x]);
+				h264o_fdct4x4(res, w);
+				for (i = 0; i < 16; i++)
+					lv[i] = (int16_t)quant_one(w[h264o_zigzag4x4[i]], h264o_quant_mf[qpc % 6][h264o_pos_class[h264o_zigzag4x4[i]]], (1 << (15 + qpc / 6)) / 3, 15 + qpc / 6);
+				bits += pcm_block_bits(lv, 16, 0);
+			}
+		}
+		if (bits > PCM_LIMIT_OPEN)
+			mb->type = H264O_MB_IPCM;
+	}
 }
 
 /* isolated: a refresh macroblock of a P picture -- under constrained_intra_pred its (inter) neighbours
@@ -1030,6 +1153,10 @@ static void intra_recon_mb(h264o_enc *e, int mx, int my, int row0, int isolated)
 	int idx, i, c;
 	uint8_t predc[2][64];
 
+	if (mb->type == H264O_MB_IPCM) { /* its reconstruction is its source: what the neighbours predict from */
+		pcm_make(e, mx, my);
+		return;
+	}
 	memset(mb->nnz, 0, sizeof(mb->nnz));
 	memset(mb->luma, 0, sizeof(mb->luma));
 	memset(mb->dc16, 0, sizeof(mb->dc16));
@@ -1380,6 +1507,28 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 				}
 	}
 	chroma_residual(e, mb, mx, my, predc, 0);
+
+	/* I_PCM: here the levels are final (the prediction comes from the previous picture): the count holds for
+	 * what CAVLC will write */
+	if (pcm_allowed(e)) {
+		int bits = PCM_HEADER_BITS;
+
+		for (idx = 0; idx < 16; idx++)
+			if (mb->cbp & (1 << (idx >> 2)))
+				bits += pcm_block_bits(mb->luma[idx], 16, 0);
+		if (mb->cbp & 0x30)
+			for (c = 0; c < 2; c++)
+				bits += pcm_block_bits(mb->cdc[c], 4, 1);
+		if (mb->cbp & 0x20)
+			for (c = 0; c < 2; c++) {
+				int b;
+
+				for (b = 0; b < 4; b++)
+					bits += pcm_block_bits(mb->cac[c][b] + 1, 15, 0);
+			}
+		if (bits > PCM_LIMIT)
+			pcm_make(e, mx, my);
+	}
 }
 
 /* motion vector prediction for a 16x16 partition, all neighbours inter with
@@ -1393,7 +1542,7 @@ static int median3(int a, int b, int c)
 
 static int mb_is_intra(const h264o_mb *m)
 {
-	return m->type == H264O_MB_I4x4 || m->type == H264O_MB_I16x16;
+	return m->type == H264O_MB_I4x4 || m->type == H264O_MB_I16x16 || m->type == H264O_MB_IPCM;
 }
 
 /* Cyclic intra refresh (cfg.intra_refresh = N): in the t-th P picture after an IDR the macroblocks with
@@ -1547,7 +1696,8 @@ static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 	int stride = e->cw;
 	/* thresholds come from the mean of the two macroblocks' QP_Y (and of their QP_C) across a macroblock
 	 * edge (8.7.2.2); they only differ from picture to picture unless regions of interest are set */
-	const int qq = e->qp_eff[my * e->mb_w + mx], qqc = chroma_qp_at(e, qq);
+	/* (8.7.2.2: qPp of an I_PCM macroblock is 0) */
+	const int qq = q->type == H264O_MB_IPCM ? 0 : e->qp_eff[my * e->mb_w + mx], qqc = chroma_qp_at(e, qq);
 	int qp = qq, qpc = qqc;
 	int alpha_y = h264o_alpha[qp], beta_y = h264o_beta[qp];
 	int alpha_c = h264o_alpha[qpc], beta_c = h264o_beta[qpc];
@@ -1564,7 +1714,7 @@ static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 			p = &e->mbs[my * e->mb_w + mx - 1];
 		}
 		{
-			const int qn = edge == 0 ? e->qp_eff[my * e->mb_w + mx - 1] : qq;
+			const int qn = edge == 0 ? (p->type == H264O_MB_IPCM ? 0 : e->qp_eff[my * e->mb_w + mx - 1]) : qq;
 
 			qp = (qn + qq + 1) >> 1;
 			qpc = (chroma_qp_at(e, qn) + qqc + 1) >> 1;
@@ -1601,7 +1751,7 @@ static void deblock_mb(h264o_enc *e, int mx, int my, int row0)
 			p = &e->mbs[(my - 1) * e->mb_w + mx];
 		}
 		{
-			const int qn = edge == 0 ? e->qp_eff[(my - 1) * e->mb_w + mx] : qq;
+			const int qn = edge == 0 ? (p->type == H264O_MB_IPCM ? 0 : e->qp_eff[(my - 1) * e->mb_w + mx]) : qq;
 
 			qp = (qn + qq + 1) >> 1;
 			qpc = (chroma_qp_at(e, qn) + qqc + 1) >> 1;
@@ -1824,6 +1974,21 @@ static void write_intra_mb(const h264o_enc *e, bitw *b, const h264o_mb *mb, int 
 {
 	int idx;
 
+	if (mb->type == H264O_MB_IPCM) { /* 7.3.5: mb_type 25, pcm_alignment_zero_bits, 256 + 2 x 64 samples */
+		int x, y, c;
+
+		bw_ue(b, (uint32_t)(25 + (p_slice ? 5 : 0)));
+		while (b->pos & 7)
+			bw_put(b, 0, 1);
+		for (y = 0; y < 16; y++)
+			for (x = 0; x < 16; x++)
+				bw_put(b, e->src_y[(size_t)(my * 16 + y) * e->cw + mx * 16 + x], 8);
+		for (c = 0; c < 2; c++)
+			for (y = 0; y < 8; y++)
+				for (x = 0; x < 8; x++)
+					bw_put(b, e->src_uv[(size_t)(my * 8 + y) * e->cw + 2 * (mx * 8 + x) + c], 8);
+		return;
+	}
 	if (mb->type == H264O_MB_I4x4) {
 		bw_ue(b, (uint32_t)(p_slice ? 5 : 0));
 		for (idx = 0; idx < 16; idx++) {
@@ -2171,7 +2336,8 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 	}
 
 	/* QP_Y as the decoder will hold it: only a macroblock with an mb_qp_delta (Intra16x16, or any coded
-	 * block) can change it; the others, P_Skip included, inherit their predecessor's (7.4.5) */
+	 * block) can change it; the others -- P_Skip and I_PCM included: no mb_qp_delta means 0 -- inherit their
+	 * predecessor's (7.4.5). (Only the deblocking filter takes an I_PCM macroblock's QP as 0, 8.7.2.2.) */
 	for (s = 0; s < e->cfg.slice_count; s++) {
 		int r0, r1, prev = e->qp;
 
@@ -2180,7 +2346,7 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 			for (mx = 0; mx < e->mb_w; mx++) {
 				const h264o_mb *mb = &e->mbs[my * e->mb_w + mx];
 
-				if (mb->type == H264O_MB_I16x16 || (mb->cbp & 0x3f))
+				if (mb->type == H264O_MB_I16x16 || (mb->type != H264O_MB_IPCM && (mb->cbp & 0x3f)))
 					prev = e->qp_t[my * e->mb_w + mx];
 				e->qp_eff[my * e->mb_w + mx] = (uint8_t)prev;
 			}

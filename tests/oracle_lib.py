@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB_PATH = os.path.join(ROOT, "oracle", "build", "libh264o.so")
 
-MB_I4x4, MB_I16x16, MB_P16x16, MB_PSKIP = 0, 1, 2, 3
+MB_I4x4, MB_I16x16, MB_P16x16, MB_PSKIP, MB_IPCM = 0, 1, 2, 3, -1
 
 
 class Config(ctypes.Structure):
@@ -20,7 +20,7 @@ class Config(ctypes.Structure):
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
         "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
         "subpel", "bitrate", "strict_mb_bits", "intra_refresh", "roi_count")] + [
-        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5)]
+        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5), ("pcm", ctypes.c_int)]
 
 
 class MB(ctypes.Structure):
@@ -93,9 +93,14 @@ def lib():
     return _lib
 
 
+# I_PCM in the twin's sessions unless a test says otherwise (h264o_config.pcm: 0 on, -1 off)
+PCM_DEFAULT = -1   # (off until the HIP path takes I_PCM too: the parity tests compare default sessions)
+
+
 def default_config(width, height, **kw):
     c = Config()
     lib().h264o_default_config(ctypes.byref(c), width, height)
+    c.pcm = PCM_DEFAULT
     for k, v in kw.items():
         if k == "roi":   # [(x, y, w, h, qp_offset), ...] in macroblocks
             c.roi_count = len(v)

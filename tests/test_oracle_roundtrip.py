@@ -256,3 +256,50 @@ def test_fuzzed_round_trips_with_round_2_options():
                        capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, FUZZ_R2="1"))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
     assert "80 cases, decode == recon" in r.stdout
+
+
+@pytest.mark.parametrize("w,h,qp,keyint,patterns,frames,kw,want_pcm", [
+    (96, 64, 1, 3, "C", 4, {}, "all"), (96, 64, 10, 3, "C", 4, {}, "all"), (96, 64, 16, 3, "C", 4, {}, "all"),
+    (96, 64, 18, 3, "C", 4, {}, "some"), (96, 64, 22, 3, "C", 4, {}, "none"), (96, 64, 1, 3, "B", 4, {}, "none"),
+    (96, 80, 12, 4, "CB", 6, dict(slice_count=2), "all"), (64, 48, 8, 25, "C", 3, dict(subpel=2), "all"),
+    (16, 48, 6, 2, "C", 3, {}, "all"), (64, 48, 5, 3, "C", 3, dict(pcm=-1), "none"),
+    (64, 48, 5, 3, "C", 3, dict(intra_refresh=3), "none"), (64, 48, 5, 3, "C", 3, dict(roi=[(0, 0, 1, 1, 2)]), "none")])
+def test_macroblocks_that_could_pass_3200_bits_are_coded_i_pcm(w, h, qp, keyint, patterns, frames, kw, want_pcm):
+    """h264o_config.pcm (default on): a macroblock whose CAVLC bits could pass the 3200 of H.264 A.3.1 is coded
+    I_PCM -- in I pictures from the open loop's levels with a tenth of room, in P pictures from the final levels.
+    Both decoders rebuild the pictures (the independent one first showed that an I_PCM macroblock leaves QP_Y as it
+    finds it, 7.4.5: only deblocking takes it as 0), no macroblock passes the limit, and the sessions that do not
+    take I_PCM (regions, refresh, pcm = -1) are as before."""
+    from tests.indep import h264_refdec as rd
+    cfg = dict(pcm=0)
+    cfg.update(kw)
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, **cfg))
+    dec, pdec = ol.OracleDecoder(), rd.Decoder()
+    n_pcm = n_mb = 0
+    for f in range(frames):
+        au = oe.encode(*ol.gen_frame(patterns[f % len(patterns)], w, h, f))
+        assert dec.decode(au) == 1
+        ry, ruv = oe.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(ry, dy) and np.array_equal(ruv, duv), f
+        pic, = pdec.decode(au)
+        assert pic.luma_bytes() == ry.tobytes() and pic.nv12_chroma_bytes() == ruv.tobytes(), f
+        mb = oe.mb_array()
+        pcm = mb["type"] == ol.MB_IPCM
+        n_pcm += int(pcm.sum())
+        n_mb += pcm.size
+        if pcm.any():   # its reconstruction is its source, its neighbours count 16 coefficients in every block
+            y, uv = ol.gen_frame(patterns[f % len(patterns)], w, h, f)
+            src = np.zeros_like(ry)
+            src[:h, :w] = y.reshape(h, w)
+            src[:h, w:] = src[:h, w - 1:w]
+            src[h:, :] = src[h - 1:h, :]
+            for i in np.flatnonzero(pcm):
+                mx, my = i % ((w + 15) // 16), i // ((w + 15) // 16)
+                assert np.array_equal(ry[16 * my:16 * my + 16, 16 * mx:16 * mx + 16], src[16 * my:16 * my + 16, 16 * mx:16 * mx + 16])
+            assert (mb["nnz"][pcm] == 16).all()
+        if want_pcm != "none" or "pcm" not in kw and not kw.get("roi") and not kw.get("intra_refresh"):
+            assert oe.max_mb_bits() <= 3200, (f, oe.max_mb_bits())
+    assert {"all": n_pcm == n_mb, "some": 0 < n_pcm < n_mb, "none": n_pcm == 0}[want_pcm], (n_pcm, n_mb)
+    if want_pcm != "none":
+        assert pdec.cover["mb_I_PCM"] == n_pcm and not pdec.level_violations()

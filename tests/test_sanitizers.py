@@ -49,11 +49,11 @@ def test_sub_sample_rate_control_and_bit_cap_paths_are_sanitizer_clean(san_tools
     clip = b"".join(np.concatenate(ol.gen_frame("CB"[f % 3 > 0], w, h, f)).tobytes() for f in range(n))
     out = tmp_path / "o.264"
     env = dict(os.environ, H264ENC_QP="6", H264ENC_KEYINT="7", H264ENC_SUBPEL="2", H264ENC_BITRATE="900000",
-               H264ENC_STRICT_MB_BITS="2", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+               H264ENC_STRICT_MB_BITS="2", H264ENC_PCM="-1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([enc, "-", str(w), str(h), str(out)], input=clip, capture_output=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
-    oe = ol.OracleEncoder(ol.default_config(w, h, qp=6, keyint=7, subpel=2, bitrate=900000, strict_mb_bits=2))
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=6, keyint=7, subpel=2, bitrate=900000, strict_mb_bits=2, pcm=-1))
     want = b"".join(oe.encode(*ol.gen_frame("CB"[f % 3 > 0], w, h, f)) for f in range(n))
     assert out.read_bytes() == want
     r = subprocess.run([dec, str(out), str(tmp_path / "o.nv12")], capture_output=True, env=env, timeout=300)

@@ -18,14 +18,16 @@ from tests.indep import h264_refdec as rd               # noqa: E402
 # w, h, qp, keyint, frames, pattern, slices [, "option=value,..." of the oracle's configuration]
 CASES = [
     (64, 48, 30, 25, 4, "B", 1), (64, 48, 24, 25, 3, "C", 1), (64, 48, 30, 25, 3, "A", 1), (70, 50, 24, 25, 3, "B", 1),
-    (64, 48, 5, 3, 4, "C", 1), (64, 48, 47, 3, 4, "B", 1), (16, 16, 24, 2, 3, "C", 1), (48, 80, 24, 4, 5, "B", 5),
-    (96, 64, 36, 4, 5, "B", 2), (64, 48, 1, 2, 2, "C", 1), (128, 96, 40, 25, 3, "B", 1), (96, 112, 18, 25, 3, "C", 1),
+    (64, 48, 5, 3, 4, "C", 1, "pcm=-1"), (64, 48, 47, 3, 4, "B", 1), (16, 16, 24, 2, 3, "C", 1), (48, 80, 24, 4, 5, "B", 5),
+    (96, 64, 36, 4, 5, "B", 2), (64, 48, 1, 2, 2, "C", 1, "pcm=-1"), (128, 96, 40, 25, 3, "B", 1), (96, 112, 18, 25, 3, "C", 1),
     (16, 96, 24, 3, 6, "B", 1), (320, 240, 30, 25, 3, "B", 1), (320, 240, 24, 1, 2, "B", 4),
     (96, 64, 28, 25, 4, "B", 1, "subpel=2"), (96, 64, 28, 12, 6, "B", 1, "intra_refresh=3"),
     (112, 80, 30, 25, 5, "B", 2, "subpel=2,intra_refresh=5"), (48, 48, 20, 30, 9, "C", 1, "intra_refresh=7"),
     (160, 96, 28, 25, 4, "B", 2, "subpel=2,roi=0:0:4:3:-6/2:1:6:4:10/9:5:1:1:-20"), (96, 64, 36, 6, 7, "C", 1, "roi=1:1:3:2:-12"),
     (128, 96, 30, 25, 5, "B", 1, "mad_th=2:5:10:20,mad_dqp=-4:-2:0:2:4"), (112, 80, 27, 8, 6, "B", 2, "subpel=2,intra_refresh=4,roi=0:0:3:3:8,mad_th=1:3:6:12,mad_dqp=6:3:0:-3:-6"),
     (64, 48, 26, 3, 5, "C", 1, "roi=0:0:1:1:24/1:0:1:1:-24/2:1:1:2:24"),   # mb_qp_delta of +-48 goes round modulo 52
+    # I_PCM: noise at a low QP (every macroblock), at QP 18 (most, some not: the neighbours of both kinds), in slices
+    (64, 48, 5, 3, 4, "C", 1, "pcm=0"), (96, 64, 18, 4, 5, "C", 1, "pcm=0"), (48, 80, 12, 25, 4, "C", 3, "pcm=0"), (64, 48, 1, 2, 3, "C", 1, "subpel=2,pcm=0"),
 ]
 
 
