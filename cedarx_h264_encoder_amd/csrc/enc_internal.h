@@ -7,7 +7,8 @@
 
 namespace cedar {
 
-enum : int { MB_I4x4 = 0, MB_I16x16 = 1, MB_P16x16 = 2, MB_PSKIP = 3 };
+enum : int { MB_I4x4 = 0, MB_I16x16 = 1, MB_P16x16 = 2, MB_PSKIP = 3,
+	     MB_IPCM = -1 }; // intra like 0 and 1 ("type < MB_P16x16"), no refIdx like them
 
 // Per-macroblock decision record (8 bytes). Written by the analysis kernels,
 // read by deblock and entropy. Plays the role of the VE's MBINFO / MVBUF
@@ -33,6 +34,9 @@ constexpr int COEF_PER_MB = 408;  // 816 bytes = 51 x 16 B
 
 constexpr int NNZ_PER_MB = 24;    // 16 luma (raster bx+4*by), 4 Cb, 4 Cr
 constexpr int MB_BITS_LIMIT = 3200; // H.264 A.3.1: bits of one macroblock_layer()
+constexpr int PCM_HEADER_BITS = 100;   // I_PCM decision: what mb_type, modes / vector differences, cbp and mb_qp_delta can cost at most
+constexpr int PCM_LIMIT_OPEN = 2900;   // ... in I pictures, where the count is taken on the open loop's levels
+constexpr uint32_t PCM_MB_BITS_FLAG = 0x80000000u; // Params::mb_bits of an I_PCM macroblock: its header bits | this
 constexpr int SLOT_BYTES = 2048;  // private CAVLC bit buffer of one macroblock
 constexpr int SLOT_WORDS = SLOT_BYTES / 4;
 constexpr int ESC_CHUNK = 32;     // bytes of RBSP per emulation-prevention thread
@@ -83,6 +87,7 @@ struct Params {
 	int32_t qp, qpc, search_range, lambda;
 	int32_t subpel;             // motion vector precision: 0 whole samples, 1 half, 2 quarter
 	int32_t is_idr;
+	int32_t pcm;                // this picture takes I_PCM macroblocks (cedar_enc_config_ext.pcm, and its QP leaves their edges unfiltered)
 	int32_t intra_refresh;      // N >= 3: macroblocks with (x + 2*y + refresh_t) % N == 0 of a P picture are coded intra; 0 off
 	int32_t refresh_t;          // P pictures since the IDR (1 for the first)
 	// quantiser, luma (index = position class 0 even/even, 1 odd/odd, 2 mixed)

@@ -263,7 +263,12 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 	const int16_t *cf = p.coef + mbaddr * COEF_PER_MB;
 	int skip = 0;
 
-	if (p.is_idr) {
+	const bool is_pcm = mi.type == MB_IPCM;
+	if (is_pcm) {
+		// I_PCM (7.3.5): mb_type 25 (+ 5 in a P slice); pcm_alignment_zero_bits and the 384 samples are placed by
+		// k_pack, straight from the source planes, at the byte position k_scan finds
+		bw_ue(b, (uint32_t)(p.is_idr ? 25 : 30));
+	} else if (p.is_idr) {
 		if (mi.type == MB_I4x4) {
 			bw_ue(b, 0);
 			const int8_t *mo = p.i4modes + mbaddr * 16;
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(64) void k_cavlc(Params p)
 		else
 			b.overflow = 1;
 	}
-	p.mb_bits[mbaddr] = total;
+	p.mb_bits[mbaddr] = is_pcm ? total | PCM_MB_BITS_FLAG : total;
 	p.skip[mbaddr] = (uint8_t)skip;
 	if (b.overflow)
 		atomicOr(&p.stream_size[p.n_streams + 1], 1u);
@@ -569,9 +574,12 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 	int skip = 0;
 	const int cbp = mi.cbp & 0x3f;
 
+	const bool is_pcm = mi.type == MB_IPCM;
 	if (valid && hl == 0) {
 		// ---- macroblock header ----
-		if (p.is_idr) {
+		if (is_pcm) { // I_PCM: mb_type only; alignment and samples come from k_pack (see k_cavlc)
+			lw_ue(b, (uint32_t)(p.is_idr ? 25 : 30));
+		} else if (p.is_idr) {
 			if (mi.type == MB_I4x4) {
 				lw_ue(b, 0);
 				const int8_t *mo = s_modes[half][0];
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 		for (int w = hl; w < nwords && w < SLOT_WORDS; w += 32)
 			slot[w] = s_out[half][w];
 		if (hl == 0) {
-			p.mb_bits[mbaddr] = (uint32_t)total;
+			p.mb_bits[mbaddr] = is_pcm ? (uint32_t)total | PCM_MB_BITS_FLAG : (uint32_t)total;
 			p.skip[mbaddr] = (uint8_t)skip;
 		}
 		if (b.overflow || (hl == 0 && nwords + 1 >= SLOT_WORDS))
@@ -768,6 +776,55 @@ DEVI int block_scan_incl(int v, int *s_tmp)
 	return v;
 }
 
+// Positions in a slice with I_PCM macroblocks (k_scan). f(pos) = pcm ? align8(pos + a) + b : pos + a.
+struct PosMap {
+	int a, b, pcm;
+};
+
+DEVI int posmap_apply(const PosMap &f, int pos)
+{
+	return f.pcm ? ((pos + f.a + 7) & ~7) + f.b : pos + f.a;
+}
+
+// g after f. align8(x + y) = x + align8(y) for x a multiple of 8: behind an I_PCM macroblock everything is aligned.
+DEVI PosMap posmap_then(const PosMap &f, const PosMap &g)
+{
+	if (!g.pcm)
+		return f.pcm ? PosMap{ f.a, f.b + g.a, 1 } : PosMap{ f.a + g.a, 0, 0 };
+	return f.pcm ? PosMap{ f.a, ((f.b + g.a + 7) & ~7) + g.b, 1 } : PosMap{ f.a + g.a, g.b, 1 };
+}
+
+// inclusive scan of position maps over the block (the structure of block_scan_incl)
+DEVI PosMap block_scan_posmap(PosMap v, PosMap *s_pm)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (int)(blockDim.x >> 6);
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const PosMap o{ __shfl_up(v.a, off, 64), __shfl_up(v.b, off, 64), __shfl_up(v.pcm, off, 64) };
+		if (lane >= off)
+			v = posmap_then(o, v);
+	}
+	__syncthreads();
+	if (lane == 63)
+		s_pm[wave] = v;
+	__syncthreads();
+	if (wave == 0) {
+		PosMap t = lane < nwaves ? s_pm[lane] : PosMap{ 0, 0, 0 };
+#pragma unroll
+		for (int off = 1; off < 16; off <<= 1) {
+			const PosMap o{ __shfl_up(t.a, off, 64), __shfl_up(t.b, off, 64), __shfl_up(t.pcm, off, 64) };
+			if (lane >= off)
+				t = posmap_then(o, t);
+		}
+		if (lane < 16)
+			s_pm[16 + lane] = t;
+	}
+	__syncthreads();
+	if (wave > 0)
+		v = posmap_then(s_pm[16 + wave - 1], v);
+	return v;
+}
+
 // ------------------------------------------------------------------------
 // k_scan: one SCAN_THREADS-thread block per unit. Entry e of bit_off / run_before:
 //   e in [0, n): macroblock e of the unit; e == n: slice trailer.
@@ -782,6 +839,7 @@ DEVI int block_scan_incl(int v, int *s_tmp)
 __global__ __launch_bounds__(1024) void k_scan(Params p)
 {
 	__shared__ int s_tmp[32];
+	__shared__ PosMap s_pm[32];
 	__shared__ int s_carry_max, s_carry_sum;
 	const int unit = blockIdx.x;
 	const int st = unit / p.slice_num, ls = unit % p.slice_num;
@@ -816,22 +874,49 @@ __global__ __launch_bounds__(1024) void k_scan(Params p)
 			prev = threadIdx.x == 0 ? cmax : s_tmp[(threadIdx.x >> 6) - 1];
 		const int r = (mb && !sk) || trailer ? e - 1 - prev : 0;
 		int bits = 0;
-		if (mb && !sk)
-			bits = (is_p ? ue_len((uint32_t)r) : 0) + (int)p.mb_bits[mb0 + e];
-		else if (trailer)
+		bool pcm_e = false;
+		if (mb && !sk) {
+			const uint32_t mbb = p.mb_bits[mb0 + e];
+			pcm_e = (mbb & PCM_MB_BITS_FLAG) != 0;
+			bits = (is_p ? ue_len((uint32_t)r) : 0) + (int)(mbb & ~PCM_MB_BITS_FLAG);
+		} else if (trailer) {
 			bits = ((is_p && r > 0) ? ue_len((uint32_t)r) : 0) + 1; // + rbsp stop bit
-		int incl = block_scan_incl<false>(bits, s_tmp);
-		const int csum = s_carry_sum;
-		if (mb || trailer) {
-			off[e] = (uint32_t)(csum + incl - bits);
-			run[e] = (uint32_t)r;
 		}
+		int end_pos; // bit position behind entry e
+		if (!p.pcm) {
+			const int incl = block_scan_incl<false>(bits, s_tmp);
+			const int csum = s_carry_sum;
+			if (mb || trailer)
+				off[e] = (uint32_t)(csum + incl - bits);
+			end_pos = csum + incl;
+		} else {
+			// I_PCM macroblocks: the samples start at the next byte boundary behind the header, so an entry is
+			// no longer a length but a map of positions, pos -> pos + a, or pos -> align8(pos + a) + b behind
+			// which everything is byte aligned again. Maps of that form compose to maps of that form (PosMap), and
+			// composition is associative: an inclusive scan gives every entry the map of all entries up to it.
+			PosMap f{ bits, pcm_e ? 3072 : 0, pcm_e ? 1 : 0 };
+			const PosMap incl = block_scan_posmap(f, s_pm);
+			const int start = s_carry_sum;
+			// (exclusive value = the map of the entries before e: from the lane to the left, the wave before)
+			PosMap ex{ __shfl_up(incl.a, 1, 64), __shfl_up(incl.b, 1, 64), __shfl_up(incl.pcm, 1, 64) };
+			__syncthreads();
+			if ((threadIdx.x & 63) == 63)
+				s_pm[threadIdx.x >> 6] = incl;
+			__syncthreads();
+			if ((threadIdx.x & 63) == 0)
+				ex = threadIdx.x == 0 ? PosMap{ 0, 0, 0 } : s_pm[(threadIdx.x >> 6) - 1];
+			if (mb || trailer)
+				off[e] = (uint32_t)posmap_apply(ex, start);
+			end_pos = posmap_apply(incl, start);
+		}
+		if (mb || trailer)
+			run[e] = (uint32_t)r;
 		if (trailer)
-			p.unit_bits[unit] = (uint32_t)(csum + incl);
+			p.unit_bits[unit] = (uint32_t)end_pos;
 		__syncthreads();
 		if (threadIdx.x == SCAN_THREADS - 1) {
 			s_carry_max = m;
-			s_carry_sum = csum + incl;
+			s_carry_sum = end_pos;
 		}
 		__syncthreads();
 	}
@@ -917,13 +1002,29 @@ __global__ __launch_bounds__(256) void k_pack(Params p)
 		or_bits(w, capw, pos, v, len);
 		pos += len;
 	}
-	const uint32_t nbits = p.mb_bits[mbaddr];
+	const uint32_t mbb = p.mb_bits[mbaddr], nbits = mbb & ~PCM_MB_BITS_FLAG;
 	const uint32_t *slot = p.slot + mbaddr * SLOT_WORDS;
 	const uint32_t full = nbits >> 5, rem = nbits & 31;
 	for (uint32_t k = 0; k < full && k < (uint32_t)SLOT_WORDS; k++)
 		or_bits(w, capw, pos + 32 * k, slot[k], 32);
 	if (rem && full < (uint32_t)SLOT_WORDS)
 		or_bits(w, capw, pos + 32 * full, slot[full] >> (32 - rem), (int)rem);
+	if (mbb & PCM_MB_BITS_FLAG) {
+		// I_PCM: pcm_alignment_zero_bits (the buffer is zero), then 256 luma, 64 Cb, 64 Cr samples from the source
+		uint32_t bp = (pos + nbits + 7) & ~7u;
+		const int my = r0 + e / p.mb_w, mx = e % p.mb_w;
+		const uint8_t *sy = p.src_y + (size_t)st * p.plane_y_stride + (size_t)(16 * my) * p.cw + 16 * mx;
+		const uint8_t *sc = p.src_uv + (size_t)st * p.plane_uv_stride + (size_t)(8 * my) * p.cw + 16 * mx;
+		for (int y = 0; y < 16; y++)
+			for (int k = 0; k < 4; k++, bp += 32)
+				or_bits(w, capw, bp, __builtin_bswap32(*(const uint32_t *)(sy + (size_t)y * p.cw + 4 * k)), 32);
+		for (int c = 0; c < 2; c++)
+			for (int y = 0; y < 8; y++) {
+				const uint8_t *r = sc + (size_t)y * p.cw + c;
+				for (int k = 0; k < 2; k++, bp += 32)
+					or_bits(w, capw, bp, (uint32_t)r[8 * k] << 24 | (uint32_t)r[8 * k + 2] << 16 | (uint32_t)r[8 * k + 4] << 8 | r[8 * k + 6], 32);
+			}
+	}
 }
 
 // ---------------- emulation prevention ----------------

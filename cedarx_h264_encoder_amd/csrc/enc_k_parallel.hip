@@ -13,6 +13,7 @@
 
 #include <time.h>
 #include "enc_device.h"
+#include "enc_cavlc_len.h"
 
 namespace cedar {
 
@@ -673,6 +674,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// (counts go to LDS from every lane of a block -- same value, same address, no branch -- and
 	// leave as three 8-byte stores at the end)
 	uint32_t nz_luma = 0; // bit = coding-order block index
+	int n_levels = 0;     // levels of the macroblock that are not zero (wave-uniform)
 	const uint8_t *predp = s_ref + (16 + bdy) * REF_STRIDE + 16 + bdx;
 	// fractional vector: the prediction is the rounded mean of two plane samples (kSubTab)
 	const bool frac = SUBPEL && ((qx | qy) & 3) != 0;
@@ -755,6 +757,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		const int rr = idct_lanes24(__mul24(level, dv_y) << qs.qshift, ci, cj);
 		s_recy[y * 16 + x] = (uint8_t)clip255(pv + rr);
 		const uint64_t bal = __ballot(level != 0);
+		n_levels += __popcll(bal); // (scalar: a count for the I_PCM gate below)
 		s_nnz[bx + 4 * by] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 #pragma unroll
 		for (int k = 0; k < 4; k++)
@@ -787,6 +790,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		s_coef[COEF_CAC + (4 * c + gq) * 16 + zz] = (int16_t)level; // (entry 0 of a block is unused: lane 0 writes its 0 there)
 		cdq[c] = __mul24(level, dv_c) << qs.qshift_c;
 		const uint64_t bal = __ballot(level != 0);
+		n_levels += __popcll(bal);
 		s_nnz[16 + 4 * c + gq] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 		nz_cac |= bal ? 1u : 0u;
 	}
@@ -804,6 +808,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	if (lane < 8)
 		s_coef[COEF_CDC + lane] = (int16_t)lqv;
 	const uint64_t dcmask = __ballot(lqv != 0) & 0xffull;
+	n_levels += __popcll(dcmask);
 	int lqs[8];
 #pragma unroll
 	for (int k = 0; k < 8; k++)
@@ -830,6 +835,40 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	if (MBQP && p.row_rule && mx == 0 && !(REFRESH && refresh) && cbp == 0)
 		cbp = 0x10;
 	WAVE_LDS_SYNC();
+	// I_PCM (Params::pcm; H.264 A.3.1 allows macroblock_layer() 3200 bits): the levels are final here, so the
+	// bits CAVLC will spend on them are known but for coeff_token's table (cavlc_block_len takes the longest)
+	// and the header (PCM_HEADER_BITS covers it). Fewer than 64 levels cannot get there -- 26 blocks x 16 bits of
+	// coeff_token + 9 of total_zeros, 28 + 3 at most per level: the rare path of a rare picture. If the count
+	// passes the limit the macroblock is its source samples: reconstruction, 16 coefficients counted in every
+	// block for the neighbours' nC (9.2.1), no level, no vector (intra).
+	bool is_pcm = false;
+	if (!REFRESH && !MBQP && p.pcm && n_levels >= 64) {
+		int bits = 0;
+		if (lane < 16) {
+			if (cbp & (1 << (lane >> 2)))
+				bits = cavlc_block_len(s_coef + COEF_LUMA + 16 * lane, 16, false);
+		} else if (lane < 18) {
+			if (cbp & 0x30)
+				bits = cavlc_block_len(s_coef + COEF_CDC + 4 * (lane - 16), 4, true);
+		} else if (lane < 26) {
+			if (cbp & 0x20)
+				bits = cavlc_block_len(s_coef + COEF_CAC + 16 * (lane - 18) + 1, 15, false);
+		}
+		is_pcm = wave_sum_i32(bits) + PCM_HEADER_BITS > MB_BITS_LIMIT;
+		if (is_pcm) {
+			if (lane < 16)
+				*(u32x4 *)(s_recy + lane * 16) = *(const u32x4 *)(s_cur + lane * 16);
+			else if (lane < 24)
+				*(u32x4 *)(s_recc + (lane - 16) * 16) = *(const u32x4 *)(s_curc + (lane - 16) * 16);
+			else if (lane < 48)
+				s_nnz[lane - 24] = 16;
+			if (lane < COEF_PER_MB * 2 / 16)
+				((u32x4 *)s_coef)[lane] = u32x4{ 0, 0, 0, 0 };
+			cbp = 0;
+			qx = qy = 0;
+			WAVE_LDS_SYNC();
+		}
+	}
 
 	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
 	if (lane < COEF_PER_MB * 2 / 16)
@@ -844,7 +883,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		*(u32x4 *)(p.i4modes + mbaddr * 16) = u32x4{ 0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u };
 	if (lane == 0) {
 		MbInfo m;
-		m.type = (REFRESH && refresh) ? MB_I16x16 : MB_P16x16;
+		m.type = (REFRESH && refresh) ? MB_I16x16 : is_pcm ? MB_IPCM : MB_P16x16;
 		m.i16_mode = (REFRESH && refresh) ? 2 : 0; // DC
 		m.chroma_mode = 0;                         // DC
 		m.cbp = (int8_t)cbp;
@@ -1131,6 +1170,8 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 	__shared__ uint8_t s_E[16][16];        // edge arrays per 4x4 block
 	__shared__ int s_dcv[16];              // DC predictor value per block
 	__shared__ uint32_t s_key[16][9];      // sad<<4 | mode per (block, mode)
+	__shared__ uint8_t s_best4[16];        // I_PCM estimate: the chosen Intra4x4 mode of every block
+	__shared__ __attribute__((aligned(16))) int16_t s_lv[24][16]; // ... and the open loop's levels, zig-zag
 
 	const int lane = threadIdx.x;
 	int mx, my, st;
@@ -1224,6 +1265,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 
 	// I16x16: each lane covers row lane>>2, columns 4*(lane&3)..+3
 	uint32_t best16 = 0xffffffffu;
+	int dc16 = 128, pl16_a = 0, pl16_b = 0, pl16_c = 0; // (kept for the I_PCM estimate below)
 	{
 		const int py = lane >> 2, pxb = 4 * (lane & 3);
 		int sadv = 0, sadh = 0, sadd = 0, sadp = 0;
@@ -1240,6 +1282,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 		}
 		const int a = 16 * ((int)s_t[16 * TS] + (int)s_t[16]);
 		const int b = (5 * H + 32) >> 6, cc = (5 * V + 32) >> 6;
+		dc16 = dcv; pl16_a = a; pl16_b = b; pl16_c = cc;
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int px = pxb + k;
@@ -1309,8 +1352,70 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 			bestc = ((uint32_t)sad[3] << 2) | 3u;
 	}
 
+	// I_PCM (Params::pcm), decided open loop like everything here: the residual of the CHOSEN predictions from
+	// source samples, every 4x4 block -- 16 luma, 4 + 4 chroma -- through the plain transform and the intra
+	// quantiser (no DC Hadamards), the zig-zag levels through CAVLC's length (cavlc_block_len). The closed loop's
+	// levels differ a little: PCM_LIMIT_OPEN leaves a tenth of room below the 3200 bits of H.264 A.3.1.
+	bool is_pcm = false;
+	if (p.pcm) {
+		const bool is4 = sum4 + 32 * p.lambda < (int)(best16 >> 2);
+		const int m16 = (int)(best16 & 3u), mc = (int)(bestc & 3u);
+		if (lane < 16)
+			s_best4[lane] = (uint8_t)best4;
+		__syncthreads();
+		const int gq = lane >> 4, l = lane & 15, pi = l >> 2, pj = l & 3;
+		const LaneK ci = lane_consts(pi), cj = lane_consts(pj);
+		const int kv = pi == 1 ? 2 : pi == 2 ? 1 : pi, kh = pj == 1 ? 2 : pj == 2 ? 1 : pj;
+		const int rpos = 4 * kv + kh, pclass = (kv & 1) == (kh & 1) ? (kv & 1) : 2, zz = zigzag_of(rpos);
+		const int mf_y = pclass == 0 ? p.mf[0] : pclass == 1 ? p.mf[1] : p.mf[2];
+		const int mf_c = pclass == 0 ? p.mfc[0] : pclass == 1 ? p.mfc[1] : p.mfc[2];
+		const int f_y = (1 << p.qbits) / 3, f_c = (1 << p.qbits_c) / 3;
+#pragma unroll
+		for (int pass = 0; pass < 4; pass++) {
+			const int idx = 4 * pass + gq, bx = blk_x(idx), by = blk_y(idx);
+			const int x = 4 * bx + pj, y = 4 * by + pi;
+			int pv;
+			if (is4)
+				pv = pred4_px(p.pred4_tab[(int)s_best4[idx] * 16 + l], s_E[idx], s_dcv[idx]);
+			else
+				pv = m16 == 0 ? (int)s_t[1 + x] : m16 == 1 ? (int)s_t[(1 + y) * TS] : m16 == 2 ? dc16
+				   : clip255((pl16_a + pl16_b * (x - 7) + pl16_c * (y - 7) + 16) >> 5);
+			const int w = fdct_lanes24((int)s_t[(1 + y) * TS + 1 + x] - pv, ci, cj);
+			s_lv[idx][zz] = (int16_t)quant24(w, mf_y, f_y, p.qbits);
+		}
+#pragma unroll
+		for (int c = 0; c < 2; c++) {
+			const uint8_t *T = s_c[c];
+			const int bx = gq & 1, by = gq >> 1, x = 4 * bx + pj, y = 4 * by + pi;
+			int stp = 0, slf = 0;
+			for (int k = 0; k < 4; k++) {
+				stp += T[1 + 4 * bx + k];
+				slf += T[(1 + 4 * by + k) * 12];
+			}
+			bool use_t = top_mb, use_l = left_mb;
+			if (bx == 1 && by == 0 && top_mb)
+				use_l = false;
+			if (bx == 0 && by == 1 && left_mb)
+				use_t = false;
+			const int dcv = (use_t && use_l) ? (stp + slf + 4) >> 3 : use_t ? (stp + 2) >> 2 : use_l ? (slf + 2) >> 2 : 128;
+			int H = 0, V = 0;
+			for (int k = 0; k < 4; k++) {
+				H += (k + 1) * ((int)T[1 + 4 + k] - (int)T[1 + 2 - k]);
+				V += (k + 1) * ((int)T[(1 + 4 + k) * 12] - (int)T[(1 + 2 - k) * 12]);
+			}
+			const int a = 16 * ((int)T[8 * 12] + (int)T[8]);
+			const int b = (34 * H + 32) >> 6, cc = (34 * V + 32) >> 6;
+			const int pv = mc == 0 ? dcv : mc == 1 ? (int)T[(1 + y) * 12] : mc == 2 ? (int)T[1 + x]
+				     : clip255((a + b * (x - 3) + cc * (y - 3) + 16) >> 5);
+			const int w = fdct_lanes24((int)T[(1 + y) * 12 + 1 + x] - pv, ci, cj);
+			s_lv[16 + 4 * c + gq][zz] = (int16_t)quant24(w, mf_c, f_c, p.qbits_c);
+		}
+		__syncthreads();
+		const int bits = lane < 24 ? cavlc_block_len(s_lv[lane], 16, false) : 0;
+		is_pcm = wave_sum_i32(bits) + PCM_HEADER_BITS > PCM_LIMIT_OPEN;
+	}
 	if (lane < 16)
-		p.i4modes[mbaddr * 16 + lane] = (int8_t)best4;
+		p.i4modes[mbaddr * 16 + lane] = (int8_t)(is_pcm ? 2 : best4);
 	if (lane == 0) {
 		MbInfo m;
 		const int qp_base = p.roi_off ? roi_qp(p, st, mx, my) : p.qp;
@@ -1319,6 +1424,11 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 			p.qp_t[mbaddr] = (uint8_t)(p.mad_on ? mad_class_qp(p, qp_base, m.type == MB_I4x4 ? sum4 : (int)(best16 >> 2)) : qp_base);
 		m.i16_mode = (int8_t)(best16 & 3u);
 		m.chroma_mode = (int8_t)(bestc & 3u);
+		if (is_pcm) {
+			m.type = MB_IPCM;
+			m.i16_mode = 0;
+			m.chroma_mode = 0;
+		}
 		m.cbp = 0;
 		m.mvx = 0;
 		m.mvy = 0;

@@ -275,7 +275,11 @@ extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 template <int MODE, int PL, int PAIRS>
 DEVI void deblock2_body(const Params &p, const int wg)
 {
-	constexpr bool IDR = MODE == 1, MIXED = MODE >= 2, QPM = MODE == 3;
+	// (4, 5: modes 0 and 1 for the pictures that may hold I_PCM macroblocks, Params::pcm -- kernels of their own,
+	// so that the two extra words per macroblock the mover then loads cost the common pictures no register)
+	constexpr bool PCM = MODE >= 4;
+	constexpr int BASE = PCM ? MODE - 4 : MODE;
+	constexpr bool IDR = BASE == 1, MIXED = BASE == 2 || BASE == 3, QPM = BASE == 3;
 	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
 
 	Db2Shared<PL, PAIRS> &S = *reinterpret_cast<Db2Shared<PL, PAIRS> *>(dyn_lds);
@@ -667,7 +671,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		MoverRegs RA{}, RB{};
 		uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
 		int mvl = 0;
-		bool intra_left = false;
+		bool intra_left = false, pcm_left = false;
 		int eff_left = 0, teff_left = 0; // MODE 3: QP_Y the decoder holds for the macroblock staged last, and for the one above that
 		int pending_x = -1;
 
@@ -708,6 +712,10 @@ DEVI void deblock2_body(const Params &p, const int wg)
 					R.qc = p.qp_t[a];
 					R.qt = p.qp_t[at];
 				}
+			}
+			if (PCM) { // pictures that may hold I_PCM macroblocks: the types of this macroblock and the one above
+				R.ty = ((const uint32_t *)&p.mbi[a])[0];
+				R.tyt = ((const uint32_t *)&p.mbi[(top_edge && row_ok) ? a - p.mb_w : a])[0];
 			}
 			if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
 				R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
@@ -812,6 +820,23 @@ DEVI void deblock2_body(const Params &p, const int wg)
 						}
 						intra_left = ic;
 					}
+				}
+				if (PCM) {
+					// I_PCM (Params::pcm: only pictures at whose QP no edge of such a macroblock is filtered at all --
+					// the filter takes its QP_Y as 0, picture_takes_pcm in enc_session.cpp): its own edges, inner ones
+					// included, and its neighbours' edges towards it are left alone
+					const bool pc = (int)(int8_t)(R.ty & 0xffu) == MB_IPCM, pt = top_edge && (int)(int8_t)(R.tyt & 0xffu) == MB_IPCM;
+					if (pc)
+						wv = wh = wc = 0;
+					if (pcm_left) {
+						wv &= ~0xffu;
+						wc &= ~0xffu;
+					}
+					if (pt) {
+						wh &= ~0xffu;
+						wc &= ~0xff0000u;
+					}
+					pcm_left = pc;
 				}
 				nz_left = nz_cur;
 				mvl = mvc;
@@ -1351,6 +1376,19 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					if (is16)
 						cbp = ((uint32_t)(bal >> (16 * g)) & 0xffffu) ? 15 : 0;
 				}
+				// ---- I_PCM (k_intra_decide's open-loop count said the macroblock could pass 3200 bits): its
+				// reconstruction is its source, what its neighbours predict from; no level, and every block counts
+				// 16 coefficients for the neighbours' nC (9.2.1). lane = sample row / block ----
+				const bool ispcm = act && mb_type == MB_IPCM;
+				if (__any(ispcm)) {
+					if (ispcm) {
+						*(u32x4 *)(L.t + (1 + l) * IT_STRIDE + 8) = *(const u32x4 *)(SY + 16 * l);
+						*(u32x4 *)(cf + COEF_LUMA + 16 * l) = u32x4{ 0, 0, 0, 0 };
+						*(u32x4 *)(cf + COEF_LUMA + 16 * l + 8) = u32x4{ 0, 0, 0, 0 };
+						cf[COEF_DC16 + l] = 0;
+						nnz_mb[l] = 16;
+					}
+				}
 				WAVE_SYNC();
 				if (act) { // hand the macroblock to the mover and its last row to the group below
 					*(u32x4 *)(L.outy[slot] + l * 16) = *(const u32x4 *)(L.t + (1 + l) * IT_STRIDE + 8);
@@ -1379,6 +1417,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 				lds_wait_ge(&s_staged[trip], base + t + 1, xw);
 				load_q(slot);
 				const int chroma_mode = (int)((L.info[slot][0] >> 16) & 0xff);
+				const bool ispcm = (int)(int8_t)(L.info[slot][0] & 0xff) == MB_IPCM; // (see the luma wave)
 				const uint8_t *SC = L.srcc[slot];
 				if (in_top && t < p.mb_w) // only the macroblock above is needed here, but the luma wave's bound is as good
 					lds_wait_ge(&s_done_c[trip_up], base_up + (t + 7 < nsteps ? t + 7 : nsteps), xw);
@@ -1472,7 +1511,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const int w = fdct_lanes(res, ci, cj);
 					if (act && l == 0)
 						L.cdc[4 * c + blk] = w; // lane (0,0) holds the DC coefficient
-					const int level = l == 0 ? 0 : quant1(w, my_mfc, f_intra_c, q_qbits_c);
+					const int level = (l == 0 || ispcm) ? 0 : quant1(w, my_mfc, f_intra_c, q_qbits_c);
 					if (act)
 						cf[COEF_CAC + (4 * c + blk) * 16 + zz] = (int16_t)level;
 					cdq[it] = (level * my_dvc) << q_qshift_c;
@@ -1480,7 +1519,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const uint64_t bal = __ballot(act && level != 0);
 					const int nn = __popc((uint32_t)(bal >> (16 * g)) & 0xffffu);
 					if (act && l == 0)
-						p.nnz[mbaddr * NNZ_PER_MB + 16 + 4 * c + blk] = (uint8_t)nn;
+						p.nnz[mbaddr * NNZ_PER_MB + 16 + 4 * c + blk] = (uint8_t)(ispcm ? 16 : nn);
 					ac_any |= (uint32_t)nn;
 				}
 				WAVE_SYNC();
@@ -1490,7 +1529,7 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const int *dcs = L.cdc + 4 * c;
 					const int s1 = (blk & 1) ? -1 : 1, s2 = (blk & 2) ? -1 : 1;
 					const int hd = dcs[0] + s1 * dcs[1] + s2 * dcs[2] + s1 * s2 * dcs[3];
-					const int lq = quant1(hd, q_mfc0, 2 * f_intra_c, q_qbits_c + 1);
+					const int lq = ispcm ? 0 : quant1(hd, q_mfc0, 2 * f_intra_c, q_qbits_c + 1);
 					L.cdl[l] = lq;
 					cf[COEF_CDC + l] = (int16_t)lq;
 					cdcnz = lq != 0;
@@ -1505,8 +1544,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					const int fd = ls[0] + s1 * ls[1] + s2 * ls[2] + s1 * s2 * ls[3];
 					const int dcr = ((fd * q_dvc0 * 16) << q_qshift_c) >> 5;
 					const int r = idct_lanes(l == 0 ? dcr : cdq[it], ci, cj);
-					if (act)
-						L.c[(1 + y) * IC_STRIDE + 8 + 2 * x + c] = (uint8_t)clip255(pvs[it] + r);
+					if (act) // (an I_PCM macroblock: its source sample)
+						L.c[(1 + y) * IC_STRIDE + 8 + 2 * x + c] = ispcm ? SC[y * 16 + 2 * x + c] : (uint8_t)clip255(pvs[it] + r);
 				}
 				const uint64_t dcm = __ballot(cdcnz != 0);
 				const uint32_t ac = ac_any, dcb = (uint32_t)(dcm >> (16 * g)) & 0xffffu;
@@ -1746,13 +1785,19 @@ static int launch_deblock(const Params &p, hipStream_t s, int planes)
 		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
 		    hipFuncSetAttribute((const void *)k_deblock2_planes<1, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
 		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<3, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<3, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<4, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock2_planes<5, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
 			return -1;
 		attr_set = true;
 	}
 	dim3 grid(planes == 4 ? 2 * nwg : nwg);
 	if (p.roi_off) // regions of interest: thresholds per macroblock; an IDR picture is "every macroblock intra" there
 		hipLaunchKernelGGL((k_deblock2_planes<3, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
+	else if (p.pcm && p.is_idr) // I_PCM macroblocks may be among them: their edges are left alone
+		hipLaunchKernelGGL((k_deblock2_planes<5, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
+	else if (p.pcm)
+		hipLaunchKernelGGL((k_deblock2_planes<4, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
 	else if (p.is_idr)
 		hipLaunchKernelGGL((k_deblock2_planes<1, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);
 	else if (p.intra_refresh > 0) // intra macroblocks among the inter ones: both sets of boundary strengths

@@ -303,6 +303,7 @@ struct cedar_enc {
 	// a picture's last stripe is gated on the END of the previous picture's deblocking, and on an in-order
 	// stream the next picture's first stripe -- which only needs that deblocking a quarter through -- would
 	// sit behind it. (submit_frame; emitted at the latest when the frame is collected.)
+	bool pcm_session = false;    // the session takes I_PCM macroblocks (picture_takes_pcm says in which pictures)
 	Flusher *flusher = nullptr;  // only sessions that hold tails back (defer_from < inter_bands)
 	int defer_default = 0;       // stripes held back unless CEDAR_DEFER says otherwise (set with the stripe count)
 	int defer_from = 0;          // first deferred stripe; inter_bands = nothing is deferred
@@ -683,6 +684,15 @@ void set_qp_params(Params &P, int qp, int chroma_qp_offset)
 	P.beta_c = kBeta[P.qpc];
 }
 
+// I_PCM (cedar_enc_config_ext.pcm): the pictures that take it are those at whose QP the edges of an I_PCM
+// macroblock are not filtered at all. The deblocking filter takes its QP_Y as 0 (8.7.2.2) and filters an edge at
+// the mean of the two macroblocks' QP_Y resp. QP_C; alpha is 0 up to index 15.
+bool picture_takes_pcm(int qp, int chroma_qp_offset)
+{
+	auto qpc = [&](int q) { const int qi = q + chroma_qp_offset; return (int)kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi]; };
+	return kAlpha[(qp + 1) >> 1] == 0 && kAlpha[(qpc(qp) + qpc(0) + 1) >> 1] == 0;
+}
+
 // ---- frame-level rate control (cedar_enc_config_ext.bitrate; the tests hold a scalar
 // twin of this law against it). Integer only: frame n looks at the sizes of frames <= n - 1 - RC_LAG (collected whatever
 // the caller's pipelining: a session keeps at most RC_LAG frames in flight), over the last keyint of
@@ -739,6 +749,7 @@ void fill_static_params(cedar_enc *e)
 	P.subpel = e->ext.subpel;
 	P.intra_refresh = e->ext.intra_refresh;
 	set_qp_params(P, c.qp, e->chroma_qp_offset);
+	P.pcm = e->pcm_session && picture_takes_pcm(P.qp, e->chroma_qp_offset) ? 1 : 0;
 }
 
 double now_ms()
@@ -920,6 +931,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			return fail(e, -EINVAL, "mad_th: four ascending thresholds 0..255");
 	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
+	if (ext.pcm < -1 || ext.pcm > 0)
+		return fail(e, -EINVAL, "pcm must be 0 (I_PCM where a macroblock could pass 3200 bits) or -1 (never)");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
 		return fail(e, -EINVAL, "requantising oversize pictures wants one stream, whole pictures, no GOP lanes (one QP per launch)");
 	if (ext.bitrate < 0 || (ext.bitrate > 0 && (G != 1 || ext.slice_num != ext.slice_count)))
@@ -945,6 +958,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	// QP up per macroblock (but no QP differs inside a picture: no row rule)
 	e->rc_multi = ext.bitrate > 0 && ext.n_streams > 1;
 	e->mb_qp = e->mb_qp || e->rc_multi;
+	e->pcm_session = ext.pcm >= 0 && !e->mb_qp && ext.intra_refresh == 0;
 	if (e->rc_multi) {
 		e->rc_bits_s.assign((size_t)ext.n_streams * 64, 0);
 		e->rc_qp_s.assign((size_t)ext.n_streams * 64, 0);
@@ -1833,6 +1847,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 						   : e->cfg.qp) + f.qp_bump,
 			      e->chroma_qp_offset);
 	f.qp = P.qp;
+	P.pcm = e->pcm_session && picture_takes_pcm(P.qp, e->chroma_qp_offset) ? 1 : 0;
 	if (e->rc_multi) { // the law per stream; the launch's own QP (Params::qp) is not used by the per-macroblock forms
 		for (int s = 0; s < S; s++)
 			f.h_qp_s[s] = (uint8_t)rc_pick_qp(e->cfg.qp, e->rc_target, &e->rc_bits_s[(size_t)s * 64], &e->rc_qp_s[(size_t)s * 64],

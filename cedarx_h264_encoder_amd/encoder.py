@@ -43,7 +43,7 @@ class _ConfigExt(ctypes.Structure):
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
         "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "roi_count")] + [
-        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5)]
+        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5), ("pcm", ctypes.c_int)]
 
 
 class _Stats(ctypes.Structure):
@@ -175,6 +175,7 @@ class EncoderConfig:
     roi: tuple = ()             # up to 4 regions of interest: (x, y, width, height in macroblocks, QP offset)
     mad_th: tuple = (0, 0, 0, 0)       # MAD classes: ascending thresholds on luma SAD / 256 against the chosen prediction
     mad_dqp: tuple = (0, 0, 0, 0, 0)   # ... and the QP offset of each of the five classes (all zero: off)
+    pcm: int = 0                # 0: macroblocks that could pass 3200 bits are coded I_PCM (where the session takes it); -1: never
 
 
 class CedarEncoder:
@@ -203,7 +204,7 @@ class CedarEncoder:
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh"):
+                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "pcm"):
             setattr(x, n, getattr(cfg, n))
         if len(cfg.roi) > 4:
             raise EncoderError(22, "at most 4 regions of interest")

@@ -157,6 +157,15 @@ struct cedar_enc_config_ext {
 				picture's QP and its region's: finer where prediction works (what the eye follows),
 				coarser where it fails anyway, or the other way round. Decisions (lambda) are taken
 				at the QP without it. All zero (default): off. The row rule of roi applies          */
+	int pcm;             /* 0 (default): a macroblock whose macroblock_layer() could pass the 3200 bits H.264
+				A.3.1 allows is coded I_PCM -- its source samples, raw, 3088 bits -- so that no
+				emitted macroblock exceeds the limit (the VE's silicon behind cedar.c:1176 has to
+				honour it at every QP cedar.c:771-775 accepts). The sessions and pictures that
+				take it: one QP per picture (no roi, no MAD classes, one stream's rate control),
+				no intra_refresh, and a picture QP at which the edges of an I_PCM macroblock --
+				QP_Y 0 for the deblocking filter -- are not filtered at all: up to 22 with the
+				reference's chroma offset (noise passes 3200 bits up to QP 16). Elsewhere, and with
+				-1 (never), strict_mb_bits says what happens                                       */
 };
 
 typedef struct cedar_enc cedar_enc;

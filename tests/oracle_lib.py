@@ -94,7 +94,7 @@ def lib():
 
 
 # I_PCM in the twin's sessions unless a test says otherwise (h264o_config.pcm: 0 on, -1 off)
-PCM_DEFAULT = -1   # (off until the HIP path takes I_PCM too: the parity tests compare default sessions)
+PCM_DEFAULT = 0
 
 
 def default_config(width, height, **kw):

@@ -61,16 +61,72 @@ def _compare_state(oe, ge):
     assert np.array_equal(ruv, ge.debug_read("recon_uv"))
 
 
-@pytest.mark.parametrize("w,h,qp,keyint,frames,pattern,slices", CASES)
+@pytest.mark.parametrize("w,h,qp,keyint,frames,pattern,slices", CASES + [(64, 48, 5, 3, 4, "C", -1)])
 def test_bitstream_and_state_equal_oracle(ce, w, h, qp, keyint, frames, pattern, slices):
-    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices))
-    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices) as ge:
+    kw = {}
+    if slices < 0:   # I_PCM switched off: noise at a very low QP keeps its escape-coded levels (and passes 3200 bits)
+        slices, kw = 1, dict(pcm=-1)
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **kw))
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, **kw) as ge:
         for f in range(frames):
             y, uv = ol.gen_frame(pattern, w, h, f)
             ref = oe.encode(y, uv)
             got = ge.encode_frame(y, uv)
             _compare_state(oe, ge)
             assert got == ref, "frame %d: bytestream differs" % f
+
+
+@pytest.mark.parametrize("w,h,qp,keyint,patterns,frames,kw", [
+    (96, 64, 1, 3, "C", 4, {}), (96, 64, 16, 3, "C", 4, {}), (96, 64, 18, 3, "C", 5, {}), (96, 64, 20, 25, "C", 4, {}),
+    (96, 80, 12, 4, "CB", 6, dict(slice_count=2)), (64, 48, 8, 25, "C", 3, dict(subpel=2)), (16, 48, 6, 2, "C", 3, {}),
+    (320, 240, 17, 5, "C", 7, dict(slice_count=3)), (640, 368, 18, 25, "CCB", 4, {}),
+    (1920, 1080, 1, 25, "C", 2, {}), (96, 64, 10, 3, "C", 6, dict(n_streams=3)), (96, 64, 14, 4, "C", 9, dict(gop_parallel=2)),
+    (96, 64, 5, 3, "C", 3, dict(pcm=-1)), (96, 64, 5, 3, "C", 3, dict(intra_refresh=3)), (96, 64, 22, 3, "C", 3, {})])
+def test_macroblocks_that_could_pass_3200_bits_are_coded_i_pcm(ce, w, h, qp, keyint, patterns, frames, kw):
+    """cedar_enc_config_ext.pcm (default on): a macroblock whose CAVLC bits could pass the 3200 of H.264 A.3.1 is coded
+    I_PCM. k_intra_decide counts on the open loop's levels (a tenth of room), k_inter on the final ones; the intra
+    wavefront copies the source, both CAVLC kernels write mb_type only, k_scan places the samples at the next byte
+    boundary, k_pack copies them from the source planes, the deblock kernel leaves the macroblock's edges alone.
+    Records, counts, levels, reconstruction and bytes equal the scalar twin's at 1080p, in slices, lock-step
+    streams, GOP lanes and with frames in flight; the independent decoder rebuilds the pictures and finds no
+    macroblock above the limit."""
+    from tests.indep import h264_refdec as rd
+    S, G = kw.get("n_streams", 1), kw.get("gop_parallel", 0)
+    okw = {k: v for k, v in kw.items() if k not in ("n_streams", "gop_parallel")}
+    src = [[ol.gen_frame(patterns[f % len(patterns)], w, h, f, s << 8) for s in range(S)] for f in range(frames)]
+    oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, **okw)) for _ in range(S)]
+    want = [[oes[s].encode(*src[f][s]) for f in range(frames)] for s in range(S)]
+    if G:
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, **kw) as ge:
+            got = _encode_gop_parallel(ge, [[src[f][0]] for f in range(frames)], streams=1)
+        assert [g[0] for g in got] == want[0]
+        return
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, **okw))
+    dec = rd.Decoder() if w <= 320 else None
+    n_pcm = 0
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, **kw) as ge:
+        for f in range(frames):
+            for s in range(S):
+                ge.set_input(src[f][s][0], src[f][s][1], stream=s)
+            ge.encode()
+            oe.encode(*src[f][0])
+            _compare_state(oe, ge)
+            n_pcm += int((oe.mb_array()["type"] == ol.MB_IPCM).sum())
+            for s in range(S):
+                assert ge.output(s) == want[s][f], "frame %d stream %d: bytestream differs" % (f, s)
+            if dec:
+                pic, = dec.decode(ge.output(0))
+                assert pic.luma_bytes() == ge.debug_read("recon_y").tobytes()
+                assert pic.nv12_chroma_bytes() == ge.debug_read("recon_uv").tobytes()
+        takes = "pcm" not in kw and "intra_refresh" not in kw and qp <= 20
+        assert (n_pcm > 0) == takes, n_pcm
+        if takes:
+            assert ge.stats()["oversize_frames"] == 0
+            if dec:
+                assert dec.max_mb_bits <= 3200 and dec.cover["mb_I_PCM"] == n_pcm and not dec.level_violations()
+    if S == 1:   # frames in flight
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, **kw) as ge:
+            assert _encode_pipelined(ge, [src[f][0] for f in range(frames)]) == want[0]
 
 
 def test_randomised_geometries_qps_slices(ce):
@@ -703,9 +759,6 @@ def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
         sys.path.insert(0, os.path.join(root, "tools"))
         from gen_indep_golden import case_options
         opts = case_options(c["case"])
-        if "pcm" in opts:   # TODO(I_PCM on the HIP path): CedarEncoder takes no pcm yet
-            if opts.pop("pcm") == 0:
-                continue
         sh, dec = hashlib.sha1(), rd.Decoder()
         with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, **opts) as ge:
             for f in range(frames):
@@ -819,23 +872,23 @@ def test_rate_control_over_several_streams(ce, w, h, S, target, extra):
 
 def test_macroblocks_above_3200_bits_are_counted_or_refused(ce):
     """H.264 A.3.1: a macroblock_layer() may take 3200 bits. Pure noise at a low QP passes that (measured
-    with the independent decoder: up to QP 16) and there is no I_PCM fallback yet. The path detects
+    with the independent decoder: up to QP 16) where I_PCM is switched off (pcm = -1) or not taken. The path detects
     it: by default the picture is emitted and counted, with strict_mb_bits it fails with EOVERFLOW and
     is dropped like any failed frame (GOP state untouched) -- the oracle does the same."""
     from tests.indep import h264_refdec as rd
     w, h = 64, 48
     frames = [ol.gen_frame("C", w, h, f) for f in range(3)] + [ol.gen_frame("A", w, h, 3)]
-    oe = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=1))
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=1, pcm=-1))
     dec = rd.Decoder()
-    with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=1) as enc:
+    with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=1, pcm=-1) as enc:
         for y, uv in frames:
             au = enc.encode_frame(y, uv)
             assert au == oe.encode(y, uv)
             dec.decode(au)
         assert dec.max_mb_bits > 3200 and oe.max_mb_bits() <= 3200   # the noise frames pass it, the flat last one does not
         assert enc.stats()["oversize_frames"] == 3
-    os_ = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=1, strict_mb_bits=1))
-    with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=1, strict_mb_bits=1) as enc:
+    os_ = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=1, strict_mb_bits=1, pcm=-1))
+    with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=1, strict_mb_bits=1, pcm=-1) as enc:
         for y, uv in frames[:3]:
             with pytest.raises(ce.EncoderError) as ex:
                 enc.encode_frame(y, uv)
@@ -850,7 +903,7 @@ def test_macroblocks_above_3200_bits_are_counted_or_refused(ce):
         assert d2.max_mb_bits <= 3200 and d2.pictures == 1
     # at the QPs of the BASELINE configs not even noise comes near the limit
     dq = rd.Decoder()
-    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=1, strict_mb_bits=1) as enc:
+    with ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=1, strict_mb_bits=1, pcm=-1) as enc:
         for y, uv in frames[:3]:
             dq.decode(enc.encode_frame(y, uv))
     assert 0 < dq.max_mb_bits <= 3200
@@ -865,14 +918,14 @@ def test_oversize_pictures_are_requantised_until_every_macroblock_fits(ce, qp, k
     from tests.indep import h264_refdec as rd
     w, h, n = 64, 48, 7
     frames = [ol.gen_frame("CB"[f % 5 == 4], w, h, f) for f in range(n)]
-    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, strict_mb_bits=2))
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, strict_mb_bits=2, pcm=-1))
     want, qps = [], []
     for y, uv in frames:
         want.append(oe.encode(y, uv))
         qps.append(oe.frame_qp())
     assert max(qps) > qp
     dec = rd.Decoder()
-    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2, pcm=-1) as enc:
         for f, (y, uv) in enumerate(frames):
             au = enc.encode_frame(y, uv)
             assert au == want[f], f
@@ -880,14 +933,14 @@ def test_oversize_pictures_are_requantised_until_every_macroblock_fits(ce, qp, k
             pic, = dec.decode(au)
             assert pic.luma_bytes() == enc.debug_read("recon_y").tobytes()
         assert enc.stats()["requantised_frames"] > 0 and dec.max_mb_bits <= 3200
-    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2, pcm=-1) as enc:
         assert _encode_pipelined(enc, frames) == want
     # the ring really full: more frames than the session takes in flight, all of its depth in flight
     n2 = ce.load_library().cedar_enc_pipeline_depth() + 9
     frames2 = [ol.gen_frame("CB"[f % 5 == 4], w, h, f) for f in range(n2)]
-    oe2 = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, strict_mb_bits=2))
+    oe2 = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, strict_mb_bits=2, pcm=-1))
     want2 = [oe2.encode(y, uv) for y, uv in frames2]
-    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2) as enc:
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, strict_mb_bits=2, pcm=-1) as enc:
         assert _encode_pipelined(enc, frames2) == want2
         assert enc.stats()["requantised_frames"] > 0
 
