@@ -38,6 +38,8 @@ Extra objects on the JSON line:
   gop_parallel the same ONE stream with G closed GOPs encoded side by side
                (cedar_enc_config_ext.gop_parallel; same bytes, G*keyint frames of latency)
   batched      S lock-step streams per GPU
+  configs      BASELINE configs[1] (854x480 QP 30) and configs[3] in its one-GPU forms (3840x2160 QP 24, one slice and
+               4 slices), 25 timed steps each (--other-configs 0 skips them)
 """
 import argparse
 import hashlib
@@ -74,6 +76,13 @@ PIPELINE_BYTES_PER_MB = {"I": 768.0, "P": 1152.0}
 # v_qsad_pk_u16_u8 16 per 14.8), so the chip's ceiling is 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz.
 SAD_OPS_PER_MB = 33 * 33 * 256
 SAD_PEAK_OPS = 256 * 4 * 64 * 2.4e9 * (4 / 4.17)
+# Round 3: the search is still exhaustive in its result but no longer in its work (successive elimination on 8x8 box
+# sums), so byte-SADs per second say nothing any more. What bounds the kernel is plain VALU issue: one
+# wave instruction per SIMD every 4 cycles, and k_inter<0,0,0> issues ~1210 of them per macroblock on its common path
+# (one pass of exact SADs over the survivors; tools/dev/isa_buckets.py on the gfx950 listing, a quarter-rate
+# v_qsad_pk_u16_u8 counted as 4).
+INTER_VALU_SLOTS_PER_MB = 1210
+VALU_PEAK_SLOTS = 256 * 4 * 2.4e9 / 4
 
 
 def parse():
@@ -92,6 +101,9 @@ def parse():
                     help="also report throughput with these many lock-step streams per GPU (0 = skip)")
     ap.add_argument("--gop-parallel", type=str, default="8",
                     help="also report ONE stream with this many closed GOPs side by side (0 = skip)")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="1: also time BASELINE configs[1] (854x480 QP 30) and configs[3] in its one-GPU forms "
+                         "(3840x2160 QP 24 as 1 slice and as 4 slices) for 25 steps each (N=1 only); 0 = skip")
     ap.add_argument("--slices-across-gpus", action="store_true",
                     help="configs[3]: rank k encodes slice k of one picture (default 3840x2160), no collective")
     ap.add_argument("--gops-across-gpus", action="store_true",
@@ -118,14 +130,17 @@ def run_rank(args, rank, world, local_rank):
     K = args.keyint
     mbs_per_frame = ((W + 15) // 16) * ((H + 15) // 16)
 
-    def make_inputs(S):
+    # what the sessions of this run encode: the headline's geometry, or (--other-configs) another BASELINE config's
+    cur = {"W": W, "H": H, "qp": args.qp, "slices": 0}
+
+    def make_inputs(S, nframes=None):
         ins = []
         for s in range(S):
             # global stream id: seed offset s<<8; one picture / one stream sharded: the same on every rank
             gs = (0 if (args.slices_across_gpus or args.gops_across_gpus) else rank * S) + s
             fr = []
-            for f in range(args.frames):
-                y, uv = ce.gen_pattern("B", W, H, f, gs << 8)
+            for f in range(nframes or args.frames):
+                y, uv = ce.gen_pattern("B", cur["W"], cur["H"], f, gs << 8)
                 fr.append((torch.from_numpy(y).to(dev), torch.from_numpy(uv).to(dev)))
             ins.append(fr)
         torch.cuda.synchronize()
@@ -153,7 +168,9 @@ def run_rank(args, rank, world, local_rank):
     def session(S, **kw):
         if args.slices_across_gpus:   # this rank's slice of the one picture
             kw.update(slice_count=world, slice_first=rank, slice_num=1)
-        return ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=K, n_streams=S, device=local_rank, **kw)
+        elif cur["slices"]:
+            kw.update(slice_count=cur["slices"])
+        return ce.CedarEncoder(width=cur["W"], height=cur["H"], qp=cur["qp"], keyframe_interval=K, n_streams=S, device=local_rank, **kw)
 
     class Pump:
         """frames through submit / collect with the ring as full as the session allows"""
@@ -173,7 +190,7 @@ def run_rank(args, rank, world, local_rank):
                 if self.in_flight == self.depth:
                     self.take()
                 for s in range(self.S):
-                    y, uv = self.inputs[s % len(self.inputs)][i % args.frames]
+                    y, uv = self.inputs[s % len(self.inputs)][i % len(self.inputs[0])]
                     self.enc.set_device_input(s, y.data_ptr(), uv.data_ptr())
                 self.enc.submit()
                 self.in_flight += 1
@@ -322,6 +339,25 @@ def run_rank(args, rank, world, local_rank):
                         "pipeline_frac_of_hbm_peak": v * 1136.64 / 1e9 / HBM_PEAK_GBS})
     work_ms = measure_work(S, inputs) if profile else None
 
+    # BASELINE configs[1] and configs[3] (in its one-GPU forms) on the same line: 25 timed steps each, like `batched`
+    others = []
+    if args.other_configs and world == 1 and not args.slices_across_gpus and (W, H, S) == (1920, 1080, 1):
+        for name, ow, oh, oqp, osl in (("configs[1]: 854x480 nv12 I+P QP 30", 854, 480, 30, 0),
+                                      ("configs[3] on one GPU: 3840x2160 nv12 I+P QP 24, one slice", 3840, 2160, 24, 0),
+                                      ("configs[3] on one GPU: 3840x2160 nv12 I+P QP 24, 4 slices (34/34/34/33 rows)", 3840, 2160, 24, 4)):
+            cur.update(W=ow, H=oh, qp=oqp, slices=osl)
+            oin = make_inputs(1, K + 1)
+            osteps = 25
+            odt, onb, _, _ = measure(1, osteps, K, oin, False)
+            ombs = ((ow + 15) // 16) * ((oh + 15) // 16)
+            ov = ombs * osteps / odt
+            others.append({"workload": name + ", keyint %d, pattern-B, 1 stream" % K, "steps": osteps, "value": ov,
+                           "ms_per_step": odt / osteps * 1e3, "macroblocks_per_frame": ombs,
+                           "realtime_30fps_multiple": ov / (ombs * 30.0), "bitstream_bytes_per_step": onb / osteps,
+                           "pipeline_frac_of_hbm_peak": ov * 1136.64 / 1e9 / HBM_PEAK_GBS})
+            del oin
+        cur.update(W=W, H=H, qp=args.qp, slices=0)
+
     if rank != 0:
         return None
 
@@ -339,9 +375,12 @@ def run_rank(args, rank, world, local_rank):
         line = {"kernel": KERNEL_NAME[k], "work_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "hbm_GBs": round(ach, 2), "hbm_frac": ach / HBM_PEAK_GBS}
         if k == "inter":
-            ops = SAD_OPS_PER_MB * mb_per_launch / (ms * 1e-3)
-            line["true_bound"] = {"kind": "valu: byte-SAD issue rate", "achieved_Tops": round(ops / 1e12, 2),
-                                  "peak_Tops": round(SAD_PEAK_OPS / 1e12, 1), "frac": ops / SAD_PEAK_OPS}
+            slots = INTER_VALU_SLOTS_PER_MB * mb_per_launch / (ms * 1e-3)
+            line["true_bound"] = {"kind": "valu issue (wave instructions; the search prunes by exact successive elimination)",
+                                  "valu_slots_per_macroblock": INTER_VALU_SLOTS_PER_MB,
+                                  "achieved_Gslots": round(slots / 1e9, 1), "peak_Gslots": round(VALU_PEAK_SLOTS / 1e9, 1),
+                                  "frac": slots / VALU_PEAK_SLOTS,
+                                  "exhaustive_equivalent_Tsad": round(SAD_OPS_PER_MB * mb_per_launch / (ms * 1e-3) / 1e12, 1)}
         elif k in ("deblock", "intra_recon"):
             mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
             nsteps = mb_w + (mb_h - 1) * (1 if k == "deblock" else 2)
@@ -366,6 +405,9 @@ def run_rank(args, rank, world, local_rank):
     roofline = {
         "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["hbm_GBs"], "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": dom["hbm_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+        # NOT a counter of this run: the HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+        # (FETCH_SIZE, WRITE_SIZE in separate runs, as the guide prescribes) of the same command
+        "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of an earlier run, see profiles/)" if traffic is not None else None,
         "work_ms": dom["work_ms"], "avg_launch_ms": round(avg_ms, 4), "launches": launches,
         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
         "true_bound": dom["true_bound"],
@@ -467,6 +509,7 @@ def run_rank(args, rank, world, local_rank):
         "bitexact_vs_cpu": bitexact,
         "gop_parallel": gop_par,
         "batched": batched,
+        "configs": others,
     }
     return out
 
@@ -513,7 +556,7 @@ def run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, 
     barrier()
     dt = allmax(time.perf_counter() - t0)
     enc.close()
-    ok = None
+    ok = ok_oracle = None
     parts = [None] * world
     if world > 1:
         dist.all_gather_object(parts, mine)
@@ -534,6 +577,25 @@ def run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, 
         ok = shards == serial
         if not ok:
             raise SystemExit("GOP shards from %d ranks do not concatenate to the serial stream" % world)
+        # ... and against the CPU oracle's serial bytes (the check above compares the HIP path with itself): the same
+        # sharding -- GOP g on shard g mod N, cedar_enc_set_frame_index -- at 320x240, where the scalar twin codes
+        # 2 N GOPs in seconds
+        from tests import oracle_lib as ol
+        sw, sh = 320, 240
+        sframes = [ol.gen_frame("B", sw, sh, f) for f in range(2 * world * K)]
+        oe = ol.OracleEncoder(ol.default_config(sw, sh, qp=args.qp, keyint=K))
+        oracle_serial = [oe.encode(y, uv) for y, uv in sframes]
+        got = [None] * len(sframes)
+        for r in range(world):
+            with ce.CedarEncoder(width=sw, height=sh, qp=args.qp, keyframe_interval=K, device=local_rank) as sh_enc:
+                for k in range(2):
+                    g = k * world + r
+                    sh_enc.set_frame_index(g * K)
+                    for t in range(K):
+                        got[g * K + t] = sh_enc.encode_frame(*sframes[g * K + t])
+        ok_oracle = got == oracle_serial
+        if not ok_oracle:
+            raise SystemExit("GOP shards do not concatenate to the ORACLE's serial stream")
     if rank != 0:
         return None
     frames = args.steps * world * K
@@ -547,6 +609,7 @@ def run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, 
                        "parallelism": "closed GOPs x%d of one stream, no collective" % world,
                        "frames_per_step": world * K, "macroblocks_per_frame": mbs_per_frame,
                        "gop_shards_concatenate_to_the_serial_stream": ok,
+                       "gop_shards_equal_the_cpu_oracles_serial_stream_320x240": ok_oracle,
                        "realtime_4k30_multiple": value / 972000.0},
             "roofline": None, "cpu_baseline": None}
 

@@ -1,0 +1,194 @@
+// cedarx_h264_encoder_amd/csrc/enc_plan.h
+// The schedule policy of a session as PURE functions of its geometry, the device's CU count, what the stream
+// probes found and the CEDAR_* development switches: how many frames in flight, how the two wavefront kernels
+// are split over workgroups, which deblock form, whether frames are pipelined on the device, how many stripes
+// and how many of them are held back, how many cohorts. No HIP, no session state: enc_session.cpp calls them
+// from CONFIG, and tests/test_plan.py holds every threshold through cedar_enc_plan() on a box without a GPU
+// (the 4K deadlock of round 2 -- more bands than wave pairs -- lived in exactly this code).
+// Every number here was measured on MI355X; DESIGN.md 5.1-5.5 says with what.
+#pragma once
+
+#include "enc_internal.h"
+
+namespace cedar {
+
+struct PlanIn {
+	int mb_w, mb_h;
+	int slice_count, slice_first, slice_num;
+	int n_streams;          // lock-step streams x GOP lanes
+	int cus;                // compute units of the device
+	int pinned_slot_bytes;  // bytes of pinned bytestream buffer one ring slot takes per stream
+	// development switches (CEDAR_*): INT32_MIN = not set
+	int env_row_pipe, env_pipe_depth, env_wf_split, env_wf_split_intra, env_db_pairs, env_deblock_streams,
+	    env_deblock_planes, env_inter_bands, env_defer, env_cohorts;
+};
+constexpr int PLAN_UNSET = -2147483647 - 1;
+constexpr int CEDAR_PLAN_MAX_DEPTH = 16; // = CEDAR_ENC_PIPELINE_DEPTH of the public header (asserted in enc_session.cpp)
+
+struct Plan {
+	int error;              // 0, or 1: a slice too tall for the deblock wavefront
+	int n_units;
+	int depth;              // frames in flight
+	int wf_split, wf_split_intra, db_pairs;
+	int split_planes;       // luma and chroma deblocking as separate workgroups
+	int want_row_pipe;      // frames pipelined on the device, if the streams turn out to overlap
+	int db_streams_wanted;  // deblock streams to probe for
+	int defer_wanted;       // one unit: the tail of a P picture may be held back (wants a third deblock stream)
+};
+
+struct PlanProbe {
+	int db_streams_usable;  // deblock streams that really run beside the analysis, the entropy stream and each other
+	int holds_pipe_token;   // this session is the one pipelined session of its device and process
+};
+
+struct PlanRun {
+	int row_pipe;
+	int db_streams;
+	int inter_bands;        // stripes of a P picture's analysis
+	int defer_default;      // stripes held back unless CEDAR_DEFER says otherwise
+	int cohorts;
+};
+
+inline void plan_band_range(const PlanIn &in, int &nb_min, int &nb_max)
+{
+	nb_min = 1 << 30;
+	nb_max = 0;
+	for (int s = in.slice_first; s < in.slice_first + in.slice_num; s++) {
+		int a, b;
+		slice_rows(in.mb_h, in.slice_count, s, &a, &b);
+		const int nb = (b - a + 3) / 4;
+		nb_min = nb < nb_min ? nb : nb_min;
+		nb_max = nb > nb_max ? nb : nb_max;
+	}
+}
+
+// everything that is decided before the streams exist
+inline Plan plan_static(const PlanIn &in)
+{
+	Plan p{};
+	const int n_units = in.n_streams * in.slice_num;
+	p.n_units = n_units;
+	auto set = [](int v) { return v != PLAN_UNSET; };
+
+	// Frames in flight. Sessions that pipeline their frames on the device (few units) take IDR pictures out of the
+	// frame order -- they depend on nothing -- so an IDR picture submitted early enough costs no time; "early
+	// enough" is its ~2.5 ms against ~0.2 ms per P picture (1080p), hence the deep ring. Everything else keeps 4.
+	// Every slot owns a pinned bytestream buffer sized for the worst case: the ring's share of host memory stays
+	// under 512 MB (4K: 33 MB a slot, eight 1080p streams: 67 MB).
+	{
+		const bool deep = set(in.env_row_pipe) ? in.env_row_pipe != 0 : n_units <= 8;
+		int depth = set(in.env_pipe_depth) ? in.env_pipe_depth : deep ? CEDAR_PLAN_MAX_DEPTH : 4;
+		const long long per_slot = (long long)in.pinned_slot_bytes * in.n_streams;
+		if (!set(in.env_pipe_depth) && deep && (long long)depth * per_slot > (512ll << 20))
+			depth = (int)((512ll << 20) / per_slot);
+		if (depth < 4) depth = set(in.env_pipe_depth) ? depth : 4;
+		if (depth < 2) depth = 2;
+		if (depth > CEDAR_PLAN_MAX_DEPTH) depth = CEDAR_PLAN_MAX_DEPTH;
+		p.depth = depth;
+	}
+
+	// Workgroups per unit for the wavefront kernels: one CU is instruction-bound by a single unit's wavefront, so
+	// few units are spread over more CUs. Measured, 1080p (17 bands of 4 macroblock rows per unit): deblock with 8
+	// wave pairs per workgroup: 1 unit 0.64 / 0.51 / 0.47 ms at 2 / 4 / 8 parts; 32 units 1.06 / 0.89 / 0.82 ms at
+	// 1 / 2 / 4 parts. Up to 8 units the frames are pipelined, which wants the resident deblock workgroups of 3
+	// frames within half of the CUs: 4 streams 55 M MB/s with 4 parts pipelined against 40 M with 8 parts back to
+	// back; 8: 69 M (2 parts, pipelined) against 62-67 M; 16: pipelining loses (80 M against 91 M).
+	int nb_min, nb_max;
+	plan_band_range(in, nb_min, nb_max);
+	auto clamp_split = [&](int split) {
+		if (split > WF_MAX_SPLIT) split = WF_MAX_SPLIT;
+		if (split > nb_min / 2) split = nb_min / 2;
+		return split < 1 ? 1 : split;
+	};
+	p.wf_split = clamp_split(set(in.env_wf_split) ? in.env_wf_split
+			: (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
+	{ // intra reconstruction: every band a triple of its own where the split allows (a workgroup with more bands than
+	  // triples serialises them: 3 triples, 1 unit: 7.1 ms at 4 parts against 3.3 ms at 6)
+		int si = set(in.env_wf_split_intra) ? in.env_wf_split_intra : (nb_max + IR_TRIPLES - 1) / IR_TRIPLES;
+		if (si > WF_MAX_SPLIT) si = WF_MAX_SPLIT;
+		if (si > nb_min) si = nb_min;
+		p.wf_split_intra = si < 1 ? 1 : si;
+	}
+	// Deblock workgroups: 8 wave pairs (a whole CU: one unit's wavefront as fast as it goes, what the pipelined
+	// sessions of up to 8 units want) or 2 pairs -- a quarter of the LDS and of the waves, which finds room on a CU
+	// beside other kernels' workgroups. Above 8 units frames run back to back and the small form wins: 16 x 1080p
+	// 114 -> 120 M MB/s, 32: 134 -> 139, 64: 139 -> 146 (up to 8 units: 1 / 4 / 8 streams 36.0 / 82.6 / 99.9 M with
+	// 8 pairs against 35.1 / 54.7 / 88.5 with 2).
+	p.db_pairs = set(in.env_db_pairs) ? (in.env_db_pairs == 2 ? 2 : 8) : n_units > 8 ? 2 : 8;
+	if (p.db_pairs < 8 && !set(in.env_wf_split) && (n_units > 8 || set(in.env_db_pairs))) {
+		// small workgroups: as many as it takes to give every band a wave pair
+		const int want = (nb_min + p.db_pairs - 1) / p.db_pairs;
+		p.wf_split = want > WF_MAX_SPLIT ? WF_MAX_SPLIT : want < 1 ? 1 : want;
+	}
+	// A band runs at most DB2_XRING (+3) macroblocks ahead of the band below it (the hand-off ring in LDS), and a
+	// workgroup with more bands than wave pairs starts band b + pairs when band b is through: on a row longer than
+	// pairs x ring that is a cycle (3840 wide, 9 bands on 8 pairs: round 2's deadlock). Then every band needs a pair.
+	auto db_safe = [&](int split, int pairs) { return (nb_max + split - 1) / split <= pairs || in.mb_w + 3 <= pairs * DB2_XRING; };
+	auto widen = [&](int pairs) {
+		while (!db_safe(p.wf_split, pairs) && p.wf_split < WF_MAX_SPLIT && p.wf_split < nb_min)
+			p.wf_split++;
+		return db_safe(p.wf_split, pairs);
+	};
+	if (!widen(p.db_pairs)) {
+		p.db_pairs = 8;
+		if (!widen(8))
+			p.error = 1;
+	}
+
+	// Luma and chroma as separate workgroups (two concurrent wavefronts) while CUs are spare; both planes in every
+	// wave pair from 32 units on, where the cohorts overlap deblocking with the other half's search: 32 x 1080p
+	// 152 M MB/s against 136-139 M with one-plane workgroups, 16 (no cohorts): 122 with one plane against 112.
+	p.split_planes = set(in.env_deblock_planes) ? in.env_deblock_planes != 0 : n_units < 32;
+
+	// One stream, one slice: the last stripes of a P picture are held back and go out between the first ones of the
+	// next (DeferredTail in enc_session.cpp), which wants a third deblock stream. 1080p, M MB/s: 5 stripes / 2
+	// streams 36.0; 8 stripes none held, 3 streams 36.4; 8 stripes 3 held, 2 streams 37.6; 8 stripes 3 held, 3 streams
+	// 42.1-43.6. CEDAR_DEFER=0 switches it off.
+	p.defer_wanted = n_units == 1 && !(set(in.env_defer) && in.env_defer == 0);
+	p.db_streams_wanted = set(in.env_deblock_streams) ? in.env_deblock_streams : p.defer_wanted ? 3 : 2;
+	// Frame pipelining needs kernels of the analysis and of the deblock streams on the GPU at the same time, and it
+	// must leave the GPU mostly free: a pipelined deblock kernel is resident (one CU per workgroup) while it waits
+	// for its frame's analysis, so the deblock workgroups of all frames in flight may only take half of the CUs.
+	p.want_row_pipe = set(in.env_row_pipe) ? in.env_row_pipe != 0
+					       : n_units <= 8 && 2 * n_units * p.wf_split * p.db_streams_wanted <= in.cus / 2;
+	return p;
+}
+
+// ... and what follows once the streams have been probed
+inline PlanRun plan_run(const PlanIn &in, const Plan &p, const PlanProbe &pr)
+{
+	PlanRun r{};
+	auto set = [](int v) { return v != PLAN_UNSET; };
+	int rows = 0; // macroblock rows of the slices this session codes
+	for (int sl = in.slice_first; sl < in.slice_first + in.slice_num; sl++) {
+		int a, b;
+		slice_rows(in.mb_h, in.slice_count, sl, &a, &b);
+		rows += b - a;
+	}
+	const int n_units = p.n_units, n_mbs = in.mb_w * rows;
+	r.row_pipe = p.want_row_pipe && pr.holds_pipe_token && pr.db_streams_usable >= 1;
+	r.db_streams = pr.db_streams_usable >= 1 && p.want_row_pipe && pr.holds_pipe_token ? pr.db_streams_usable : 1;
+	// every stripe costs a gate and two dependent launches: small pictures take fewer (854x480 13.1 -> 13.5 M MB/s
+	// with 3, 1080p equal from 3 to 8 while nothing is held back)
+	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 ? 5 : 3);
+	r.defer_default = 0;
+	if (r.row_pipe && p.defer_wanted && r.db_streams >= 3 && n_mbs >= 4000) {
+		if (!set(in.env_inter_bands))
+			nb = 8;
+		r.defer_default = nb >= 8 ? 3 : nb >= 6 ? 2 : 0;
+	}
+	if (nb > 64) nb = 64;
+	r.inter_bands = r.row_pipe ? (nb < 1 ? 1 : nb) : 1;
+	// Cohorts (sessions whose frames run back to back): two from 32 units on, with the small deblock form -- the
+	// deblocking of one half then runs beside the search of the other: 32 x 1080p 1.87 -> 1.73 ms per step, 64:
+	// 3.58 -> 3.18 ms. Not below: the deblock wavefront of a picture takes its time however few pictures there are,
+	// and half of 16 streams' search is shorter than that (16: 120 -> 92 M MB/s). Three or four lose everywhere.
+	int C = set(in.env_cohorts) ? in.env_cohorts : (n_units >= 32 && p.db_pairs == 2 ? 2 : 1);
+	if (r.row_pipe || C < 1) C = 1;
+	if (C > 4) C = 4;
+	if (C > in.n_streams) C = in.n_streams;
+	r.cohorts = C;
+	return r;
+}
+
+} // namespace cedar

@@ -29,6 +29,7 @@
 
 #include "../../include/cedar_h264enc.h"
 #include "enc_internal.h"
+#include "enc_plan.h"
 
 using namespace cedar;
 
@@ -499,6 +500,13 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 			}
 			slow[i][j] = worst > base + 1.5 ? worst - base : 0.0;
 		}
+	// Two queues share a pipe or they do not: what one direction shows holds for the other. A single probe misses
+	// the effect now and then (it comes and goes), and a pair measured as free in one direction once dealt the
+	// analysis stream a pipe-mate -- with 7 streams on 8 queues exactly one stream has none, and that one must
+	// carry the gates: one 1080p stream ran at 27-28 M MB/s instead of 43 M in 2 of 14 sessions.
+	for (int i = 0; i < NP; i++)
+		for (int j = i + 1; j < NP; j++)
+			slow[i][j] = slow[j][i] = slow[i][j] > slow[j][i] ? slow[i][j] : slow[j][i];
 	HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
 	int best[NROLE] = { 0, 1, 2, 3, 5, 6, 4 }, cur[NROLE];
 	double best_cost = 1e30;
@@ -864,6 +872,30 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 	return rc;
 }
 
+// geometry + the CEDAR_* development switches of the process -> what the schedule policy (enc_plan.h) works from
+static PlanIn plan_input(int mb_w, int mb_h, int slice_count, int slice_first, int slice_num, int n_streams, int cus)
+{
+	auto env = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : PLAN_UNSET; };
+	const long long slot = (long long)mb_w * mb_h * 1024 + 4096;
+	return PlanIn{ mb_w, mb_h, slice_count, slice_first, slice_num, n_streams, cus, (int)(slot < (1ll << 20) ? (1ll << 20) : slot),
+		       env("CEDAR_ROW_PIPE"), env("CEDAR_PIPE_DEPTH"), env("CEDAR_WF_SPLIT"), env("CEDAR_WF_SPLIT_INTRA"), env("CEDAR_DB_PAIRS"),
+		       env("CEDAR_DEBLOCK_STREAMS"), env("CEDAR_DEBLOCK_PLANES"), env("CEDAR_INTER_BANDS"), env("CEDAR_DEFER"), env("CEDAR_COHORTS") };
+}
+
+extern "C" int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar_enc_plan_result *r)
+{
+	if (!q || !r || q->mb_w < 1 || q->mb_h < 1 || q->slice_count < 1 || q->slice_count > q->mb_h || q->n_streams < 1 || q->cus < 1 ||
+	    q->slice_first < 0 || q->slice_num < 0 || q->slice_first + q->slice_num > q->slice_count)
+		return -EINVAL;
+	const int num = q->slice_num ? q->slice_num : q->slice_count - q->slice_first;
+	const PlanIn in = plan_input(q->mb_w, q->mb_h, q->slice_count, q->slice_first, num, q->n_streams, q->cus);
+	const Plan p = plan_static(in);
+	const PlanRun run = plan_run(in, p, PlanProbe{ q->db_streams_usable, q->holds_pipe_token });
+	*r = cedar_enc_plan_result{ p.error, p.depth, p.wf_split, p.wf_split_intra, p.db_pairs, p.split_planes, p.want_row_pipe,
+				    p.db_streams_wanted, run.row_pipe, run.db_streams, run.inter_bands, run.defer_default, run.cohorts };
+	return 0;
+}
+
 static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
 {
 	struct cedar_enc_config_ext ext{};
@@ -968,24 +1000,17 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	const int S = ext.n_streams;
 	const int n_units = S * ext.slice_num;
 
-	// Frames in flight. Sessions that pipeline their frames on the device (few units, below) take
-	// IDR pictures out of the frame order -- they depend on nothing -- so an IDR picture submitted
-	// early enough costs no time; "early enough" is its ~2.5 ms against ~0.23 ms per P picture
-	// (1080p), hence the deep ring. Everything else keeps 4.
-	{
-		const char *envp = getenv("CEDAR_ROW_PIPE"), *envd = getenv("CEDAR_PIPE_DEPTH");
-		const bool deep = envp ? atoi(envp) != 0 : n_units <= 8;
-		e->depth = envd ? atoi(envd) : deep ? CEDAR_ENC_PIPELINE_DEPTH : 4;
-		// every slot owns a pinned bytestream buffer sized for the worst case: keep the ring's
-		// share of host memory bounded (4K: 33 MB a slot, eight 1080p streams: 67 MB)
-		const size_t per_slot = ((size_t)P.n_mb * 1024 + 4096 < ((size_t)1 << 20) ? (size_t)1 << 20 : (size_t)P.n_mb * 1024 + 4096) * S;
-		if (!envd && deep && (size_t)e->depth * per_slot > ((size_t)512 << 20))
-			e->depth = (int)(((size_t)512 << 20) / per_slot);
-		if (e->depth < 4) e->depth = envd ? e->depth : 4;
-		if (e->depth < 2) e->depth = 2;
-		if (e->depth > CEDAR_ENC_PIPELINE_DEPTH) e->depth = CEDAR_ENC_PIPELINE_DEPTH;
-		e->nrec = e->depth + 1;
-	}
+	// The schedule policy is a pure function of geometry, CU count and the CEDAR_* switches (enc_plan.h; held
+	// by tests/test_plan.py without a GPU): frames in flight, wavefront splits, deblock form, what to probe for.
+	static_assert(CEDAR_PLAN_MAX_DEPTH == CEDAR_ENC_PIPELINE_DEPTH, "enc_plan.h");
+	int cus = 0;
+	HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+	const PlanIn pin = plan_input(P.mb_w, P.mb_h, P.slice_count, ext.slice_first, ext.slice_num, S, cus);
+	const Plan plan = plan_static(pin);
+	if (plan.error)
+		return fail(e, -EINVAL, "picture too tall for the deblock wavefront");
+	e->depth = plan.depth;
+	e->nrec = e->depth + 1;
 	// ---- buffer manager (cedar.c:605-704) ----
 	const int luma_sz = align_up(cfg->src_width * cfg->src_height, 4096);      // cedar.c:612
 	const int chroma_sz = align_up(cfg->src_width * cfg->src_height / 2, 4096); // cedar.c:621
@@ -1124,73 +1149,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
 	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
-	{
-		// workgroups per unit for the wavefront kernels: one CU is instruction-bound by a
-		// single unit's wavefront, so few units are spread over more CUs
-		int nb_min = 1 << 30;
-		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
-			int a, b;
-			slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
-			if ((b - a + 3) / 4 < nb_min) nb_min = (b - a + 3) / 4;
-		}
-		auto clamp_split = [&](int split) {
-			if (split > WF_MAX_SPLIT) split = WF_MAX_SPLIT;
-			if (split > nb_min / 2) split = nb_min / 2;
-			return split < 1 ? 1 : split;
-		};
-		const char *env = getenv("CEDAR_WF_SPLIT"), *env_i = getenv("CEDAR_WF_SPLIT_INTRA");
-		// Measured on MI355X, 1080p (17 bands of 4 macroblock rows per unit), see DESIGN.md:
-		//   deblock (8 filter/mover pairs per workgroup): 1 unit 0.64 / 0.51 / 0.47 ms at 2 / 4 / 8
-		//   parts; 32 units 1.06 / 0.89 / 0.82 ms at 1 / 2 / 4 parts
-		//   intra recon (IR_TRIPLES luma/chroma/mover triples per workgroup): a workgroup with more bands
-		//   than triples serialises them (3 triples: 7.1 ms at 4 parts against 3.3 ms at 6, 1 unit)
-		int nb_max = 0;
-		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
-			int a, b;
-			slice_rows(P.mb_h, P.slice_count, s2, &a, &b);
-			if ((b - a + 3) / 4 > nb_max) nb_max = (b - a + 3) / 4;
-		}
-		// Up to 8 units the frames are pipelined (below), which wants the resident deblock
-		// workgroups of 3 frames within half of the CUs: 1080p x 4 streams 55 M MB/s with 4 parts
-		// pipelined against 40 M with 8 parts back to back; x 8: 69 M (2 parts, pipelined) against
-		// 62-67 M; x 16: pipelining loses (80 M against 91 M), frames run back to back from there.
-		e->wf_split = clamp_split(env ? atoi(env) : (n_units <= 2 ? 8 : n_units <= 5 ? 4 : n_units <= 8 ? 2 : n_units <= 64 ? 4 : n_units <= 128 ? 2 : 1));
-		{ // every band a triple of its own where the split allows (a workgroup with more bands serialises them)
-			int si = env_i ? atoi(env_i) : (nb_max + IR_TRIPLES - 1) / IR_TRIPLES;
-			if (si > WF_MAX_SPLIT) si = WF_MAX_SPLIT;
-			if (si > nb_min) si = nb_min;
-			e->wf_split_intra = si < 1 ? 1 : si;
-		}
-		const char *env_p = getenv("CEDAR_DB_PAIRS");
-		// Deblock workgroups: 8 wave pairs (a whole CU: one unit's wavefront as fast as it goes, what the
-		// pipelined sessions of up to 8 units want) or 2 pairs -- a quarter of the LDS and of the waves,
-		// which finds room on a CU beside other kernels' workgroups. Above 8 units frames run back to back
-		// and the small form wins: 16 x 1080p 114 -> 120 M MB/s, 32: 134 -> 139, 64: 139 -> 146. (Up to 8
-		// units the big form stays: 1 / 4 / 8 streams 36.0 / 82.6 / 99.9 M against 35.1 / 54.7 / 88.5 with 2
-		// pairs and 34.2 / 85.9 / 93.8 with 4; the kernel's own time is 0.38-0.39 ms per picture in every
-		// form -- its three spilled registers cost nothing measurable.)
-		e->db_pairs = env_p ? (atoi(env_p) == 2 ? 2 : 8) : n_units > 8 ? 2 : 8;
-		if (e->db_pairs < 8 && !env && (n_units > 8 || env_p)) { // small workgroups: as many as it takes to give every band a wave pair
-			const int want = (nb_min + e->db_pairs - 1) / e->db_pairs;
-			e->wf_split = want > WF_MAX_SPLIT ? WF_MAX_SPLIT : want < 1 ? 1 : want;
-		}
-		// A band runs at most DB2_XRING (+3) macroblocks ahead of the band below it (the hand-off ring in
-		// LDS), and a workgroup with more bands than wave pairs starts band b + pairs when band b is
-		// through: on a row longer than pairs x ring that is a cycle. Then every band needs a pair.
-		auto db_safe = [&](int split, int pairs) {
-			return (nb_max + split - 1) / split <= pairs || P.mb_w + 3 <= pairs * DB2_XRING;
-		};
-		auto widen = [&](int pairs) {
-			while (!db_safe(e->wf_split, pairs) && e->wf_split < WF_MAX_SPLIT && e->wf_split < nb_min)
-				e->wf_split++;
-			return db_safe(e->wf_split, pairs);
-		};
-		if (!widen(e->db_pairs)) {
-			e->db_pairs = 8;
-			if (!widen(8))
-				return fail(e, -EINVAL, "picture too tall for the deblock wavefront (%d bands of a slice)", nb_max);
-		}
-	}
+	e->wf_split = plan.wf_split;
+	e->wf_split_intra = plan.wf_split_intra;
+	e->db_pairs = plan.db_pairs;
 	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
 		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
@@ -1219,20 +1180,11 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (int i = 1; i < AN_STREAMS; i++)
 		HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ana[i], hipStreamNonBlocking));
 	if (e->depth > 4) {
-		const char *envd3 = getenv("CEDAR_DEBLOCK_STREAMS"), *envdf = getenv("CEDAR_DEFER");
-		const int rc_roles = assign_stream_roles(e, envd3 ? atoi(envd3) : (n_units == 1 && !(envdf && atoi(envdf) == 0)) ? 3 : 2);
+		const int rc_roles = assign_stream_roles(e, plan.db_streams_wanted);
 		if (rc_roles)
 			return rc_roles;
 	}
-	{
-		const char *env = getenv("CEDAR_DEBLOCK_PLANES");
-		// Luma and chroma as separate workgroups (two concurrent wavefronts) while CUs are spare; both planes
-		// in every wave pair from 32 units on, where the cohorts overlap deblocking with the other half's
-		// search: 32 x 1080p 152 M MB/s against 136-139 M with one-plane workgroups (twice as many of them
-		// waiting for room beside k_inter), 64: 161 against 156; 16 (no cohorts): 122 with one plane per
-		// workgroup against 112
-		e->split_planes = env ? atoi(env) != 0 : n_units < 32;
-	}
+	e->split_planes = plan.split_planes != 0;
 	HIP_TRY(e, hipEventCreateWithFlags(&e->ev_host_in, hipEventDisableTiming));
 	if (getenv("CEDAR_TRACE_TIMELINE")) {
 		HIP_TRY(e, hipEventCreate(&e->ev_base));
@@ -1247,21 +1199,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// workgroup, nothing else fits beside it) while it waits for its frame's analysis, so the
 		// deblock workgroups of all frames in flight may only take a fraction of the CUs, or the
 		// analysis they wait for finds no CU to run on.
-		int cus = 0;
-		HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-		const char *env = getenv("CEDAR_ROW_PIPE");
-		const char *envd = getenv("CEDAR_DEBLOCK_STREAMS");
-		// measured (1080p, 1 stream, M MB/s): analysis x deblock streams 1x2 16.8, 2x2 15.3-16.7,
-		// 2x3 15.8, 3x3 15.9, 1x3 12: the leanest set that overlaps two deblock kernels wins
-		// One stream, one slice: the last stripes of a P picture are held back and go out between the first ones
-		// of the next (DeferredTail), which wants a third deblock stream -- a picture's deblocking may then start
-		// while the one two frames back is still resident. 1080p, M MB/s over 4-6 runs each: 5 stripes / 2 streams
-		// 36.0; 8 stripes none held, 3 streams 36.4-36.5; 8 stripes 3 held, 2 streams 37.4-37.8; 6 stripes 2 held,
-		// 3 streams 42.1-42.4; 8 stripes 3 held, 3 streams 42.1-43.6. CEDAR_DEFER=0 switches it off.
-		const char *envdf = getenv("CEDAR_DEFER");
-		const bool defer_wanted = n_units == 1 && !e->mux && !(envdf && atoi(envdf) == 0);
-		const int db_max = envd ? atoi(envd) : defer_wanted ? 3 : 2;
-		bool want = env ? atoi(env) != 0 : n_units <= 8 && 2 * n_units * e->wf_split * db_max <= cus / 2;
+		const int db_max = plan.db_streams_wanted;
+		bool want = plan.want_row_pipe != 0;
 		if (want && !e->holds_pipe_token) {
 			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
 				e->holds_pipe_token = true;
@@ -1290,8 +1229,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			}
 		}
 		HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
-		e->row_pipe = want && usable >= 1;
-		e->db_streams = usable >= 1 ? usable : 1;
+		const PlanRun run = plan_run(pin, plan, PlanProbe{ usable, e->holds_pipe_token ? 1 : 0 });
+		e->row_pipe = run.row_pipe != 0;
+		e->db_streams = run.db_streams;
 		// further analysis streams: each must run beside every deblock stream and every analysis
 		// stream already accepted (a frame's gate kernels spin while the next frame's run)
 		int an = 1;
@@ -1313,18 +1253,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			}
 		}
 		e->an_streams = an;
-		const char *envb = getenv("CEDAR_INTER_BANDS");
-		// (every stripe costs a gate and two dependent launches: small pictures take fewer; 854x480
-		// 13.1 -> 13.5 M MB/s with 3, 1080p equal from 3 to 8)
-		int nb = envb ? atoi(envb) : (P.mb_w * P.row_num >= 4000 ? 5 : 3);
-		e->defer_default = 0;
-		if (defer_wanted && e->db_streams >= 3 && P.mb_w * P.row_num >= 4000) {
-			if (!envb)
-				nb = 8;
-			e->defer_default = nb >= 8 ? 3 : nb >= 6 ? 2 : 0;
-		}
-		if (nb > 64) nb = 64;
-		e->inter_bands = e->row_pipe ? (nb < 1 ? 1 : nb) : 1;
+		e->inter_bands = run.inter_bands;
+		e->defer_default = run.defer_default;
 		// Look-ahead for IDR pictures: two more streams -- the IDR picture's analysis (busy for
 		// milliseconds) and the input of all frames (which must never queue behind that, nor behind
 		// a gate on s_main) -- dealt by assign_stream_roles; each must run beside every stream in use.
@@ -1385,12 +1315,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			// Three or four cohorts lose everywhere (more, smaller launches on the same four hardware queues).
 			// Wave priority (s_setprio) for the deblock waves and sleeping instead of spinning in their
 			// waits changed nothing either way.
-			const char *envc = getenv("CEDAR_COHORTS");
-			int C = envc ? atoi(envc) : (n_units >= 32 && e->db_pairs == 2 ? 2 : 1);
-			if (e->row_pipe || C < 1)
-				C = 1;
-			if (C > MAX_COHORTS) C = MAX_COHORTS;
-			if (C > S) C = S;
+			const int C = run.cohorts;
 			e->cohorts = C;
 			// CEDAR_COHORT_STREAMS (development): bit 0 the deblocking, bit 1 the entropy chain of cohort c > 0 on a
 			// stream of its own. Off by default: measured at 32 x 1080p, both on 162.7 M MB/s against 168.9 M on the

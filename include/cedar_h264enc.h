@@ -296,7 +296,28 @@ void cedar_enc_gen_pattern(int pattern, int width, int height, int frame,
 const char *cedar_enc_last_error(cedar_enc *enc);
 const char *cedar_enc_version(void);
 
+/* Schedule introspection (no device needed; tests/test_plan.py): what CONFIG decides for a geometry -- frames in
+ * flight, how the two wavefront kernels are split over workgroups, the deblock form, whether frames are pipelined on
+ * the device, stripes and how many are held back, cohorts -- given what the stream probes found. The CEDAR_*
+ * development switches are read from the environment as CONFIG reads them. Returns 0, or -EINVAL. */
+struct cedar_enc_plan_query {
+	int mb_w, mb_h;                         /* coded size in macroblocks */
+	int slice_count, slice_first, slice_num; /* as cedar_enc_config_ext (slice_num 0 = all) */
+	int n_streams;                          /* lock-step streams x GOP lanes */
+	int cus;                                /* compute units of the device (MI355X: 256) */
+	int db_streams_usable;                  /* probe result: deblock streams that run beside the others */
+	int holds_pipe_token;                   /* 1: no other pipelined session on the device in this process */
+};
+struct cedar_enc_plan_result {
+	int error;                              /* 1: a slice too tall for the deblock wavefront */
+	int depth, wf_split, wf_split_intra, db_pairs, split_planes;
+	int want_row_pipe, db_streams_wanted;   /* before the probes */
+	int row_pipe, db_streams, inter_bands, defer_default, cohorts; /* after them */
+};
+int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar_enc_plan_result *r);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif /* CEDAR_H264ENC_H */

@@ -47,6 +47,11 @@ def test_bench_single_gpu_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0  # 1 thread and all cores
     assert j["bitexact_vs_cpu"] is True  # the GPU bytes of the sample equal the oracle's
+    # BASELINE configs[1] and configs[3] (one-GPU forms) ride on the same line; the traffic figure says where it is from
+    assert [c["macroblocks_per_frame"] for c in j["configs"]] == [54 * 30, 240 * 135, 240 * 135] and all(c["value"] > 0 for c in j["configs"])
+    assert rf["traffic"] is None or "static" in rf["traffic_source"]
+    ki = [k for k in rf["kernels"] if k["kernel"] == "k_inter"][0]
+    assert ki["true_bound"]["valu_slots_per_macroblock"] > 0 and 0 < ki["true_bound"]["frac"] < 1
 
 
 @pytest.mark.gpu

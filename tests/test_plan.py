@@ -1,0 +1,118 @@
+"""The schedule policy of a session (cedarx_h264_encoder_amd/csrc/enc_plan.h) through cedar_enc_plan(): pure
+functions of geometry, CU count, probe results and the CEDAR_* switches, so every threshold is held here on a box
+without a GPU -- pipelining on / off, deblock wave pairs, cohorts, planes, the widening of the deblock split
+(round 2's 4K deadlock lived in that code), stripes and how many are held back. The reference has no counterpart:
+its one silicon pipeline runs one frame at a time (kernel/cedar.c:1176-1180)."""
+import ctypes
+
+import pytest
+
+import cedarx_h264_encoder_amd as ce
+
+
+class Query(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("mb_w", "mb_h", "slice_count", "slice_first", "slice_num", "n_streams", "cus",
+                                            "db_streams_usable", "holds_pipe_token")]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("error", "depth", "wf_split", "wf_split_intra", "db_pairs", "split_planes",
+                                            "want_row_pipe", "db_streams_wanted", "row_pipe", "db_streams", "inter_bands",
+                                            "defer_default", "cohorts")]
+
+
+ENV = ("CEDAR_ROW_PIPE", "CEDAR_PIPE_DEPTH", "CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DB_PAIRS", "CEDAR_DEBLOCK_STREAMS",
+       "CEDAR_DEBLOCK_PLANES", "CEDAR_INTER_BANDS", "CEDAR_DEFER", "CEDAR_COHORTS")
+
+
+@pytest.fixture
+def plan(monkeypatch):
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    L = ce.load_library()
+    L.cedar_enc_plan.argtypes = [ctypes.POINTER(Query), ctypes.POINTER(Result)]
+
+    def run(w=1920, h=1080, streams=1, slices=1, first=0, num=0, cus=256, usable=3, token=1, **env):
+        for k, v in env.items():
+            monkeypatch.setenv("CEDAR_" + k.upper(), str(v))
+        q = Query((w + 15) // 16, (h + 15) // 16, slices, first, num, streams, cus, usable, token)
+        r = Result()
+        rc = L.cedar_enc_plan(ctypes.byref(q), ctypes.byref(r))
+        for k in env:
+            monkeypatch.delenv("CEDAR_" + k.upper())
+        assert rc == 0
+        return r
+    return run
+
+
+def test_one_1080p_stream_is_pipelined_with_held_back_stripes(plan):
+    r = plan()
+    assert (r.depth, r.wf_split, r.db_pairs, r.split_planes) == (16, 8, 8, 1)
+    assert (r.want_row_pipe, r.db_streams_wanted) == (1, 3)
+    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 3, 8, 3, 1)
+    assert r.wf_split_intra == 9            # 17 bands of 4 rows, two triples per workgroup
+    # only two deblock streams really overlap: no third one, nothing held back, 5 stripes as before
+    r = plan(usable=2)
+    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default) == (1, 2, 5, 0)
+    # no stream overlaps, or another session of the process holds the device's pipelining: frames back to back
+    for kw in (dict(usable=0), dict(token=0)):
+        r = plan(**kw)
+        assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default) == (0, 1, 1, 0)
+    # switches
+    assert plan(defer=0).db_streams_wanted == 2 and plan(defer=0).defer_default == 0
+    assert plan(inter_bands=6).defer_default == 2 and plan(inter_bands=5).defer_default == 0
+    assert plan(row_pipe=0).row_pipe == 0 and plan(row_pipe=0).depth == 4
+    assert plan(pipe_depth=7).depth == 7
+
+
+def test_small_pictures_take_three_stripes_and_hold_nothing_back(plan):
+    r = plan(w=854, h=480)
+    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default) == (1, 3, 3, 0)
+    r = plan(w=320, h=240)
+    assert (r.wf_split, r.wf_split_intra) == (2, 2)   # 4 bands: a split never leaves a workgroup fewer than two
+    r = plan(w=3840, h=2160)
+    assert (r.row_pipe, r.inter_bands, r.defer_default, r.depth) == (1, 8, 3, 16)   # 33 MB of pinned bytestream a slot: 16 of them just fit 512 MB
+
+
+def test_units_decide_the_deblock_form_the_split_and_the_pipelining(plan):
+    want = {  # streams: (wf_split, db_pairs, want_row_pipe, split_planes, cohorts)
+        1: (8, 8, 1, 1, 1), 2: (8, 8, 1, 1, 1), 3: (4, 8, 1, 1, 1), 5: (4, 8, 1, 1, 1), 6: (2, 8, 1, 1, 1), 8: (2, 8, 1, 1, 1),
+        9: (9, 2, 0, 1, 1), 16: (9, 2, 0, 1, 1), 31: (9, 2, 0, 1, 1), 32: (9, 2, 0, 0, 2), 64: (9, 2, 0, 0, 2), 200: (9, 2, 0, 0, 2),
+    }
+    for s, w in want.items():
+        r = plan(streams=s, usable=2)
+        assert (r.wf_split, r.db_pairs, r.want_row_pipe, r.split_planes, r.cohorts) == w, s
+        slot = 8160 * 1024 + 4096   # pinned bytestream per stream and ring slot; the ring stays under 512 MB
+        assert r.depth == (max(4, min(16, (512 << 20) // (slot * s))) if s <= 8 else 4), s
+        assert r.db_streams_wanted == (3 if s == 1 else 2)
+    # pipelining must leave half of the CUs to the analysis the resident deblock workgroups wait for
+    assert plan(streams=4, cus=256).want_row_pipe == 1 and plan(streams=4, cus=120).want_row_pipe == 0
+    assert plan(streams=32, cohorts=3).cohorts == 3 and plan(streams=2, cohorts=4).cohorts == 1   # (pipelined: one)
+    assert plan(streams=32, db_pairs=8).cohorts == 1 and plan(streams=32, deblock_planes=1).split_planes == 1
+
+
+def test_a_band_needs_a_wave_pair_where_rows_are_long(plan):
+    """A band runs at most 16 (+3) macroblocks ahead of the band below it (the LDS ring); a workgroup with more bands
+    than wave pairs starts band b + pairs when band b is through: on a row longer than pairs x 16 macroblocks that is a
+    cycle -- 3840 wide, 9 bands on 8 pairs deadlocked in round 2. The split widens until every band has a pair."""
+    r = plan(w=3840, h=592, wf_split=1)                # 240 x 37 macroblocks, 10 bands, asked to run as ONE workgroup
+    assert r.error == 0 and (10 + r.wf_split - 1) // r.wf_split <= r.db_pairs
+    r = plan(w=3840, h=2160, streams=16)               # 34 bands, small form: 17 workgroups would do, 16 is the most
+    assert r.error == 0 and r.db_pairs == 8 and (34 + r.wf_split - 1) // r.wf_split <= 8
+    r = plan(w=1920, h=1080, streams=16)               # 120 + 3 <= 2 x 16? no: every band its own pair
+    assert (r.db_pairs, r.wf_split) == (2, 9) and (17 + 8) // 9 <= 2
+    r = plan(w=256, h=4352, wf_split=1)                # short rows: 16 + 3 <= 8 x 16, one workgroup may serialise its 68 bands
+    assert r.error == 0 and r.wf_split == 1
+    assert plan(w=3840, h=16 * 4 * 8 * 16 + 64).error == 1   # 513 bands: more than 16 workgroups x 8 pairs can give a pair each
+
+
+def test_slices_and_slice_shards(plan):
+    r = plan(w=3840, h=2160, slices=4)                 # configs[3] on one GPU: 4 units of 34 / 34 / 34 / 33 rows
+    assert (r.wf_split, r.db_pairs, r.want_row_pipe, r.db_streams_wanted, r.defer_default) == (4, 8, 1, 2, 0)
+    assert r.wf_split_intra == 5                       # 9 bands, two triples per workgroup
+    r = plan(w=3840, h=2160, slices=4, first=3, num=1)  # one slice of four on its own GPU: one unit of 33 rows
+    assert (r.wf_split, r.db_pairs, r.want_row_pipe, r.db_streams_wanted) == (4, 8, 1, 3)
+    assert (r.inter_bands, r.defer_default) == (8, 3)   # 240 x 33 macroblocks: held-back stripes as for any one unit
+    L = ce.load_library()
+    bad = Query(120, 68, 4, 3, 2, 1, 256, 2, 1)
+    assert L.cedar_enc_plan(ctypes.byref(bad), ctypes.byref(Result())) < 0
