@@ -87,6 +87,7 @@ struct Params {
 	int32_t qp, qpc, search_range, lambda;
 	int32_t subpel;             // motion vector precision: 0 whole samples, 1 half, 2 quarter
 	int32_t is_idr;
+	uint32_t *cut_votes;        // scene cuts (cedar_enc_config_ext.scene_cut; nullptr: off): macroblocks of this P picture that their own mean predicts better than the best vector
 	int32_t pcm;                // this picture takes I_PCM macroblocks (cedar_enc_config_ext.pcm, and its QP leaves their edges unfiltered)
 	int32_t intra_refresh;      // N >= 3: macroblocks with (x + 2*y + refresh_t) % N == 0 of a P picture are coded intra; 0 off
 	int32_t refresh_t;          // P pictures since the IDR (1 for the first)

@@ -538,11 +538,17 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 
 	// ---- stage everything the half needs (coalesced) ----
 	{
+		// levels: only the block groups the macroblock's coded block pattern names (k_inter stores no others;
+		// 16-byte chunk hl = half a luma block, hl + 32 = Intra16x16 DCs, chroma DCs, chroma AC halves)
+		const MbInfo m0 = p.mbi[mbaddr];
+		const bool i16 = m0.type == MB_I16x16;
 		const u32x4 *src = (const u32x4 *)(p.coef + mbaddr * COEF_PER_MB);
 		u32x4 *dst = (u32x4 *)s_cf[half];
-		dst[hl] = src[hl];
-		if (hl + 32 < COEF_PER_MB / 8)
-			dst[hl + 32] = src[hl + 32];
+		if ((m0.cbp >> (hl >> 3)) & 1)
+			dst[hl] = src[hl];
+		const int c2 = hl + 32;
+		if (c2 < COEF_PER_MB / 8 && (c2 < 34 ? i16 : c2 == 34 ? (m0.cbp & 0x30) != 0 : (m0.cbp & 0x20) != 0))
+			dst[c2] = src[c2];
 		if (hl < 24) {
 			s_nnz[half][0][hl] = p.nnz[mbaddr * NNZ_PER_MB + hl];
 			s_nnz[half][1][hl] = has_left ? p.nnz[(mbaddr - 1) * NNZ_PER_MB + hl] : 0;

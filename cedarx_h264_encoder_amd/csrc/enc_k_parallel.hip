@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 	// first job of every frame on this stream: the ticket / abort / progress words of the intra
 	// wavefront kernel (region 0) start at zero; the deblock regions are cleared on the deblock
 	// kernel's own stream
+	if (blockIdx.y == 0 && st == 0 && seg == 0 && p.cut_votes) // scene cuts: this frame's count starts at zero
+		p.cut_votes[0] = 0;
 	if (blockIdx.y == 0 && st == 0 && p.wf_split_intra > 1) {
 		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
 		for (int i = seg; i < used; i += gridDim.x * blockDim.x)
@@ -636,6 +638,15 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		}
 		final_cost = bestj;
 	}
+	// scene cuts (Params::cut_votes): does the macroblock's own mean predict it better than the best vector? The
+	// session counts the votes of the picture and codes it again as an IDR picture if they reach its threshold.
+	if (p.cut_votes && !(REFRESH && refresh)) {
+		const uint32_t mine = ((const uint32_t *)s_cur)[lane];
+		const int mean = (wave_sum_i32((int)__builtin_amdgcn_sad_u8(mine, 0u, 0u)) + 128) >> 8;
+		const int sadm = wave_sum_i32((int)__builtin_amdgcn_sad_u8(mine, (uint32_t)mean * 0x01010101u, 0u));
+		if (lane == 0 && valid && (uint32_t)(sadm + 32 * qs.lambda) < final_cost)
+			atomicAdd(p.cut_votes, 1u);
+	}
 	// MAD classes (Params::mad_on): the SAD of the chosen prediction -- its cost without the vector's
 	// share -- picks one of five QP offsets for the residual; the decision above was taken without it
 	if (MBQP) {
@@ -871,8 +882,22 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	}
 
 	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
-	if (lane < COEF_PER_MB * 2 / 16)
-		*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)s_coef + lane * 16);
+	{
+		// levels: only the block groups the coded block pattern names (16-byte chunk = half a luma block, the
+		// chroma DCs, half a chroma AC block; the Intra16x16 DCs only for a refresh macroblock) -- nobody reads the
+		// others, and at the rates of real pictures most are empty: 6.7 MB per 1080p picture were written, then read
+		bool need;
+		if (lane < 32)
+			need = (cbp >> (lane >> 3)) & 1;
+		else if (lane < 34)
+			need = REFRESH && refresh;
+		else if (lane == 34)
+			need = (cbp & 0x30) != 0;
+		else
+			need = lane < COEF_PER_MB * 2 / 16 && (cbp & 0x20) != 0;
+		if (need)
+			*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)s_coef + lane * 16);
+	}
 	if (lane < 16)
 		*(u32x4 *)(rec_y + (uint32_t)lane * cw) = *(const u32x4 *)(s_recy + lane * 16);
 	else if (lane < 24)
@@ -1039,6 +1064,8 @@ __global__ __launch_bounds__(256) void k_copy_out(Params p, uint8_t *host_out, u
 		((u32x4 *)host_out)[i] = ((const u32x4 *)p.out)[i];
 	if (blockIdx.x == 0 && (int)threadIdx.x < p.n_streams + 2)
 		host_sizes[threadIdx.x] = p.stream_size[threadIdx.x];
+	if (p.cut_votes && blockIdx.x == 0 && (int)threadIdx.x == p.n_streams + 2) // scene cuts (one stream, one cohort): the picture's votes
+		host_sizes[threadIdx.x] = p.cut_votes[0];                              // (the analysis is over: the entropy stream waited for it)
 	if (!p.done_flag)
 		return;
 	// Pipelined frames: the last workgroup raises the frame's "bitstream delivered" flag (after

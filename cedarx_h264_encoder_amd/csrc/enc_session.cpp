@@ -305,6 +305,7 @@ struct cedar_enc {
 	// stream the next picture's first stripe -- which only needs that deblocking a quarter through -- would
 	// sit behind it. (submit_frame; emitted at the latest when the frame is collected.)
 	bool pcm_session = false;    // the session takes I_PCM macroblocks (picture_takes_pcm says in which pictures)
+	uint32_t *d_cut_votes[CEDAR_ENC_PIPELINE_DEPTH] = {}; // scene cuts: the votes of the P picture in every device slot
 	Flusher *flusher = nullptr;  // only sessions that hold tails back (defer_from < inter_bands)
 	int defer_default = 0;       // stripes held back unless CEDAR_DEFER says otherwise (set with the stripe count)
 	int defer_from = 0;          // first deferred stripe; inter_bands = nothing is deferred
@@ -420,6 +421,8 @@ void free_all(cedar_enc *e)
 		F(e->d_rbsp[l]); F(e->d_esc[l]); F(e->d_nal_off[l]); F(e->d_nal_size[l]); F(e->d_stream_size[l]);
 	}
 	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab); F(e->d_abort_all);
+	for (uint32_t *v : e->d_cut_votes)
+		F(v);
 	if (e->mux) {
 		F(e->mux->d_store_y); F(e->mux->d_store_uv);
 		delete e->mux;
@@ -963,6 +966,10 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			return fail(e, -EINVAL, "mad_th: four ascending thresholds 0..255");
 	if (ext.strict_mb_bits < 0 || ext.strict_mb_bits > 2)
 		return fail(e, -EINVAL, "strict_mb_bits must be 0, 1 or 2");
+	if (ext.scene_cut < 0 || ext.scene_cut > 100)
+		return fail(e, -EINVAL, "scene_cut is a percentage: 0 (off) .. 100");
+	if (ext.scene_cut > 0 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count || ext.first_frame_index != 0))
+		return fail(e, -EINVAL, "scene_cut: one stream, whole pictures, no gop_parallel, a stream that starts at frame 0");
 	if (ext.pcm < -1 || ext.pcm > 0)
 		return fail(e, -EINVAL, "pcm must be 0 (I_PCM where a macroblock could pass 3200 bits) or -1 (never)");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
@@ -1149,6 +1156,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
 	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
+	for (int i = 0; i < e->depth && ext.scene_cut > 0; i++)
+		if ((rc = dalloc(e, &e->d_cut_votes[i], (size_t)4))) return rc;
 	e->wf_split = plan.wf_split;
 	e->wf_split_intra = plan.wf_split_intra;
 	e->db_pairs = plan.db_pairs;
@@ -1773,6 +1782,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			      e->chroma_qp_offset);
 	f.qp = P.qp;
 	P.pcm = e->pcm_session && picture_takes_pcm(P.qp, e->chroma_qp_offset) ? 1 : 0;
+	P.cut_votes = e->ext.scene_cut > 0 && !idr ? e->d_cut_votes[ds] : nullptr; // scene cuts: P pictures are asked
 	if (e->rc_multi) { // the law per stream; the launch's own QP (Params::qp) is not used by the per-macroblock forms
 		for (int s = 0; s < S; s++)
 			f.h_qp_s[s] = (uint8_t)rc_pick_qp(e->cfg.qp, e->rc_target, &e->rc_bits_s[(size_t)s * 64], &e->rc_qp_s[(size_t)s * 64],
@@ -1914,11 +1924,12 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		for (int k = 0; k < e->ext.slice_num; k++) {
 			int r0, r1;
 			slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
-			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, (int)(gop & 1), r0 * P.mb_w,
+			// (scene cuts put IDR pictures anywhere: two in a row must still differ in idr_pic_id, so it follows their count)
+			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, e->ext.scene_cut > 0 ? (int)(e->idr_count & 1u) : (int)(gop & 1), r0 * P.mb_w,
 									       (e->rc_multi ? (int)f.h_qp_s[s] : P.qp) - e->cfg.qp);
 		}
 		// cedar.c:1058-1061: SPS + PPS in front of the stream's first picture (the IDR picture of GOP 0)
-		f.with_ps[s] = idr && (gop == 0 || e->ext.repeat_headers) && e->ext.slice_first == 0;
+		f.with_ps[s] = idr && ((e->ext.scene_cut > 0 ? gidx == 0 : gop == 0) || e->ext.repeat_headers) && e->ext.slice_first == 0;
 		f.h_prefix[s] = (f.with_ps[s] ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
 	}
 	// entropy lanes: frames alternate between two streams with scratch buffers of their own
@@ -1937,6 +1948,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.stream_size = e->d_stream_size[lane];
 	f.lane = lane;
 	f.host_out = slot; // every frame in flight owns one host buffer until it is collected
+	if (e->ext.scene_cut > 0)
+		e->h_sizes[slot][S + 2] = 0; // (k_copy_out reports a P picture's votes there)
 	f.s_ent = s_ent;
 	f.s_db = s_db;
 	f.events = !pipe;
@@ -2280,6 +2293,19 @@ static int collect_frame(cedar_enc *e)
 		too_big = too_big || sz[n] > (size_t)n * e->stream_out_cap;
 	}
 	const uint32_t wf_err = *f.h_wf_err;
+	// Scene cut (cedar_enc_config_ext.scene_cut): enough macroblocks of this P picture said their own mean predicts them
+	// better than the best vector: the picture is coded again as an IDR picture that starts a new GOP, and the frames
+	// submitted behind it after it -- the machinery of a failed frame, with the frame itself put back first.
+	if (e->ext.scene_cut > 0 && !f.idr && !hip_failed && !wf_err && !(flags & ~4u) && !too_big &&
+	    (uint64_t)e->h_sizes[slot][S + 2] * 100 >= (uint64_t)e->ext.scene_cut * e->P.n_mb) {
+		ReplayIn again{ f.in_used, f.in_own, f.lane_gidx, true, f.qp_bump };
+		const InFlight snapshot = f;
+		const int rc = recover(e, snapshot, &again);
+		if (rc)
+			return rc;
+		e->stats.scene_cuts++;
+		return collect_frame(e);
+	}
 	// flag 4: a macroblock of more than 3200 bits (H.264 A.3.1). Counted, or -- strict_mb_bits -- refused
 	const bool oversize = (flags & 4u) != 0;
 	flags &= ~4u;
@@ -2703,6 +2729,29 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 		return fail(e, -ENOSPC, "debug buffer needs %zu bytes", n);
 	HIP_TRY(e, hipSetDevice(e->device));
 	HIP_TRY(e, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+	if (what == CEDAR_ENC_DBG_COEF) {
+		// k_inter only stores the levels of the block groups its coded block pattern names (the entropy kernels
+		// read no others): what the buffer holds elsewhere is an earlier picture's. Shown as what it means: zero.
+		std::vector<MbInfo> mi((size_t)P.n_mb);
+		HIP_TRY(e, hipMemcpy(mi.data(), e->d_mbi[par] + (size_t)stream * P.n_mb, sizeof(MbInfo) * P.n_mb, hipMemcpyDeviceToHost));
+		int16_t *cf = (int16_t *)dst;
+		for (int i = 0; i < P.n_mb; i++, cf += COEF_PER_MB) {
+			if (mi[i].type == MB_IPCM) { // (no level at all)
+				memset(cf, 0, sizeof(int16_t) * COEF_PER_MB);
+				continue;
+			}
+			if (mi[i].type < MB_P16x16)
+				continue;
+			for (int g8 = 0; g8 < 4; g8++)
+				if (!(mi[i].cbp & (1 << g8)))
+					memset(cf + COEF_LUMA + 64 * g8, 0, 128);
+			memset(cf + COEF_DC16, 0, 32);
+			if (!(mi[i].cbp & 0x30))
+				memset(cf + COEF_CDC, 0, 16);
+			if (!(mi[i].cbp & 0x20))
+				memset(cf + COEF_CAC, 0, 256);
+		}
+	}
 	return (int)n;
 }
 

@@ -92,6 +92,7 @@ static int ve_config(int width, int height) /* h264enc.c:47-117 */
 	}
 	ext.subpel = env_int("H264ENC_SUBPEL", 0);
 	ext.pcm = env_int("H264ENC_PCM", 0); /* -1: no I_PCM macroblocks */
+	ext.scene_cut = env_int("H264ENC_SCENE_CUT", 0);
 
 	ret = cedar_enc_config_ext(cedar, &config, &ext);
 	if (ret) {

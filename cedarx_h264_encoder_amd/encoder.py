@@ -43,7 +43,7 @@ class _ConfigExt(ctypes.Structure):
         "size", "device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
         "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
         "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "roi_count")] + [
-        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5), ("pcm", ctypes.c_int)]
+        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5), ("pcm", ctypes.c_int), ("scene_cut", ctypes.c_int)]
 
 
 class _Stats(ctypes.Structure):
@@ -52,7 +52,7 @@ class _Stats(ctypes.Structure):
                 ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int),
                 ("frames_pipelined", ctypes.c_int), ("idr_lookahead", ctypes.c_int), ("depth", ctypes.c_int),
                 ("deblock_streams", ctypes.c_int), ("oversize_frames", ctypes.c_uint64), ("frame_qp", ctypes.c_int),
-                ("requantised_frames", ctypes.c_uint64)]
+                ("requantised_frames", ctypes.c_uint64), ("scene_cuts", ctypes.c_uint64)]
 
 
 _lib = None
@@ -176,6 +176,7 @@ class EncoderConfig:
     mad_th: tuple = (0, 0, 0, 0)       # MAD classes: ascending thresholds on luma SAD / 256 against the chosen prediction
     mad_dqp: tuple = (0, 0, 0, 0, 0)   # ... and the QP offset of each of the five classes (all zero: off)
     pcm: int = 0                # 0: macroblocks that could pass 3200 bits are coded I_PCM (where the session takes it); -1: never
+    scene_cut: int = 0          # 1..100: a P picture whose macroblocks vote for it by this percentage becomes an IDR picture
 
 
 class CedarEncoder:
@@ -204,7 +205,7 @@ class CedarEncoder:
         x.size = ctypes.sizeof(_ConfigExt)
         for n in ("device", "n_streams", "slice_count", "slice_first", "slice_num", "search_range",
                   "chroma_qp_offset_minus4", "repeat_headers", "aud", "fps_num", "fps_den", "first_frame_index",
-                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "pcm"):
+                  "gop_parallel", "strict_mb_bits", "subpel", "gop_low_latency", "bitrate", "intra_refresh", "pcm", "scene_cut"):
             setattr(x, n, getattr(cfg, n))
         if len(cfg.roi) > 4:
             raise EncoderError(22, "at most 4 regions of interest")
@@ -302,7 +303,7 @@ class CedarEncoder:
         return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms, "wf_split": s.wf_split,
                 "deblock_planes_split": bool(s.deblock_planes_split),
                 "frames_pipelined": bool(s.frames_pipelined), "idr_lookahead": bool(s.idr_lookahead),
-                "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames, "frame_qp": s.frame_qp, "requantised_frames": s.requantised_frames,
+                "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames, "frame_qp": s.frame_qp, "requantised_frames": s.requantised_frames, "scene_cuts": s.scene_cuts,
                 "ms": {n: s.ms[i] for i, n in enumerate(STAGES)},
                 "launches": {n: s.launches[i] for i, n in enumerate(STAGES)}}
 

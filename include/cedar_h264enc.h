@@ -166,6 +166,14 @@ struct cedar_enc_config_ext {
 				QP_Y 0 for the deblocking filter -- are not filtered at all: up to 22 with the
 				reference's chroma offset (noise passes 3200 bits up to QP 16). Elsewhere, and with
 				-1 (never), strict_mb_bits says what happens                                       */
+	int scene_cut;       /* 1..100: a P picture in which at least this percentage of the macroblocks is predicted
+				better by its own mean than by the best vector (SAD against the mean + 32 lambda
+				< the search's cost) is coded as an IDR picture instead and starts a new GOP
+				there -- what a scene cut wants is the I-picture path, all modes, for that
+				picture (the VE's MEPARA / PARA0, cedar.c:1155-1171, leave intra-in-P to
+				silicon). The analysis reports the count with the frame; the session codes the
+				frame again as an IDR picture, and the frames in flight behind it after it (the
+				machinery of a failed frame). One stream, whole pictures, no gop_parallel. 0: off   */
 };
 
 typedef struct cedar_enc cedar_enc;
@@ -265,6 +273,7 @@ struct cedar_enc_stats {
 	uint64_t oversize_frames;                /* frames with a macroblock above 3200 bits (A.3.1)   */
 	int      frame_qp;                       /* slice QP of the frame collected last (rate control; of stream 0 when several streams are steered) */
 	uint64_t requantised_frames;             /* re-encodes because of a macroblock above 3200 bits  */
+	uint64_t scene_cuts;                     /* P pictures coded again as IDR pictures (scene_cut)  */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */

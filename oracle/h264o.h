@@ -71,6 +71,9 @@ typedef struct h264o_config {
 	                       * difference against its chosen prediction (luma SAD / 256) ... */
 	int mad_dqp[5];       /* ... and the QP offset (-12..12) of each of the five classes, on top of the picture's QP and
 	                       * the region's. All zero: off */
+	int scene_cut;        /* 1..100: a P picture in which at least this percentage of the macroblocks is better predicted by
+	                       * its own mean than by the best vector (SAD against the mean + 32 lambda < the search's cost) is
+	                       * coded as an IDR picture instead and starts a new GOP there; 0: off. One stream, whole pictures */
 	int pcm;              /* 0 (default): a macroblock whose macroblock_layer() could pass the 3200 bits of H.264 A.3.1 is
 	                       * coded I_PCM -- its source samples, raw -- in the sessions that take it (one QP per picture of
 	                       * at most 30, no cyclic refresh: DESIGN.md 3.6); -1: never, strict_mb_bits says what happens */

@@ -36,6 +36,8 @@ struct h264o_enc {
 	int cur; /* index of reference_current (cedar.c:117-119) */
 	h264o_mb *mbs;
 	int last_idr;
+	int idr_count;   /* IDR pictures coded so far (cfg.scene_cut: idr_pic_id alternates with it) */
+	int cut_votes;   /* cfg.scene_cut: macroblocks of the P picture being analysed that their own mean predicts better */
 	int qp;          /* slice QP of the frame being coded: cfg.qp, or what the rate control picks */
 	int mbqp;        /* QP of the macroblock being analysed: qp + the offset of its region of interest (+ its MAD class) */
 	int mad_on;      /* cfg.mad_dqp has a non-zero entry */
@@ -1454,6 +1456,20 @@ static void inter_mb(h264o_enc *e, int mx, int my, int row0, int row1)
 		}
 		best_of_refine = best;
 	}
+	/* scene cuts (cfg.scene_cut): does the macroblock's own mean predict it better than the best vector? */
+	if (e->cfg.scene_cut > 0) {
+		int sum = 0, sadm = 0, mean, x, y;
+
+		for (y = 0; y < 16; y++)
+			for (x = 0; x < 16; x++)
+				sum += e->src_y[(y0 + y) * stride + x0 + x];
+		mean = (sum + 128) >> 8;
+		for (y = 0; y < 16; y++)
+			for (x = 0; x < 16; x++)
+				sadm += abs(e->src_y[(y0 + y) * stride + x0 + x] - mean);
+		if (sadm + 32 * lam < best_of_refine)
+			e->cut_votes++;
+	}
 	/* the SAD of the chosen prediction = its cost without the vector's share */
 	mad_qp(e, mx, my, (int)(best_of_refine - lam * (mv_bits_q(qx) + mv_bits_q(qy))));
 	mb->type = H264O_MB_P16x16;
@@ -2065,6 +2081,8 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 			return NULL;
 	if (cfg->intra_refresh < 0 || (cfg->intra_refresh > 0 && cfg->intra_refresh < 3) || cfg->intra_refresh > 65535)
 		return NULL;
+	if (cfg->scene_cut < 0 || cfg->scene_cut > 100 || cfg->pcm < -1 || cfg->pcm > 0)
+		return NULL;
 	if (cfg->search_range < 0 || cfg->search_range > 16)
 		return NULL;
 	if (cfg->slice_count < 1 || cfg->slice_count > ALIGN16(cfg->height) / 16)
@@ -2208,11 +2226,19 @@ static void pad_source(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma)
 int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8_t *out, int out_cap)
 {
 	int max_mb_bits = 0, ue_bits_of_run = 0;
-	int idr = e->frame_p_count == 0; /* cedar.c:1047-1050 */
-	int o = 0, o_hdr, s, mx, my, r;
-	int idr_pic_id = (e->frame_count / e->cfg.keyint) & 1;
+	int idr, forced_idr = 0;
+	int o, o_hdr, s, mx, my, r;
+	int idr_pic_id;
 
 	pad_source(e, luma, chroma);
+restart: /* cfg.scene_cut: the analysis of a P picture may ask for an IDR picture instead */
+	if (forced_idr)
+		e->frame_p_count = 0; /* a new GOP starts here */
+	idr = e->frame_p_count == 0; /* cedar.c:1047-1050 */
+	/* (two IDR pictures in a row must differ in idr_pic_id: by the GOP's number on the regular cadence, by the
+	 * count of IDR pictures where cuts put them anywhere) */
+	idr_pic_id = (e->cfg.scene_cut > 0 ? e->idr_count : e->frame_count / e->cfg.keyint) & 1;
+	o = 0;
 
 	if (e->cfg.aud) {
 		r = h264o_write_aud(idr, out + o, out_cap - o);
@@ -2242,6 +2268,7 @@ int h264o_encode(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma, uint8
 again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is coded again, 6 QP steps coarser */
 	o = o_hdr;
 	max_mb_bits = 0;
+	e->cut_votes = 0;
 	/* regions of interest: the first one that covers a macroblock moves its QP */
 	for (my = 0; my < e->mb_h; my++)
 		for (mx = 0; mx < e->mb_w; mx++) {
@@ -2333,6 +2360,11 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 						mb->type = H264O_MB_PSKIP;
 				}
 		}
+	}
+
+	if (!idr && e->cfg.scene_cut > 0 && e->cut_votes * 100 >= e->cfg.scene_cut * e->mb_w * e->mb_h) {
+		forced_idr = 1;
+		goto restart;
 	}
 
 	/* QP_Y as the decoder will hold it: only a macroblock with an mb_qp_delta (Intra16x16, or any coded
@@ -2429,6 +2461,8 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 	/* cedar.c:1193-1201 */
 	e->max_mb_bits = max_mb_bits;
 	e->last_idr = idr;
+	if (idr)
+		e->idr_count++;
 	e->frame_p_count++;
 	if (e->frame_p_count == e->cfg.keyint)
 		e->frame_p_count = 0;

@@ -129,6 +129,38 @@ def test_macroblocks_that_could_pass_3200_bits_are_coded_i_pcm(ce, w, h, qp, key
             assert _encode_pipelined(ge, [src[f][0] for f in range(frames)]) == want[0]
 
 
+@pytest.mark.parametrize("w,h,qp,keyint,before,after,cuts,kw", [
+    (320, 240, 30, 25, "B", "A", (5,), {}), (320, 240, 30, 25, "A", "B", (1, 9), {}), (640, 368, 28, 6, "B", "A", (7,), dict(subpel=2)),
+    (320, 240, 30, 25, "A", "B", (3,), dict(slice_count=2)), (1920, 1080, 24, 25, "B", "A", (4,), {}), (320, 240, 28, 25, "B", "C", (2,), {})])
+def test_scene_cuts_become_idr_pictures_like_the_oracles(ce, w, h, qp, keyint, before, after, cuts, kw):
+    """cedar_enc_config_ext.scene_cut: k_inter counts the macroblocks of a P picture that their own mean predicts better
+    than the best vector, k_copy_out reports the count with the frame, and collect codes the picture again as an IDR
+    picture that starts a new GOP -- the frames in flight behind it after it (the replay of a failed frame). Bytes equal
+    the scalar twin's, synchronous and with the ring full; cuts right after an IDR picture and across a GOP boundary."""
+    n = max(cuts) + ce.load_library().cedar_enc_pipeline_depth() + 4
+    def pat(f):
+        k = sum(1 for c in cuts if f >= c)
+        return (before, after)[k & 1]
+    frames = [ol.gen_frame(pat(f), w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, scene_cut=50, **kw))
+    want, n_cut = [], 0
+    for f, (y, uv) in enumerate(frames):
+        want.append(oe.encode(y, uv))
+        n_cut += int(ol.lib().h264o_last_frame_type(oe.h) == 1 and f > 0 and (after == "C" or f in cuts))
+    assert n_cut >= len(cuts)
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, scene_cut=50, **kw) as enc:
+        got = [enc.encode_frame(y, uv) for y, uv in frames[:max(cuts) + 3]]
+        assert got == want[:len(got)]
+        assert enc.stats()["scene_cuts"] >= sum(1 for c in cuts if c < len(got))
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, scene_cut=50, **kw) as enc:
+        assert _encode_pipelined(enc, frames) == want
+        assert enc.stats()["scene_cuts"] >= len(cuts)
+    for bad in (dict(scene_cut=101), dict(scene_cut=50, n_streams=2), dict(scene_cut=50, gop_parallel=2),
+                dict(scene_cut=50, slice_count=2, slice_first=0, slice_num=1)):
+        with pytest.raises(ce.EncoderError):
+            ce.CedarEncoder(width=w, height=h, **bad)
+
+
 def test_randomised_geometries_qps_slices(ce):
     """Seeded sweep over odd shapes: widths/heights that are not multiples of 16, row counts
     that are not multiples of 4 (idle row groups in the wavefront kernels), several slices,
@@ -846,7 +878,7 @@ def test_rate_control_over_several_streams(ce, w, h, S, target, extra):
     okw = {k: (list(v) if k == "roi" else v) for k, v in extra.items()}
     want, qps = [], []
     for s in range(S):
-        oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25, bitrate=target, **okw))
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=25, bitrate=target, pcm=-1, **okw))   # (several steered streams: no I_PCM)
         aus, q = [], []
         for f in range(n):
             aus.append(oe.encode(*src[f][s]))

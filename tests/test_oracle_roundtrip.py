@@ -303,3 +303,48 @@ def test_macroblocks_that_could_pass_3200_bits_are_coded_i_pcm(w, h, qp, keyint,
     assert {"all": n_pcm == n_mb, "some": 0 < n_pcm < n_mb, "none": n_pcm == 0}[want_pcm], (n_pcm, n_mb)
     if want_pcm != "none":
         assert pdec.cover["mb_I_PCM"] == n_pcm and not pdec.level_violations()
+
+
+@pytest.mark.parametrize("w,h,qp,before,after,cut_at,kw", [
+    (320, 240, 30, "B", "A", 5, {}), (320, 240, 30, "A", "B", 5, {}), (320, 240, 28, "B", "C", 3, dict(subpel=2)),
+    (320, 240, 30, "A", "B", 1, dict(slice_count=2)), (160, 96, 24, "B", "A", 7, dict(keyint=8))])
+def test_scene_cuts_become_idr_pictures(w, h, qp, before, after, cut_at, kw):
+    """h264o_config.scene_cut = 50: a P picture half of whose macroblocks are predicted better by their own mean than
+    by the best vector is coded as an IDR picture that starts a new GOP (two IDR pictures in a row still differ in
+    idr_pic_id). At the cut the access unit is smaller and no worse than the P picture it replaces; away from cuts
+    nothing changes; both decoders rebuild every picture."""
+    from tests.indep import h264_refdec as rd
+    n, keyint = cut_at + 5, kw.pop("keyint", 25)
+
+    def run(sc):
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, scene_cut=sc, **kw))
+        dec, pdec = ol.OracleDecoder(), rd.Decoder()
+        aus, idr, err = [], [], []
+        for f in range(n):
+            y, uv = ol.gen_frame(before if f < cut_at else after, w, h, f)
+            au = oe.encode(y, uv)
+            assert dec.decode(au) == 1
+            ry, ruv = oe.recon()
+            dy, duv = dec.picture()
+            assert np.array_equal(ry, dy) and np.array_equal(ruv, duv), f
+            pic, = pdec.decode(au)
+            assert pic.luma_bytes() == ry.tobytes() and pic.nv12_chroma_bytes() == ruv.tobytes(), f
+            aus.append(au)
+            idr.append(ol.lib().h264o_last_frame_type(oe.h))
+            err.append(float(np.mean((ry[:h, :w].astype(np.int64) - y.reshape(h, w)) ** 2)))
+        return aus, idr, err
+
+    plain, idr0, err0 = run(0)
+    cut, idr1, err1 = run(50)
+    assert plain[:cut_at] == cut[:cut_at]                     # nothing changes before the cut
+    assert idr0[cut_at] == 0 and idr1[cut_at] == 1
+    if after == "C":   # noise: the intra picture costs about the same bytes and is a good deal better (finer dead zone)
+        assert len(cut[cut_at]) < 1.05 * len(plain[cut_at]) and err1[cut_at] < 0.8 * err0[cut_at]
+    else:
+        assert len(cut[cut_at]) < len(plain[cut_at]) and err1[cut_at] <= err0[cut_at] * 1.05
+    if after != "C":                                          # (noise: every picture is a cut)
+        want = [int(f == 0 or f == cut_at or (f > cut_at and (f - cut_at) % keyint == 0) or (f < cut_at and f % keyint == 0)) for f in range(n)]
+        assert idr1 == want                                   # the GOP restarts at the cut
+    for bad in (-1, 101):
+        with pytest.raises(Exception):
+            ol.OracleEncoder(ol.default_config(w, h, scene_cut=bad))

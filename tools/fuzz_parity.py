@@ -74,6 +74,8 @@ for case in range(n_cases):
         sr_ = okw.pop("search_range")
         okw["search_range"] = 16 if sr_ == 0 else max(sr_, 0)
         okw["chroma_qp_offset"] = okw.pop("chroma_qp_offset_minus4") + 4
+    if S > 1 and okw.get("bitrate", 0) > 0:
+        okw["pcm"] = -1   # rate control over several lock-step streams: such a session takes no I_PCM (cedar_h264enc.h, pcm)
     oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=keyint, slice_count=slices, **okw)) for _ in range(S)]
     want = [[oes[s].encode(*frames[f][s]) for s in range(S)] for f in range(n)]
     if os.environ.get("FUZZ_WIDE") and slices >= 2 and S == 1 and case % 3 == 0 and not ({"strict_mb_bits", "bitrate"} & set(kw)):
