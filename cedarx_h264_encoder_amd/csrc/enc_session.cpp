@@ -1968,7 +1968,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	// frames back to back: sync words and size words are left zeroed, the completion flags raised, by the kernels
 	// themselves as for pipelined frames (not with cohorts on streams of their own: the last cohort's kernel
 	// would speak for kernels of other streams)
-	const bool self_reset = !pipe && e->batch_self_reset && !e->s_db_c[1] && !e->s_ent_c[1];
+	const bool self_zero = !pipe && e->batch_self_reset;                      // the kernels leave their sync / size words zeroed
+	const bool self_reset = self_zero && !e->s_db_c[1] && !e->s_ent_c[1];     // ... and raise the completion flags too
 	// a held-back tail only waits for the first stripes of a pipelined P picture; anything else: out with it
 	if (e->deferred.active && !(pipe && !idr && C == 1)) {
 		const int rc_f = flush_deferred(e);
@@ -2007,8 +2008,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			// Frames back to back do the same (a memset or a 1-thread kernel that meets a chip full of k_inter
 			// workgroups waits for a CU like everybody else: 32 x 1080p showed the wf_sync memset take 377 us
 			// in front of a deblock kernel). Cohorts follow each other on one stream: the last one's flag says all.
-			Pc.db_self_reset = pipe || self_reset ? 1 : 0;
-			Pc.done_flag = pipe || c == C - 1 ? f.d_done + 1 : nullptr;
+			Pc.db_self_reset = pipe || self_zero ? 1 : 0;
+			Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done + 1 : nullptr;
 			Pc.done_tag = f.done_tag;
 			if (!Pc.db_self_reset && e->wf_split > 1)
 				HIP_TRY(e, hipMemsetAsync(Pc.wf_sync + WF_SYNC_WORDS, 0,
@@ -2128,7 +2129,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_entc);
 		// Pipelined: as few packets on the entropy stream as possible (see launch_deblock): the size
 		// words are left zeroed and the done flag raised by k_copy_out's last workgroup
-		if (!pipe && !self_reset)
+		if (!pipe && !self_zero)
 			HIP_TRY(e, hipMemsetAsync(Pc.stream_size, 0, sizeof(uint32_t) * (Pc.n_streams + 4), s_entc));
 		// macroblocks differ in QP: QP_Y as the decoder will hold it, for the mb_qp_delta of the next one
 		if (Pc.roi_off && Launch::qp_eff(Pc, s_entc))
@@ -2138,7 +2139,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		if (c == C - 1)
 			tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_entc);
 		// (frames back to back: every cohort's k_copy_out leaves its size words zeroed, the last one raises the flag)
-		Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done : self_reset ? e->d_abort_all + 8 : nullptr;
+		Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done : self_zero ? e->d_abort_all + 8 : nullptr;
 		Pc.done_tag = f.done_tag;
 		if (Launch::copy_out(Pc, s_entc, e->dv_out[f.host_out] + (size_t)(S * c / C) * (C > 1 ? e->stream_out_cap : 0),
 				     e->dv_sizes[slot] + (size_t)c * (S + 2)))
