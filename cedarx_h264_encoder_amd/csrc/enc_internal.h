@@ -45,7 +45,7 @@ constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
 constexpr int IR_TRIPLES = 2;     // intra reconstruction: (luma, chroma, mover) wave triples per workgroup, one per band of 4 rows
 constexpr int DB2_XRING = 16;     // deblock: macroblocks of bottom rows a band keeps for the band below (power of two)
 constexpr int WF_MAX_SPLIT = 16;  // workgroups sharing one unit's wavefront
-constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * WF_MAX_SPLIT; // [0] ticket [1] abort [16..] progress
+constexpr int WF_SYNC_WORDS = 16 + MAX_UNITS * 32; // [0] ticket [1] abort [16..] progress: a word per workgroup, [unit][workgroups per unit]
 constexpr int PROG_BANDS = 128;     // deblock bands (4 macroblock rows) per unit with a progress word
 constexpr int PROG_ALL = 0xffff;     // progress value: everything through
 constexpr int INTER_WAVES = 4;       // macroblocks (waves) per k_inter workgroup: a 1080p picture is workgroup-launch bound at 1
@@ -137,11 +137,14 @@ struct Params {
 	// abort flag and per-workgroup progress words (zeroed before every launch),
 	// and the write-through hand-off buffer for the rows crossing a workgroup boundary
 	uint32_t *wf_sync;               // [3][WF_SYNC_WORDS]: region 0 intra_recon, 1 deblock (luma), 2 deblock chroma
-	uint64_t *wf_hbuf;               // [n_units][WF_MAX_SPLIT-1][mb_w][WF_HBUF_GRANULES] deblock
+	uint64_t *wf_hbuf;               // [n_units][wf_hb_slots][mb_w][WF_HBUF_GRANULES] deblock
 	uint64_t *wf_hbuf_intra;         // same shape, intra reconstruction (the two kernels of an IDR picture overlap)
 	int32_t wf_split;                // workgroups per unit: deblock
 	int32_t wf_split_intra;          // workgroups per unit: intra recon
 	int32_t db_pairs;                // filter/mover wave pairs per deblock workgroup: 8 (a whole CU) or 2
+	int32_t wf_hb_slots;             // workgroup boundaries per unit the hand-off buffers have room for
+	int32_t db_rows;                 // deblocking with a wave per macroblock row (k_deblock_rows): a workgroup per band of 4 rows ...
+	int32_t db_bands;                // ... and plane, this many per unit (the bands of the session's tallest slice)
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
 	// picture along diagonals (absolute macroblock coordinates), so progress is counted in
 	// diagonals: "every macroblock with s < D is through" -- s = x + y for the deblock kernel and
@@ -228,6 +231,8 @@ struct Launch {
 	static int deblock(const Params &p, void *stream, int planes); // 1 luma, 2 chroma, 3 both
 	static int entropy(const Params &p, void *stream); // cavlc, scan, pack, escape
 };
+
+int launch_deblock_rows(const Params &p, void *stream); // enc_k_deblock.hip (Launch::deblock when Params::db_rows)
 
 // host-built table for the 4x4 intra predictors: entry = kind<<4 | k
 // kind 0 copy E[k], 1 (E[k]+E[k+1]+1)>>1, 2 (E[k-1]+2E[k]+E[k+1]+2)>>2, 3 DC

@@ -1,0 +1,705 @@
+// cedarx_h264_encoder_amd/csrc/enc_k_deblock.hip
+// k_deblock_rows: the in-loop deblocking filter of clause 8.7 (raster macroblock order semantics) with ONE WAVE PER
+// MACROBLOCK ROW. The dependency chain of deblocking is (x, y) <- (x-1, y), (x, y-1), (x+1, y-1): rows follow each other
+// one macroblock apart, 120 + 68 steps for a 1080p picture whatever the kernel does, so the picture costs what ONE step
+// costs. In k_deblock2_planes (enc_k_wavefront.hip) a step is ~1100 instructions of one wave: a lane filters a whole
+// line of a macroblock, its 4 edges one after the other, and 4 rows share the wave. Here the 4 edges of a line are the 4
+// lanes of a quad:
+//   * bS < 4 changes at most p1, p0, q0, q1 and reads p2 .. q2, so of edge e-1 only q1' reaches edge e (as its p2), and
+//     q1' needs nothing of edge e-2: every lane computes its q1' from the samples as staged, passes it up the quad (DPP),
+//     then every lane finishes its edge. The 4 edges cost one edge and a half.
+//   * bS 4 (macroblock edges of intra macroblocks) changes q2 as well, which is p1 of edge 1: the strong filter runs
+//     first on lane 0 (wave-uniform branch, only where the picture has such edges), lane 1 takes its word from lane 0.
+//   * vertical edges: lane (line l, edge e) holds the 4 samples after its edge as one word, the 4 before it come from
+//     lane e-1 (lane 0: the last columns of the macroblock to the left, final); horizontal edges: lane (column c, edge e),
+//     the same code on words gathered with byte loads.
+// A workgroup is ONE band of 4 macroblock rows on one CU: 4 filter waves (one per row, one per SIMD) and a mover wave
+// that stages samples and edge codes 1 step ahead, has the loads of 3 steps ahead in flight, and writes back 1 step behind
+// (the mover of k_deblock2_planes, 4 rows in its 4 lane groups). Rows inside a band hand their bottom rows on through LDS
+// (`bot`), bands through the write-through hand-off buffer under a progress word, as workgroups of the other kernel do.
+// Luma and chroma are independent given the edge codes: a workgroup filters one plane (chroma: 32 lanes of each wave).
+// Every wait is a bounded spin. Bytes are those of k_deblock2_planes (tests/test_gpu_parity.py runs both).
+//
+// The reference delegates deblocking to silicon (kernel/cedar.c:1135-1153 programs REC/REF/MBINFO addresses, :1176
+// triggers); the policy is the slice header's (cedar.c:1024-1029: idc 0, offsets 0).
+#include <stdlib.h>
+
+#include <hip/hip_runtime.h>
+
+#include "enc_device.h"
+#include "enc_wf_common.h"
+
+namespace cedar {
+
+constexpr int DBR_WAVES = 5; // 4 filter waves + 1 mover
+
+template <int PL>
+struct DbrShared {
+	Db2GroupLds<PL> g[4];
+	int staged;   // steps the mover has staged (step t: macroblock t - g of row g)
+	int vdone[4]; // macroblocks of row g through their vertical edges
+	int filt[4];  // macroblocks of row g filtered
+	int ticket;
+	int abort;        // a wait of this workgroup ran out: stop waiting
+	uint64_t qdb[52]; // MODE 3: per QP alpha, beta, tc0 of bS 1..3, QP_C (one byte each), from the session's table
+};
+
+extern __shared__ __attribute__((aligned(16))) uint8_t dbr_lds[];
+
+// lane e of a quad takes the value of lane e-1 (lane 0: its own) / of lane e+1 (lane 3: its own)
+DEVI uint32_t quad_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x90, 0xf, 0xf, true); }
+DEVI uint32_t quad_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF9, 0xf, 0xf, true); }
+
+// One line of 16 luma samples across its 4 edges, lane e of the quad = edge e. A0: the 4 samples before edge 0 (lane 0
+// only: the neighbouring macroblock's, final); B: the 4 samples after the lane's edge, in line order from byte 0.
+// code: the lane's edge code (0x80 | tc0, 0x40 on top: bS 4; 0: leave the edge alone); al, be: alpha and beta of the
+// lane's edge. SM: 0 no bS 4 in this picture, 1 an IDR picture (a coded edge 0 IS bS 4), 2 bS 4 where the code says so.
+// Returns B after all 4 edges; Aout (lane 0) = A0 after edge 0.
+template <int SM>
+DEVI void edge_quad(uint32_t A0, uint32_t &B, uint32_t &Aout, uint32_t code, int e, int al, int be)
+{
+	const int valid = -(int)((code >> 7) & 1u);
+	int strong = 0;
+	if (SM) {
+		strong = SM == 1 ? (e == 0 ? valid : 0) : -(int)((code >> 6) & 1u);
+		if (__any(strong)) {
+			int p3 = (int)(A0 & 0xffu), p2 = (int)((A0 >> 8) & 0xffu), p1 = (int)((A0 >> 16) & 0xffu), p0 = (int)(A0 >> 24);
+			int q0 = (int)(B & 0xffu), q1 = (int)((B >> 8) & 0xffu), q2 = (int)((B >> 16) & 0xffu), q3 = (int)(B >> 24);
+			filt_luma_s2((uint32_t)strong & 0x80u, 0, al, be, p3, p2, p1, p0, q0, q1, q2, q3);
+			A0 = (uint32_t)p3 | (uint32_t)p2 << 8 | (uint32_t)p1 << 16 | (uint32_t)p0 << 24;
+			B = (uint32_t)q0 | (uint32_t)q1 << 8 | (uint32_t)q2 << 16 | (uint32_t)q3 << 24;
+		}
+	}
+	const uint32_t Bprev = quad_prev(B); // (every lane takes part: not inside the selection)
+	const uint32_t A = e ? Bprev : A0;
+	const int nv = valid & ~strong;
+	const int tc0 = (int)(code & 0x3fu);
+	const int p2 = (int)((A >> 8) & 0xffu), p1 = (int)((A >> 16) & 0xffu), p0 = (int)(A >> 24);
+	const int q0 = (int)(B & 0xffu), q1 = (int)((B >> 8) & 0xffu), q2 = (int)((B >> 16) & 0xffu);
+	const int m = (max(max(sadb(p0, q0, -al), sadb(p1, p0, -be)), sadb(q1, q0, -be)) >> 31) & nv;
+	const int sq = sadb(q2, q0, -be) >> 31;
+	const int tcq = tc0 & sq & m;
+	const int avg = (p0 + q0 + 1) >> 1;
+	const int q1n = q1 + med3i((q2 + avg - (q1 << 1)) >> 1, -tcq, tcq);
+	// p2 of edge e is q1 of edge e-1 AFTER that edge (which took nothing from the edge before it)
+	const int q1prev = (int)quad_prev((uint32_t)q1n);
+	const int p2x = e ? q1prev : p2;
+	const int sp = sadb(p2x, p0, -be) >> 31;
+	const int tc = (tc0 - sp - sq) & m;
+	const int tcp = tc0 & sp & m;
+	const int delta = med3i((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+	const int p1n = p1 + med3i((p2x + avg - (p1 << 1)) >> 1, -tcp, tcp);
+	const int p0n = med3i(p0 + delta, 0, 255), q0n = med3i(q0 - delta, 0, 255);
+	const uint32_t pn = (uint32_t)p1n | (uint32_t)p0n << 8;
+	const uint32_t nx = quad_next(pn); // samples 2, 3 after this edge are p1, p0 of the next
+	const uint32_t hi = e == 3 ? B >> 16 : nx;
+	B = (uint32_t)q0n | (uint32_t)q1n << 8 | hi << 16;
+	Aout = (A0 & 0xffffu) | pn << 16;
+}
+
+// per-lane variant of lds_wait_ge: every lane has a counter of its own to wait for (the mover's 4 lane groups)
+DEVI void lds_wait_ge_lanes(const int *word, int need, const WaitCtx &w)
+{
+	uint64_t t0 = 0;
+	for (int spins = 0; __any(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need); spins++) {
+		if (spins < 2048) {
+			__builtin_amdgcn_s_sleep(0);
+			continue;
+		}
+		if (wait_expired((uint32_t)spins, t0)) {
+			__hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(w.abort_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			xstore32(w.abort_x, 1u);
+			break;
+		}
+		if (__hip_atomic_load(w.abort_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+			break;
+		__builtin_amdgcn_s_sleep(32);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// MODE as in k_deblock2_planes: 0 a P picture of inter macroblocks; 1 an IDR picture; 2 a P picture with intra
+// macroblocks in it; 3 any picture of a session with QPs per macroblock; 4, 5: 0, 1 for pictures that may hold I_PCM
+template <int MODE, int PL>
+DEVI void deblock_rows_body(const Params &p)
+{
+	constexpr bool PCM = MODE >= 4;
+	constexpr int BASE = PCM ? MODE - 4 : MODE;
+	constexpr bool IDR = BASE == 1, MIXED = BASE == 2 || BASE == 3, QPM = BASE == 3;
+	constexpr bool DO_Y = (PL & 1) != 0, DO_C = (PL & 2) != 0;
+	constexpr int SM = IDR ? 1 : MIXED ? 2 : 0;
+
+	DbrShared<PL> &S = *reinterpret_cast<DbrShared<PL> *>(dbr_lds);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool is_mover = wave == 4;
+	const int NB = p.db_bands;
+	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
+	if (threadIdx.x == 0) {
+		S.ticket = (int)atomicAdd(&sync[0], 1u); // bands are taken in the order workgroups start: whoever waits, waits for a resident one
+		S.abort = 0;
+		S.staged = 0;
+	}
+	if (QPM && threadIdx.x < 52) {
+		const QpRow &r = p.qtab[threadIdx.x];
+		S.qdb[threadIdx.x] = (uint64_t)(uint32_t)r.alpha | (uint64_t)(uint32_t)r.beta << 8 | (uint64_t)(uint32_t)r.tc0[0] << 16 |
+				     (uint64_t)(uint32_t)r.tc0[1] << 24 | (uint64_t)(uint32_t)r.tc0[2] << 32 | (uint64_t)(uint32_t)r.qpc << 40;
+	}
+	if (threadIdx.x < 4) {
+		S.vdone[threadIdx.x] = 0;
+		S.filt[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	// a ticket beyond the launch means the sync words were not zero when the kernel started: refuse
+	// to index memory with it (code 32 in the frame's error word) rather than fault
+	if (S.ticket < 0 || S.ticket >= p.n_streams * p.slice_num * NB) {
+		if (threadIdx.x == 0)
+			__hip_atomic_store(p.wf_err, 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		return;
+	}
+	const int unit = S.ticket / NB, band = S.ticket % NB;
+	const int st = unit / p.slice_num, sl = p.slice_first + unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, sl, &r0, &r1);
+	const int nbands = (r1 - r0 + 3) >> 2;
+	if (band >= nbands) // (slices of a picture differ by one row: the launch has the bands of the tallest)
+		return;
+	uint32_t *xprog = sync + 16 + unit * NB; // [band]: macroblocks of the band's last row whose bottom rows are in the hand-off buffer
+	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
+	const WaitCtx xw{xerr, &S.abort, xabort};
+
+	if (!is_mover) {
+		// =========================== filter wave of row g ===========================
+		const int g = wave;
+		const int my = r0 + 4 * band + g;
+		if (my >= r1)
+			return;
+		const bool top_edge = my > r0;
+		Db2GroupLds<PL> &L = S.g[g];
+		const Db2GroupLds<PL> &LU = S.g[g > 0 ? g - 1 : 0];
+		const int e = lane & 3, q4 = lane >> 2; // luma: quad = line (vertical edges) / column (horizontal edges), lane of the quad = edge
+		for (int mx = 0; mx < p.mb_w; mx++) {
+			const int t = mx + g;
+			const bool left_edge = mx > 0;
+			const int slot = t % 3, pslot = (t + 2) % 3;
+			lds_wait_ge(&S.staged, t + 1, xw);
+			// thresholds by edge class: the picture's, or this macroblock's (MODE 3)
+			int ayL = p.alpha_y, byL = p.beta_y, ayT = p.alpha_y, byT = p.beta_y, ayI = p.alpha_y, byI = p.beta_y;
+			int acL = p.alpha_c, bcL = p.beta_c, acT = p.alpha_c, bcT = p.beta_c, acI = p.alpha_c, bcI = p.beta_c;
+			if (QPM) {
+				const u32x4 abw = *(const u32x4 *)L.ab[slot];
+				ayL = abw.x & 0xff; byL = (abw.x >> 8) & 0xff; ayT = (abw.x >> 16) & 0xff; byT = abw.x >> 24;
+				ayI = abw.y & 0xff; byI = (abw.y >> 8) & 0xff;
+				acL = abw.z & 0xff; bcL = (abw.z >> 8) & 0xff; acT = (abw.z >> 16) & 0xff; bcT = abw.z >> 24;
+				acI = abw.w & 0xff; bcI = (abw.w >> 8) & 0xff;
+			}
+			if (DO_Y) {
+				// ---- vertical edges: quad = sample row q4 ----
+				uint8_t *row = L.y[slot] + (4 + q4) * DT_STRIDE + 16;
+				uint32_t B = *(const uint32_t *)(row + 4 * e);
+				const uint32_t A0 = *(const uint32_t *)(L.y[pslot] + (4 + q4) * DT_STRIDE + 28); // (lane 0 of the quad)
+				const uint32_t code = (L.bsv[slot][q4] >> (8 * e)) & 0xffu;
+				uint32_t Aout = A0;
+				if (__any(code & 0x80u)) {
+					edge_quad<SM>(A0, B, Aout, code, e, e ? ayI : ayL, e ? byI : byL);
+					*(uint32_t *)(row + 4 * e) = B;
+				}
+				// the last columns of the macroblock to the left are final now: beside this tile for the write-back,
+				// and into its bottom rows for the row below
+				if (e == 0 && left_edge) {
+					*(uint32_t *)(row - 4) = Aout;
+					if (q4 >= 12)
+						*(uint32_t *)(L.bot[(mx - 1) & 3] + (q4 - 12) * 16 + 12) = Aout;
+				}
+			}
+			if (DO_C && lane < 32) {
+				// ---- vertical chroma edges (x = 0, 4): lane = (row r, edge e2, plane c); nothing passes between them ----
+				const int r = lane >> 2, e2 = (lane >> 1) & 1, c = lane & 1;
+				uint8_t *row = L.c[slot] + (2 + r) * DC_STRIDE + 16;
+				const uint32_t W1 = *(const uint32_t *)(row + 8 * e2);
+				const uint32_t W0 = e2 ? *(const uint32_t *)(row + 4) : *(const uint32_t *)(L.c[pslot] + (2 + r) * DC_STRIDE + 28);
+				const uint32_t code = (L.bsc[slot][c * 8 + r] >> (8 * e2)) & 0xffu;
+				const int p1 = (int)((W0 >> (8 * c)) & 0xffu);
+				int p0 = (int)((W0 >> (16 + 8 * c)) & 0xffu), q0 = (int)((W1 >> (8 * c)) & 0xffu);
+				const int q1 = (int)((W1 >> (16 + 8 * c)) & 0xffu);
+				const int na = e2 ? -acI : -acL, nb = e2 ? -bcI : -bcL;
+				const uint32_t strong = SM == 1 ? (e2 == 0 ? code : 0u) : SM == 2 ? ((code & 0x40u) ? code : 0u) : 0u;
+				if (SM)
+					filt_chroma_s2(strong, 0, na, nb, p1, p0, q0, q1);
+				filt_chroma_n2(code ^ strong, 0, na, nb, p1, p0, q0, q1);
+				if (e2 || left_edge) {
+					row[8 * e2 - 2 + c] = (uint8_t)p0;
+					row[8 * e2 + c] = (uint8_t)q0;
+				}
+				if (e2 == 0 && left_edge) {
+					row[-4 + c] = (uint8_t)p1;
+					if (r >= 6) {
+						uint8_t *bp = L.botc[(mx - 1) & 3] + (r - 6) * 16 + 12;
+						bp[c] = (uint8_t)p1;
+						bp[2 + c] = (uint8_t)p0;
+					}
+				}
+			}
+			lds_signal(&S.vdone[g], mx + 1, lane);
+			// rows above: the row above is through (mx, y-1) and through the vertical edges of (mx+1, y-1), the last
+			// thing to touch the bottom rows of (mx, y-1)
+			if (g > 0) {
+				if (mx + 1 < p.mb_w)
+					lds_wait_ge(&S.vdone[g - 1], mx + 2, xw);
+				else
+					lds_wait_ge(&S.filt[g - 1], mx + 1, xw);
+			} else {
+				WAVE_SYNC();
+			}
+			if (DO_Y) {
+				// ---- horizontal edges: quad = sample column q4; rows above from the row above's bottom rows (row 0 of a
+				// band: staged into the tile by the mover, from the band above) ----
+				uint8_t *col = L.y[slot] + 16 + q4;
+				const uint8_t *tsrc = g > 0 ? LU.bot[mx & 3] + q4 : col;
+				const int tstr = g > 0 ? 16 : DT_STRIDE;
+				const uint32_t code = (L.bsh[slot][q4] >> (8 * e)) & 0xffu;
+				if (__any(code & 0x80u)) {
+					uint8_t *bp = col + (4 + 4 * e) * DT_STRIDE;
+					uint32_t B = (uint32_t)bp[0] | (uint32_t)bp[DT_STRIDE] << 8 | (uint32_t)bp[2 * DT_STRIDE] << 16 | (uint32_t)bp[3 * DT_STRIDE] << 24;
+					const uint32_t A0 = (uint32_t)tsrc[0] | (uint32_t)tsrc[tstr] << 8 | (uint32_t)tsrc[2 * tstr] << 16 | (uint32_t)tsrc[3 * tstr] << 24;
+					uint32_t Aout = A0;
+					edge_quad<SM>(A0, B, Aout, code, e, e ? ayI : ayT, e ? byI : byT);
+					bp[0] = (uint8_t)B;
+					bp[DT_STRIDE] = (uint8_t)(B >> 8);
+					bp[2 * DT_STRIDE] = (uint8_t)(B >> 16);
+					bp[3 * DT_STRIDE] = (uint8_t)(B >> 24);
+					if (e == 0 && top_edge) {
+						col[0] = (uint8_t)Aout;
+						col[DT_STRIDE] = (uint8_t)(Aout >> 8);
+						col[2 * DT_STRIDE] = (uint8_t)(Aout >> 16);
+						col[3 * DT_STRIDE] = (uint8_t)(Aout >> 24);
+					}
+				} else if (g > 0 && top_edge && lane < 4) {
+					// nothing to filter: the rows above still go into the tile, which is where the write-back takes them
+					*(u32x4 *)(L.y[slot] + lane * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 3] + lane * 16);
+				}
+			}
+			if (DO_C && lane < 32) {
+				// ---- horizontal chroma edges (y = 0, 4): lane = (byte column b, edge e2) ----
+				const int b = lane >> 1, e2 = lane & 1;
+				uint8_t *col = L.c[slot] + 16 + b;
+				const uint8_t *pa = e2 ? col + 4 * DC_STRIDE : g > 0 ? LU.botc[mx & 3] + b : col;
+				const int ps = e2 || g == 0 ? DC_STRIDE : 16;
+				uint8_t *qa = col + (2 + 4 * e2) * DC_STRIDE;
+				const uint32_t code = (L.bsc[slot][b] >> (16 + 8 * e2)) & 0xffu;
+				const int p1 = pa[0];
+				int p0 = pa[ps], q0 = qa[0];
+				const int q1 = qa[DC_STRIDE];
+				const int na = e2 ? -acI : -acT, nb = e2 ? -bcI : -bcT;
+				const uint32_t strong = SM == 1 ? (e2 == 0 ? code : 0u) : SM == 2 ? ((code & 0x40u) ? code : 0u) : 0u;
+				if (SM)
+					filt_chroma_s2(strong, 0, na, nb, p1, p0, q0, q1);
+				filt_chroma_n2(code ^ strong, 0, na, nb, p1, p0, q0, q1);
+				if (e2 || top_edge) {
+					qa[0] = (uint8_t)q0;
+					qa[-DC_STRIDE] = (uint8_t)p0; // (edge 0: tile row 1, the last row above)
+				}
+				if (e2 == 0 && top_edge)
+					col[0] = (uint8_t)p1;
+			}
+			WAVE_SYNC();
+			// bottom rows for the row below (its last columns are patched by the next macroblock's vertical edges)
+			if (DO_Y && lane < 4)
+				*(u32x4 *)(L.bot[mx & 3] + lane * 16) = *(const u32x4 *)(L.y[slot] + (16 + lane) * DT_STRIDE + 16);
+			if (DO_C && lane < 2)
+				*(u32x4 *)(L.botc[mx & 3] + lane * 16) = *(const u32x4 *)(L.c[slot] + (8 + lane) * DC_STRIDE + 16);
+			lds_signal(&S.filt[g], mx + 1, lane);
+		}
+		return;
+	}
+
+	// ============================== mover wave ==============================
+	// (the mover of k_deblock2_planes: its 4 lane groups are the 4 rows of the band, at step t group g is at macroblock
+	// t - g; see there for the frame pipelining and the two ways of counting progress)
+	const int g = lane >> 4, l = lane & 15;
+	const int my = r0 + 4 * band + g;
+	const bool row_ok = my < r1;
+	const bool top_edge = my > r0;
+	Db2GroupLds<PL> &L = S.g[g];
+	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
+	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
+	const int nsteps = p.mb_w + 3;
+	const bool feeds_next = g == 3 && band + 1 < nbands; // its last 4 rows are stored by whoever filters below
+	const bool xwg_band = band > 0;
+	const bool xwg_top = g == 0 && xwg_band;
+	const bool is_xprod = feeds_next;
+	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
+	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
+	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + band) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + (band > 0 ? band - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint32_t xseen = 0;
+	const int y0b = r0 + 4 * band;
+	const int diag0 = 2 * y0b;
+	uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
+	uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
+	auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
+		const bool idr_pic = IDR || (QPM && p.is_idr); // (mode 3 serves the IDR pictures of its sessions too)
+		const uint32_t need = idr_pic ? (uint32_t)(t + 3 + diag0 + 4)  // x + 2*y: group 3 is 3 diagonals ahead of group 0
+					      : (uint32_t)(t + y0b + 1);       // x + y: all four rows are on t + y0
+		if (inter_seen >= need)
+			return;
+		const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
+		if (idr_pic && p.prog_intra) { // the band itself, the one above (top rows) and the one below (its consumers)
+			w0 = p.prog_intra + unit * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1);
+			w1 = band > 0 ? w0 - 1 : w0;
+			w2 = band + 1 < nbands && band + 1 < PROG_BANDS ? w0 + 1 : w0;
+		}
+		uint32_t spins = 0;
+		uint64_t t0 = 0;
+		while (true) {
+			const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t want = p.prog_tag | need;
+			if ((int32_t)(v0 - want) >= 0 && (int32_t)(v1 - want) >= 0 && (int32_t)(v2 - want) >= 0) {
+				const uint32_t a = v0 & 0xffffu, b = v1 & 0xffffu, c = v2 & 0xffffu;
+				inter_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
+				break;
+			}
+			if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+				__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				inter_seen = 0x7fffffffu;
+				break;
+			}
+			if (spins < 8)
+				__builtin_amdgcn_s_sleep(16);
+			else
+				__builtin_amdgcn_s_sleep(127);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	};
+	auto publish_diag = [&](uint32_t d) { // every macroblock of this band with x + y < d is written back
+		if (!my_prog)
+			return;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (lane == 0)
+			__hip_atomic_store(my_prog, p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
+	struct MoverRegs {
+		u32x4 in, c;
+		uint64_t topx;
+		uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
+		uint32_t ty, tyt; // MIXED: its first dword (type in the low byte)
+		uint8_t qc, qt;   // MODE 3: QP the macroblock, and the one above it, is quantised with (qp_t)
+		uint8_t nz, nzt;
+		bool top_ok;
+	};
+	MoverRegs RA{}, RB{};
+	uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
+	int mvl = 0;
+	bool intra_left = false, pcm_left = false;
+	int eff_left = 0, teff_left = 0; // MODE 3: QP_Y the decoder holds for the macroblock staged last, and for the one above that
+	int pending_x = -1;
+
+	auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t
+		const int nmx = t - g, mx0 = t;
+		const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
+		const int cmx = nact ? nmx : 0;
+		const size_t a = row_mb + cmx;
+		const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
+		if (t < nsteps)
+			wait_analysis(t);
+		// readiness of the rows above first: its acquire must not sit behind this step's own loads
+		R.top_ok = true;
+		if (xwg_band && mx0 < p.mb_w) { // rows above come from the band above, another workgroup
+			const uint32_t need = (uint32_t)mx0 + 1u;
+			if (xseen < need)
+				xseen = xload32(&xprog[band - 1]);
+			if (xseen < need && block)
+				xseen = xwait(&xprog[band - 1], xabort, xerr, need);
+			R.top_ok = xseen >= need;
+		}
+		if (DO_Y)
+			R.in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
+		if (DO_C)
+			R.c = *(const u32x4 *)(rec_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
+		if (!IDR) {
+			R.mv = ((const uint32_t *)&p.mbi[a])[1];
+			R.nz = p.nnz[a * NNZ_PER_MB + l];
+			const size_t at = (top_edge && row_ok) ? a - p.mb_w : a;
+			R.mvt = ((const uint32_t *)&p.mbi[at])[1];
+			R.nzt = p.nnz[at * NNZ_PER_MB + l];
+			if (MIXED) {
+				R.ty = ((const uint32_t *)&p.mbi[a])[0];
+				R.tyt = ((const uint32_t *)&p.mbi[at])[0];
+			}
+			if (QPM) {
+				R.qc = p.qp_t[a];
+				R.qt = p.qp_t[at];
+			}
+		}
+		if (PCM) { // pictures that may hold I_PCM macroblocks: the types of this macroblock and the one above
+			R.ty = ((const uint32_t *)&p.mbi[a])[0];
+			R.tyt = ((const uint32_t *)&p.mbi[(top_edge && row_ok) ? a - p.mb_w : a])[0];
+		}
+		if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
+			R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
+	};
+
+	auto stage_step = [&](int t, const MoverRegs &R) { // registers -> tile slot t%3 + edge codes
+		const int mx = t - g;
+		const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+		const bool left_edge = mx > 0;
+		const int slot = t % 3;
+		uint32_t nz_cur = 0, nz_top = 0;
+		int mvc = 0, mvt = 0;
+		if (!IDR) {
+			const uint64_t bal_c = __ballot(act && R.nz != 0), bal_t = __ballot(act && top_edge && R.nzt != 0);
+			nz_cur = (uint32_t)(bal_c >> (16 * g)) & 0xffffu;
+			nz_top = (uint32_t)(bal_t >> (16 * g)) & 0xffffu;
+			mvc = (int)R.mv;
+			mvt = (int)R.mvt;
+		}
+		uint32_t wv = 0, wh = 0, wc = 0;
+		if (act) {
+			if (DO_Y)
+				*(u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16) = R.in;
+			if (DO_C && l < 8)
+				*(u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16) = R.c;
+			if (xwg_top) { // rows above from the band above (inside a band the filter waves fetch them)
+				if (DO_Y && l < 8)
+					*(uint64_t *)(L.y[slot] + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = R.topx;
+				else if (DO_C && l >= 8 && l < 12)
+					*(uint64_t *)(L.c[slot] + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = R.topx;
+			}
+			if (IDR) { // all intra: bS 4 (strong) on macroblock edges, 3 inside
+				const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
+				wv = in_y | (left_edge ? 0x80u : 0u);
+				wh = in_y | (top_edge ? 0x80u : 0u);
+				wc = (left_edge ? 0x80u : 0u) | in_c << 8 | (top_edge ? 0x80u : 0u) << 16 | in_c << 24;
+			} else {
+				// edge code by strength for the macroblock's left edge, top edge, inner edges (MODE 3: its own tc0)
+				uint32_t cyL = cod_y, cyT = cod_y, cyI = cod_y, ccL = cod_c, ccT = cod_c, ccI = cod_c;
+				if (QPM) {
+					// QP_Y as the decoder holds it: a macroblock without mb_qp_delta keeps that of the one before it in
+					// its row; thresholds from the mean across a macroblock edge (8.7.2.2), per plane
+					auto coded = [](uint32_t w0) { return (int)(int8_t)(w0 & 0xffu) == MB_I16x16 || ((w0 >> 24) & 0x3fu) != 0; };
+					const int eff = (mx == 0 || coded(R.ty)) ? (int)R.qc : eff_left;
+					const int teff = (mx == 0 || coded(R.tyt)) ? (int)R.qt : teff_left;
+					auto qpc_of = [&](int q) { return (int)((S.qdb[q] >> 40) & 0xffu); };
+					const int ce = qpc_of(eff);
+					const uint64_t yL = S.qdb[(eff_left + eff + 1) >> 1], yT = S.qdb[(teff + eff + 1) >> 1], yI = S.qdb[eff];
+					const uint64_t cL = S.qdb[(qpc_of(eff_left) + ce + 1) >> 1], cT = S.qdb[(qpc_of(teff) + ce + 1) >> 1], cI = S.qdb[ce];
+					auto code3 = [](uint64_t r) { // tc0 of bS 1..3 -> edge codes 0x80 | tc0 in bytes 1..3
+						return (uint32_t)((r >> 8) & 0xffffff00ull) | 0x80808000u;
+					};
+					cyL = code3(yL); cyT = code3(yT); cyI = code3(yI);
+					ccL = code3(cL); ccT = code3(cT); ccI = code3(cI);
+					if (l == 0)
+						*(u32x4 *)L.ab[slot] = u32x4{ (uint32_t)(yL & 0xffffu) | (uint32_t)(yT & 0xffffu) << 16, (uint32_t)(yI & 0xffffu),
+									      (uint32_t)(cL & 0xffffu) | (uint32_t)(cT & 0xffffu) << 16, (uint32_t)(cI & 0xffffu) };
+					eff_left = eff;
+					teff_left = teff;
+				}
+				const int k = l >> 2, ks = (l & 7) >> 1;
+				int bv[4], bh[4];
+				// vectors are in quarter samples: bS 1 from a difference of a whole sample on (8.7.2.1)
+				const int mvd_l = mv_far(mvc, mvl), mvd_t = mv_far(mvc, mvt);
+				const int nzv0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
+				bv[0] = (2 * nzv0 + ((1 - nzv0) & mvd_l)) & -(int)left_edge;
+				const int nzh0 = (int)(((nz_cur >> k) | (nz_top >> (12 + k))) & 1u);
+				bh[0] = (2 * nzh0 + ((1 - nzh0) & mvd_t)) & -(int)top_edge;
+#pragma unroll
+				for (int e = 1; e < 4; e++) {
+					bv[e] = 2 * (int)(((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1u);
+					bh[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
+				}
+				const int nzc0 = (int)(((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1u);
+				const int bsc0 = (2 * nzc0 + ((1 - nzc0) & mvd_l)) & -(int)left_edge;
+				const int bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					wv |= (((e == 0 ? cyL : cyI) >> (8 * bv[e])) & 0xffu) << (8 * e);
+					wh |= (((e == 0 ? cyT : cyI) >> (8 * bh[e])) & 0xffu) << (8 * e);
+				}
+				wc = ((ccL >> (8 * bsc0)) & 0xffu) | ((ccI >> (8 * bsc2)) & 0xffu) << 8 |
+				     ((ccT >> (8 * bh[0])) & 0xffu) << 16 | ((ccI >> (8 * bh[2])) & 0xffu) << 24;
+				if (MIXED) { // an intra macroblock on either side: bS 4 on the macroblock edge (code 0xC0), 3 inside
+					const bool ic = (int)(int8_t)(R.ty & 0xffu) < MB_P16x16, it = (int)(int8_t)(R.tyt & 0xffu) < MB_P16x16;
+					if (ic) {
+						const uint32_t in_y = (cyI >> 24) * 0x01010100u, in_c = ccI >> 24;
+						wv = (wv & 0xffu) | in_y;
+						wh = (wh & 0xffu) | in_y;
+						wc = (wc & 0x00ff00ffu) | in_c << 8 | in_c << 24;
+					}
+					if (left_edge && (ic || intra_left)) {
+						wv = (wv & ~0xffu) | 0xC0u;
+						wc = (wc & ~0xffu) | 0xC0u;
+					}
+					if (top_edge && (ic || it)) {
+						wh = (wh & ~0xffu) | 0xC0u;
+						wc = (wc & ~0xff0000u) | 0xC00000u;
+					}
+					intra_left = ic;
+				}
+			}
+			if (PCM) {
+				// I_PCM (only pictures at whose QP no edge of such a macroblock is filtered at all): its own edges, inner
+				// ones included, and its neighbours' edges towards it are left alone
+				const bool pc = (int)(int8_t)(R.ty & 0xffu) == MB_IPCM, pt = top_edge && (int)(int8_t)(R.tyt & 0xffu) == MB_IPCM;
+				if (pc)
+					wv = wh = wc = 0;
+				if (pcm_left) {
+					wv &= ~0xffu;
+					wc &= ~0xffu;
+				}
+				if (pt) {
+					wh &= ~0xffu;
+					wc &= ~0xff0000u;
+				}
+				pcm_left = pc;
+			}
+			nz_left = nz_cur;
+			mvl = mvc;
+		}
+		if (DO_Y) {
+			L.bsv[slot][l] = wv;
+			L.bsh[slot][l] = wh;
+		}
+		if (DO_C)
+			L.bsc[slot][l] = wc;
+	};
+
+	auto writeback_step = [&](int t) { // filtered tile of step t -> memory, next band
+		const int mx = t - g;
+		const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+		const bool left_edge = mx > 0;
+		const int slot = t % 3;
+		const int x0 = mx * 16, y0 = my * 16;
+		if (!act)
+			return;
+		if (DO_Y && !(feeds_next && l >= 12)) {
+			*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
+			if (left_edge)
+				*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+		}
+		if (DO_C && l < 8 && !(feeds_next && l >= 6)) {
+			*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
+			if (left_edge)
+				*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+		}
+		if (top_edge) {
+			if (DO_Y && l < 4)
+				*(u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + l * DT_STRIDE + 16);
+			else if (DO_C && l >= 4 && l < 6)
+				*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16);
+		}
+		if (is_xprod) {
+			const bool my_gran = (DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES);
+			if (left_edge && my_gran) {
+				const uint8_t *src = l < 8 ? L.bot[(mx - 1) & 3] + (l >> 1) * 16 + (l & 1) * 8
+							   : L.botc[(mx - 1) & 3] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
+				xstore64(hb_out + (size_t)(mx - 1) * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+			}
+			if (mx == p.mb_w - 1 && my_gran) {
+				const uint8_t *src = l < 8 ? L.bot[mx & 3] + (l >> 1) * 16 + (l & 1) * 8
+							   : L.botc[mx & 3] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
+				xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+			}
+			pending_x = mx == p.mb_w - 1 ? p.mb_w : mx;
+		}
+	};
+
+	auto publish = [&]() { // everything issued an iteration ago has completed by now
+		if (band + 1 < nbands) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (is_xprod && l == 0 && pending_x >= 0)
+				xstore32(&xprog[band], (uint32_t)pending_x);
+			pending_x = -1;
+		}
+	};
+
+	auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
+		if (t >= 1) { // every row has filtered its macroblock of step t-1
+			const int done = t - g;
+			lds_wait_ge_lanes(&S.filt[g], row_ok ? (done < 0 ? 0 : done > p.mb_w ? p.mb_w : done) : 0, xw);
+		}
+		publish();
+		if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
+			publish_diag((uint32_t)(t - 1 + y0b)); // every macroblock of the band with x + y < that
+		if (t + 1 < nsteps) {
+			if (!R.top_ok)
+				load_step(t + 1, true, R);
+			stage_step(t + 1, R);
+			// fault injection (tests): from step 8 of the first band on, this mover stops reporting
+			const bool lost = p.fault_inject == 1 && unit == 0 && band == 0 && t >= 8;
+			lds_signal(&S.staged, lost ? 1 : t + 2, lane);
+			load_step(t + 3, false, R); // may wait for this frame's analysis: after the filter waves have their tiles
+		}
+		if (t >= 1)
+			writeback_step(t - 1);
+	};
+	// prologue: step 0 staged, loads of steps 1 and 2 in flight
+	load_step(0, true, RA);
+	load_step(1, false, RB);
+	stage_step(0, RA);
+	load_step(2, false, RA);
+	lds_signal(&S.staged, 1, lane);
+	for (int t = 0; t <= nsteps; t += 2) {
+		mover_iter(t, RB);
+		if (t + 1 <= nsteps)
+			mover_iter(t + 1, RA);
+	}
+	publish();
+	publish_diag((uint32_t)PROG_ALL);
+}
+
+// grid: the luma bands of every unit, then the chroma bands (db_bands workgroups per unit and plane)
+template <int MODE>
+__global__ __launch_bounds__(64 * DBR_WAVES) void k_deblock_rows(Params p)
+{
+	const int nwg = p.n_streams * p.slice_num * p.db_bands;
+	if ((int)blockIdx.x < nwg)
+		deblock_rows_body<MODE, 1>(p);
+	else
+		deblock_rows_body<MODE, 2>(p);
+	if (!p.db_self_reset)
+		return;
+	// Epilogue as in k_deblock2_planes: the last workgroup to get here leaves the sync words of both deblock regions
+	// zeroed for the next frame that uses this slot and tells the host that the frame is deblocked.
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t *r1 = p.wf_sync + WF_SYNC_WORDS, *r2 = p.wf_sync + 2 * WF_SYNC_WORDS;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (__hip_atomic_fetch_add(&r1[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			const int used = 16 + p.n_streams * p.slice_num * p.db_bands;
+			for (int i = 0; i < used; i++) {
+				xstore32(&r1[i], 0u);
+				xstore32(&r2[i], 0u);
+			}
+			if (p.done_flag)
+				__hip_atomic_store(p.done_flag, p.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
+int launch_deblock_rows(const Params &p, void *stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	const size_t lds = sizeof(DbrShared<1>) > sizeof(DbrShared<2>) ? sizeof(DbrShared<1>) : sizeof(DbrShared<2>);
+	const dim3 grid((unsigned)(2 * p.n_streams * p.slice_num * p.db_bands)), block(64 * DBR_WAVES);
+	if (p.roi_off) // regions of interest: thresholds per macroblock; an IDR picture is "every macroblock intra" there
+		hipLaunchKernelGGL((k_deblock_rows<3>), grid, block, lds, s, p);
+	else if (p.pcm && p.is_idr)
+		hipLaunchKernelGGL((k_deblock_rows<5>), grid, block, lds, s, p);
+	else if (p.pcm)
+		hipLaunchKernelGGL((k_deblock_rows<4>), grid, block, lds, s, p);
+	else if (p.is_idr)
+		hipLaunchKernelGGL((k_deblock_rows<1>), grid, block, lds, s, p);
+	else if (p.intra_refresh > 0) // intra macroblocks among the inter ones: both sets of boundary strengths
+		hipLaunchKernelGGL((k_deblock_rows<2>), grid, block, lds, s, p);
+	else
+		hipLaunchKernelGGL((k_deblock_rows<0>), grid, block, lds, s, p);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+} // namespace cedar

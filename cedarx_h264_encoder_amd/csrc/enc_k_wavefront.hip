@@ -21,48 +21,10 @@
 #include <hip/hip_runtime.h>
 
 #include "enc_device.h"
+#include "enc_wf_common.h"
 
 namespace cedar {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// intra-wave hand-off through LDS only: order LDS accesses, leave global loads
-// and stores in flight (a plain fence would drain them with vmcnt(0))
-#define WAVE_SYNC()                                                            \
-	do {                                                                   \
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
-		__builtin_amdgcn_wave_barrier();                               \
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
-	} while (0)
-
-// ---- hand-off between the workgroups (CUs) that share one unit's wavefront ----
-// Producer: payload as 8-byte write-through (agent-scope relaxed atomic = sc1)
-// stores, every storing wave drains with s_waitcnt vmcnt(0), then ONE lane stores
-// the progress word. Consumer: relaxed agent-scope poll of that ONE word, then
-// sc1 loads of the payload (cdna guide G16, form R1, first row of the validity
-// table). Spins are bounded: a time-out raises the abort word, which every waiter
-// checks, and flags the frame as failed instead of hanging the GPU.
-DEVI uint32_t xload32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVI void xstore32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVI uint64_t xload64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVI void xstore64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// wave-uniform: wait until *word >= need; returns the value seen (or a huge one after abort)
-DEVI uint32_t xwait(const uint32_t *word, uint32_t *abort_word, uint32_t *err_word, uint32_t need)
-{
-	uint32_t v = xload32(word), spins = 0;
-	uint64_t t0 = 0;
-	while (v < need) {
-		if (wait_expired(++spins, t0) || xload32(abort_word)) {
-			xstore32(abort_word, 1u);
-			__hip_atomic_store(err_word, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			return 0x7fffffffu;
-		}
-		__builtin_amdgcn_s_sleep(8);
-		v = xload32(word);
-	}
-	return v;
-}
 
 
 // 4x4 Hadamard sign H[i][a] for rows (1,1,1,1) (1,1,-1,-1) (1,-1,-1,1) (1,-1,1,-1)
@@ -90,161 +52,8 @@ DEVI int hsign(int i, int a)
 #define IT_STRIDE 32 // luma tile: sample (x,y) at [(1+y)*32 + 8 + x], x in [-1,19], y in [-1,15]
 #define IC_STRIDE 32 // chroma tile (nv12): sample (x,y,c) at [(1+y)*32 + 8 + 2x + c], x,y in [-1,7]
 
-// ------------------------------------------------------------------------
-// k_deblock2: in-loop deblocking as a macroblock wavefront. A band of 4 macroblock
-// rows is swept left to right; lane group g = lane>>4 works on row band+g, two
-// macroblocks behind group g-1, so all 64 lanes are busy. Within a group the 16
-// lanes are the 16 sample rows of the macroblock for the vertical edges and its 16
-// sample columns for the horizontal edges; each lane filters its line in registers
-// with pure integer mask arithmetic (hipcc turns `c ? a : b` chains into exec-mask
-// branches, which saturate the CU's one scalar pipe).
-//
-// SPECIALISED WAVES. A wave alone on its SIMD issues one instruction per ~4.5
-// cycles whatever their dependencies, so a step costs its instruction count. One
-// wave doing everything needed ~1400 instructions per step, of which ~550 filter
-// samples. Here every band is served by a PAIR:
-//   filter wave  per step: copy left columns / top rows inside LDS, 4 vertical +
-//                4 horizontal edges on the staged tile, save the bottom rows (`bot`)
-//   mover wave   ahead: loads of step t+3 in flight, stages step t+1 (samples +
-//                edge codes) into the next of 3 tile slots; behind: writes step t-1
-//                back to memory, feeds the next workgroup, publishes progress
-// They meet only through two monotonic LDS counters (staged / filtered). The bottom
-// rows a macroblock hands to the row below travel through LDS (`bot`) between the
-// groups of one filter wave; band boundaries (another pair) go through memory under
-// the progress counters, workgroup boundaries through the write-through hand-off
-// buffer. Templates: picture type (P pictures carry no strong-filter code) and planes
-// (luma and chroma are independent given the edge codes and run as two kernels).
-// ------------------------------------------------------------------------
-#define DT_STRIDE 32 // luma tile: (x,y) at [(4+y)*32 + 16 + x], x,y in [-4,15]
-#define DC_STRIDE 32 // chroma tile (nv12): (x,y,c) at [(2+y)*32 + 16 + 2x + c], x,y in [-2,7]
-// Edge codes: the mover turns every boundary strength into one byte, 0x80 | tc0 (0 = edge
-// not filtered), so the filter wave spends two bit-field extracts on it. |a-b|+c on byte
-// values is one v_sad_u8; thresholds go in negated so the sign bit is the comparison.
-DEVI int sadb(int a, int b, int c) { return (int)__builtin_amdgcn_sad_u8((uint32_t)a, (uint32_t)b, (uint32_t)c); }
-DEVI int med3i(int x, int lo, int hi) { return min(max(x, lo), hi); }
-DEVI int code_tc0(uint32_t w, int e) { return (int)((w >> (8 * e)) & 0x7fu); }
-DEVI int code_valid(uint32_t w, int e) { return (int)(w << (24 - 8 * e)) >> 31; }
-
-DEVI void filt_luma_n2(uint32_t w, int e, int nalpha, int nbeta,
-		       int &p2, int &p1, int &p0, int &q0, int &q1, int &q2)
-{
-	const int tc0 = code_tc0(w, e);
-	const int m = (max(max(sadb(p0, q0, nalpha), sadb(p1, p0, nbeta)), sadb(q1, q0, nbeta)) >> 31) & code_valid(w, e);
-	const int sp = sadb(p2, p0, nbeta) >> 31, sq = sadb(q2, q0, nbeta) >> 31; // -1 where the side is smooth
-	const int tc = (tc0 - sp - sq) & m;
-	const int tcp = tc0 & sp & m, tcq = tc0 & sq & m; // a masked-off update is a clip to [0, 0]
-	const int delta = med3i((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
-	const int avg = (p0 + q0 + 1) >> 1;
-	p1 += med3i((p2 + avg - (p1 << 1)) >> 1, -tcp, tcp);
-	q1 += med3i((q2 + avg - (q1 << 1)) >> 1, -tcq, tcq);
-	p0 = med3i(p0 + delta, 0, 255);
-	q0 = med3i(q0 - delta, 0, 255);
-}
-
-DEVI void filt_luma_s2(uint32_t w, int e, int alpha, int beta, int p3, int &p2, int &p1, int &p0,
-		       int &q0, int &q1, int &q2, int q3)
-{
-	const int d = sadb(p0, q0, 0);
-	const int m = (max(max(d - alpha, sadb(p1, p0, -beta)), sadb(q1, q0, -beta)) >> 31) & code_valid(w, e);
-	const int small = (d - ((alpha >> 2) + 2)) >> 31;
-	const int sp = small & (sadb(p2, p0, -beta) >> 31), sq = small & (sadb(q2, q0, -beta) >> 31);
-	const int np0 = sel(sp, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, (2 * p1 + p0 + q1 + 2) >> 2);
-	const int np1 = sel(sp, (p2 + p1 + p0 + q0 + 2) >> 2, p1);
-	const int np2 = sel(sp, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2);
-	const int nq0 = sel(sq, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, (2 * q1 + q0 + p1 + 2) >> 2);
-	const int nq1 = sel(sq, (p0 + q0 + q1 + q2 + 2) >> 2, q1);
-	const int nq2 = sel(sq, (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3, q2);
-	p0 = sel(m, np0, p0); p1 = sel(m, np1, p1); p2 = sel(m, np2, p2);
-	q0 = sel(m, nq0, q0); q1 = sel(m, nq1, q1); q2 = sel(m, nq2, q2);
-}
-
-DEVI void filt_chroma_n2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &p0, int &q0, int q1)
-{
-	const int m = (max(max(sadb(p0, q0, nalpha), sadb(p1, p0, nbeta)), sadb(q1, q0, nbeta)) >> 31) & code_valid(w, e);
-	const int tc = (code_tc0(w, e) + 1) & m;
-	const int delta = med3i((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
-	p0 = med3i(p0 + delta, 0, 255);
-	q0 = med3i(q0 - delta, 0, 255);
-}
-
-DEVI void filt_chroma_s2(uint32_t w, int e, int nalpha, int nbeta, int p1, int &p0, int &q0, int q1)
-{
-	const int m = (max(max(sadb(p0, q0, nalpha), sadb(p1, p0, nbeta)), sadb(q1, q0, nbeta)) >> 31) & code_valid(w, e);
-	const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-	p0 = sel(m, np0, p0);
-	q0 = sel(m, nq0, q0);
-}
-
-// byte e of an edge-code word if it carries the bS 4 mark (0x40 on top of 0x80), else 0
-DEVI uint32_t strong_part(uint32_t w, int e)
-{
-	return ((w >> (8 * e)) & 0x40u) ? w & (0xffu << (8 * e)) : 0u;
-}
-
-// packed { int16 mvx, mvy } words: 1 if a component differs by 4 quarter samples or more
-DEVI int mv_far(int a, int b)
-{
-	const int dx = (int)(int16_t)a - (int)(int16_t)b, dy = (a >> 16) - (b >> 16);
-	return (int)((uint32_t)(3 - iabs(dx)) >> 31) | (int)((uint32_t)(3 - iabs(dy)) >> 31);
-}
-
 constexpr int DB2_PAIRS_MAX = WF_WAVES / 2;
 
-// (PL: the planes a workgroup filters, 1 luma, 2 chroma, 3 both. A one-plane workgroup only carries its plane's
-// tiles: 2.6 KB resp. 1.3 KB per row group instead of 3.9 -- in the small form that is what lets it into the
-// room ONE retiring k_inter workgroup leaves on a full CU, 22 KB + the CU's 7.7 KB of slack)
-template <int PL>
-struct __attribute__((aligned(16))) Db2GroupLds {
-	uint8_t y[(PL & 1) ? 3 : 1][(PL & 1) ? 20 * DT_STRIDE : 16];
-	uint8_t c[(PL & 2) ? 3 : 1][(PL & 2) ? 10 * DC_STRIDE : 16];
-	uint8_t bot[4][(PL & 1) ? 4 * 16 : 16];
-	uint8_t botc[4][(PL & 2) ? 2 * 16 : 16];
-	uint32_t bsv[(PL & 1) ? 3 : 1][16];  // per lane (= sample row): edge codes of the 4 vertical luma edges, one byte each
-	uint32_t bsh[(PL & 1) ? 3 : 1][16];  // per lane (= sample column): the 4 horizontal luma edges
-	uint32_t bsc[(PL & 2) ? 3 : 1][16];  // chroma codes: bytes 0,1 vertical edges 0,2 (lane = plane, row); bytes 2,3 horizontal 0,2 (lane = column)
-	__attribute__((aligned(16))) uint32_t ab[3][4]; // MODE 3: alpha | beta << 8 of the left edge, the same << 16 of the top edge; of the inner edges; chroma likewise
-};
-
-// Where a wave of a wavefront workgroup reports a wait that ran out, and where it looks for the
-// reports of others: once one hand-off is lost every later wait would run out too, one after the
-// other; the abort flags make the rest of the grid drain in milliseconds instead.
-struct WaitCtx {
-	uint32_t *err;     // pinned host word of the frame (collect turns it into -EIO)
-	int *abort_lds;    // this workgroup
-	uint32_t *abort_x; // all workgroups of the launch (device memory, zeroed per launch when wf_split > 1)
-};
-
-DEVI void lds_wait_ge(const int *word, int need, const WaitCtx &w)
-{
-	// bounded like every spin here: a lost partner ends in -EIO at collect, not in a hung grid
-	uint64_t t0 = 0;
-	for (int spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spins++) {
-		// back off after ~50 us: the partner is usually a few hundred cycles away, but with frames
-		// pipelined a whole workgroup can wait for a millisecond for its frame's analysis
-		if (spins < 2048) {
-			__builtin_amdgcn_s_sleep(0);
-			continue;
-		}
-		if (wait_expired((uint32_t)spins, t0)) {
-			__hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(w.abort_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			xstore32(w.abort_x, 1u);
-			break;
-		}
-		if (__hip_atomic_load(w.abort_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-			break;
-		__builtin_amdgcn_s_sleep(32);
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-DEVI void lds_signal(int *word, int value, int lane)
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-	__builtin_amdgcn_wave_barrier();
-	if (lane == 0)
-		__hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // Everything a deblock workgroup keeps in LDS. It lives in DYNAMIC shared memory so that the
 // luma and the chroma instantiation can sit in one kernel (k_deblock2_planes: one launch, the
@@ -342,8 +151,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 	uint32_t *xprog = sync + 16 + unit * WF_MAX_SPLIT;
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	const WaitCtx xw{xerr, &S.abort, xabort};
-	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
-	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
 	uint32_t xseen = 0;
 
 	int iter = 0;
@@ -1136,8 +945,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	const WaitCtx xw{xerr, &s_abort, xabort};
 	// hand-off granules per macroblock: 0,1 = last luma row, 2,3 = last chroma row
-	uint64_t *hb_out = p.wf_hbuf_intra + ((size_t)unit * (WF_MAX_SPLIT - 1) + wj) * p.mb_w * WF_HBUF_GRANULES;
-	const uint64_t *hb_in = p.wf_hbuf_intra + ((size_t)unit * (WF_MAX_SPLIT - 1) + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+	uint64_t *hb_out = p.wf_hbuf_intra + ((size_t)unit * p.wf_hb_slots + wj) * p.mb_w * WF_HBUF_GRANULES;
+	const uint64_t *hb_in = p.wf_hbuf_intra + ((size_t)unit * p.wf_hb_slots + (wj > 0 ? wj - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
 	uint32_t xseen = 0;
 
 	Ir2GroupLds &L = s_g[trip * 4 + g];
@@ -1809,6 +1618,8 @@ static int launch_deblock(const Params &p, hipStream_t s, int planes)
 
 int Launch::deblock(const Params &p, void *stream, int planes)
 {
+	if (p.db_rows)
+		return launch_deblock_rows(p, stream);
 	return p.db_pairs == 2 ? launch_deblock<2>(p, (hipStream_t)stream, planes) : launch_deblock<DB2_PAIRS_MAX>(p, (hipStream_t)stream, planes);
 }
 

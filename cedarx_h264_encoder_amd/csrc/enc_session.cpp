@@ -299,6 +299,9 @@ struct cedar_enc {
 	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
 	int wf_split = 1, wf_split_intra = 1;
 	int db_pairs = 8;
+	bool db_rows = true;   // deblocking with a wave per macroblock row (k_deblock_rows); CEDAR_DEBLOCK_ROWS=0: the band-pair kernel
+	int db_bands = 1;      // ... its workgroups per unit and plane: the bands of 4 rows of the tallest slice
+	int hb_slots = WF_MAX_SPLIT - 1; // workgroup boundaries per unit the hand-off buffers have room for
 	// Pipelined P pictures: the last stripes of a picture's analysis (from defer_from on), its final gate
 	// and its entropy launches are held back and enqueued BETWEEN the first stripes of the next picture:
 	// a picture's last stripe is gated on the END of the previous picture's deblocking, and on an in-order
@@ -1161,9 +1164,22 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	e->wf_split = plan.wf_split;
 	e->wf_split_intra = plan.wf_split_intra;
 	e->db_pairs = plan.db_pairs;
+	{
+		const char *envr = getenv("CEDAR_DEBLOCK_ROWS");
+		e->db_rows = envr && atoi(envr) != 0; // (development: off unless asked for)
+		e->db_bands = 1;
+		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
+			int a, b;
+			slice_rows(mb_h, ext.slice_count, s2, &a, &b);
+			e->db_bands = std::max(e->db_bands, (b - a + 3) / 4);
+		}
+		if ((int64_t)n_units * e->db_bands > WF_SYNC_WORDS - 16)
+			e->db_rows = false; // (a progress word per band: more units x bands than the sync region holds)
+		e->hb_slots = std::max(WF_MAX_SPLIT - 1, e->db_rows ? e->db_bands - 1 : 0);
+	}
 	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
-		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
+		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
 		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 3 * n_units * PROG_BANDS))) return rc;
 		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 3 * (size_t)n_units * PROG_BANDS)));
 	}
@@ -1385,7 +1401,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			}
 			// (all of it assumes the deblock sweep of a unit is ONE front, every band 5 steps behind the band
 			// above: a workgroup with more bands than wave pairs starts band b + pairs when band b is through)
-			const bool one_front = (bands_max + e->wf_split - 1) / e->wf_split <= e->db_pairs;
+			const bool one_front = e->db_rows || (bands_max + e->wf_split - 1) / e->wf_split <= e->db_pairs; // (a workgroup per band: always)
 			// CEDAR_DEFER = number of stripes to hold back (0: none). Between two submits the device then holds
 			// kernels that wait for work only the NEXT submit enqueues; a device-wide synchronisation by anybody in
 			// the process in between would wait for them, so the session's flush thread enqueues the tail itself
@@ -1394,8 +1410,18 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			int kd = nb;
 			if (e->row_pipe && e->cohorts == 1 && !e->mux && want > 0 && want < nb && nb >= 3 && one_front)
 				kd = nb - want;
+			// Safe only if the previous picture's deblocking can get as far as this picture's stripe j asks (k_gate:
+			// diagonal stripe_s[j + 1] + 4, in every band that has such diagonals) on what is published of the
+			// previous picture's analysis when that gate runs: its stripes up to kd + j - 1 are in front of the gate,
+			// but the end of a stripe is published by the gate of the NEXT one, so diagonal stripe_s[kd + j - 1] it is.
+			// How far ahead of the asked diagonal the analysis must be: the progress words move every 8 steps (+8),
+			// a mover waits for the analysis of 3 steps ahead (+4), and every band runs behind the band above it --
+			// k_deblock_rows: a band is a workgroup and its rows above cross the hand-off buffer, 6 steps behind the
+			// band above = 2 diagonals per band. (k_deblock2_planes, bands inside one workgroup: the margin it has
+			// always run with, found by experiment.)
+			const int slack = e->db_rows ? 2 * bands_max + 16 : bands_max + 14;
 			for (int j = 0; j < kd && kd < nb; j++)
-				if (e->stripe_s[j + 1] + bands_max + 14 > e->stripe_s[std::min(nb, kd + j)])
+				if (e->stripe_s[j + 1] + slack > e->stripe_s[std::min(nb, kd + j - (e->db_rows ? 1 : 0))])
 					kd = nb;
 			e->defer_from = kd;
 			if (kd < nb) {
@@ -1450,7 +1476,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.abort_all = e->d_abort_all;
 	P.wf_sync = e->d_wf_sync[0];
 	P.wf_hbuf = e->d_wf_hbuf[0];
-	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * (WF_MAX_SPLIT - 1) * mb_w * WF_HBUF_GRANULES;
+	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES;
 	P.prog_inter = nullptr;
 	P.prog_db = nullptr;
 	P.prog_intra = nullptr;
@@ -1460,6 +1486,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.prog_tag = P.prev_tag = 0;
 	P.wf_split = e->wf_split;
 	P.db_pairs = e->db_pairs;
+	P.wf_hb_slots = e->hb_slots;
+	P.db_rows = e->db_rows ? 1 : 0;
+	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;
 	{
 		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO
@@ -1617,8 +1646,8 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	Q.out += (size_t)s0 * e->stream_out_cap;
 	Q.out_cap = (int32_t)((size_t)n * e->stream_out_cap);
 	Q.wf_sync += (size_t)c * 3 * WF_SYNC_WORDS;
-	Q.wf_hbuf += u0 * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
-	Q.wf_hbuf_intra += u0 * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
+	Q.wf_hbuf += u0 * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
+	Q.wf_hbuf_intra += u0 * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
 	return Q;
 }
 
@@ -1807,7 +1836,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.coef = e->d_coef[ds];
 	P.wf_sync = e->d_wf_sync[ds];
 	P.wf_hbuf = e->d_wf_hbuf[ds];
-	P.wf_hbuf_intra = e->d_wf_hbuf[ds] + (size_t)S * e->ext.slice_num * (WF_MAX_SPLIT - 1) * P.mb_w * WF_HBUF_GRANULES;
+	P.wf_hbuf_intra = e->d_wf_hbuf[ds] + (size_t)S * e->ext.slice_num * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
 	P.out = e->d_out[ds];
 	const int prev = e->prev_slot;
 	const bool pipe = e->row_pipe;
@@ -2011,9 +2040,10 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			Pc.db_self_reset = pipe || self_zero ? 1 : 0;
 			Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done + 1 : nullptr;
 			Pc.done_tag = f.done_tag;
-			if (!Pc.db_self_reset && e->wf_split > 1)
+			if (!Pc.db_self_reset && (e->wf_split > 1 || e->db_rows))
 				HIP_TRY(e, hipMemsetAsync(Pc.wf_sync + WF_SYNC_WORDS, 0,
-							  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)Pc.n_streams * e->ext.slice_num * WF_MAX_SPLIT), s_dbc));
+							  sizeof(uint32_t) * (WF_SYNC_WORDS + 16 + (size_t)Pc.n_streams * e->ext.slice_num *
+									      (e->db_rows ? e->db_bands : WF_MAX_SPLIT)), s_dbc));
 			if (c == 0)
 				tm_begin(e, f, CEDAR_ENC_STAGE_DEBLOCK, s_dbc);
 			// luma and chroma are independent wavefronts: one launch, the plane picked per workgroup
