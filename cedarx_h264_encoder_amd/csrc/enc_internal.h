@@ -143,7 +143,7 @@ struct Params {
 	int32_t wf_split_intra;          // workgroups per unit: intra recon
 	int32_t db_pairs;                // filter/mover wave pairs per deblock workgroup: 8 (a whole CU) or 2
 	int32_t wf_hb_slots;             // workgroup boundaries per unit the hand-off buffers have room for
-	int32_t db_rows;                 // deblocking with a wave per macroblock row (k_deblock_rows): a workgroup per band of 4 rows ...
+	int32_t db_rows;                 // > 0: deblocking with a wave per macroblock row (k_deblock_rows), KiB of LDS a workgroup claims; a workgroup per band of 4 rows ...
 	int32_t db_bands;                // ... and plane, this many per unit (the bands of the session's tallest slice)
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
 	// picture along diagonals (absolute macroblock coordinates), so progress is counted in

@@ -13,10 +13,16 @@
 //   * vertical edges: lane (line l, edge e) holds the 4 samples after its edge as one word, the 4 before it come from
 //     lane e-1 (lane 0: the last columns of the macroblock to the left, final); horizontal edges: lane (column c, edge e),
 //     the same code on words gathered with byte loads.
-// A workgroup is ONE band of 4 macroblock rows on one CU: 4 filter waves (one per row, one per SIMD) and a mover wave
-// that stages samples and edge codes 1 step ahead, has the loads of 3 steps ahead in flight, and writes back 1 step behind
-// (the mover of k_deblock2_planes, 4 rows in its 4 lane groups). Rows inside a band hand their bottom rows on through LDS
-// (`bot`), bands through the write-through hand-off buffer under a progress word, as workgroups of the other kernel do.
+// A workgroup is ONE band of 4 macroblock rows on one CU, seven waves:
+//   4 filter waves  one per row, one per SIMD; they only touch LDS
+//   stager          stages samples and edge codes 1 step ahead of the filter waves (4 rows in its 4 lane groups, at step
+//                   t group g is at macroblock t - g), with the loads of 5 steps ahead in flight
+//   writer          writes filtered tiles back to memory as the rows finish them, publishes the band's progress
+//   courier         the only one that talks to other workgroups: pushes the bottom rows of the band's last row into the
+//                   write-through hand-off buffer as soon as they are final and raises the band's progress word; polls
+//                   the band above's word and pulls its rows into an LDS ring the filter wave of row 0 reads
+// Rows inside a band hand their bottom rows on through LDS (`bot`), one macroblock behind each other; a band follows the
+// band above by that same macroblock plus the courier's two trips through L2 (~3 us), not by steps of its own.
 // Luma and chroma are independent given the edge codes: a workgroup filters one plane (chroma: 32 lanes of each wave).
 // Every wait is a bounded spin. Bytes are those of k_deblock2_planes (tests/test_gpu_parity.py runs both).
 //
@@ -31,12 +37,29 @@
 
 namespace cedar {
 
-constexpr int DBR_WAVES = 5; // 4 filter waves + 1 mover
+constexpr int DBR_WAVES = 7; // 4 filter waves, stager, writer, courier
+constexpr int DBR_RING = 8;  // macroblocks of bottom rows a row keeps for the row (or band) below (power of two)
+
+template <int PL>
+struct __attribute__((aligned(16))) DbrRowLds {
+	uint8_t y[(PL & 1) ? 4 : 1][(PL & 1) ? 20 * DT_STRIDE : 16]; // tiles, ring by step (layout: enc_wf_common.h)
+	uint8_t c[(PL & 2) ? 4 : 1][(PL & 2) ? 10 * DC_STRIDE : 16];
+	uint8_t bot[DBR_RING][(PL & 1) ? 4 * 16 : 16];  // last 4 luma rows of macroblock mx (slot mx & 7) ...
+	uint8_t botc[DBR_RING][(PL & 2) ? 2 * 16 : 16]; // ... last 2 chroma rows
+	uint32_t bsv[(PL & 1) ? 4 : 1][16]; // per sample row: edge codes of the 4 vertical luma edges, one byte each
+	uint32_t bsh[(PL & 1) ? 4 : 1][16]; // per sample column: the 4 horizontal luma edges
+	uint32_t bsc[(PL & 2) ? 4 : 1][16]; // chroma codes: bytes 0,1 vertical edges 0,2 (index = plane, row); bytes 2,3 horizontal 0,2 (index = column)
+	__attribute__((aligned(16))) uint32_t ab[4][4]; // MODE 3: alpha | beta << 8 of the left edge, the same << 16 of the top edge; of the inner edges; chroma likewise
+};
 
 template <int PL>
 struct DbrShared {
-	Db2GroupLds<PL> g[4];
-	int staged;   // steps the mover has staged (step t: macroblock t - g of row g)
+	DbrRowLds<PL> g[4];
+	uint8_t top[DBR_RING][(PL & 1) ? 4 * 16 : 2 * 16]; // bottom rows of the band above (courier), slot mx & 7
+	int staged;   // steps the stager has staged
+	int written;  // steps the writer has written back
+	int pushed;   // macroblocks of row 3 whose bottom rows the courier has sent on (their ring slots are free)
+	int topready; // macroblocks of the band above in `top`
 	int vdone[4]; // macroblocks of row g through their vertical edges
 	int filt[4];  // macroblocks of row g filtered
 	int ticket;
@@ -102,8 +125,31 @@ DEVI void lds_wait_ge_lanes(const int *word, int need, const WaitCtx &w)
 {
 	uint64_t t0 = 0;
 	for (int spins = 0; __any(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need); spins++) {
-		if (spins < 2048) {
-			__builtin_amdgcn_s_sleep(0);
+		if (spins < 1024) {
+			__builtin_amdgcn_s_sleep(1);
+			continue;
+		}
+		if (wait_expired((uint32_t)spins, t0)) {
+			__hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(w.abort_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			xstore32(w.abort_x, 1u);
+			break;
+		}
+		if (__hip_atomic_load(w.abort_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+			break;
+		__builtin_amdgcn_s_sleep(32);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// lds_wait_ge with a first phase that sleeps a cycle count instead of re-issuing at once: the waves of a band share 4 SIMDs
+// (a filter wave that spins takes issue slots from the stager it waits for)
+DEVI void lds_wait_ge1(const int *word, int need, const WaitCtx &w)
+{
+	uint64_t t0 = 0;
+	for (int spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spins++) {
+		if (spins < 1024) {
+			__builtin_amdgcn_s_sleep(1);
 			continue;
 		}
 		if (wait_expired((uint32_t)spins, t0)) {
@@ -132,13 +178,15 @@ DEVI void deblock_rows_body(const Params &p)
 
 	DbrShared<PL> &S = *reinterpret_cast<DbrShared<PL> *>(dbr_lds);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const bool is_mover = wave == 4;
 	const int NB = p.db_bands;
 	uint32_t *sync = p.wf_sync + WF_SYNC_WORDS * (PL == 2 ? 2 : 1);
 	if (threadIdx.x == 0) {
 		S.ticket = (int)atomicAdd(&sync[0], 1u); // bands are taken in the order workgroups start: whoever waits, waits for a resident one
 		S.abort = 0;
 		S.staged = 0;
+		S.written = 0;
+		S.pushed = 0;
+		S.topready = 0;
 	}
 	if (QPM && threadIdx.x < 52) {
 		const QpRow &r = p.qtab[threadIdx.x];
@@ -167,22 +215,25 @@ DEVI void deblock_rows_body(const Params &p)
 	uint32_t *xprog = sync + 16 + unit * NB; // [band]: macroblocks of the band's last row whose bottom rows are in the hand-off buffer
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	const WaitCtx xw{xerr, &S.abort, xabort};
+	const bool feeds_next = band + 1 < nbands; // the last 4 rows of the band's row 3 are stored by whoever filters below
+	const bool from_above = band > 0;          // row 0 takes the rows above it from the band above
 
-	if (!is_mover) {
+	if (wave < 4) {
 		// =========================== filter wave of row g ===========================
 		const int g = wave;
 		const int my = r0 + 4 * band + g;
 		if (my >= r1)
 			return;
+		__builtin_amdgcn_s_setprio(3); // the chain: ahead of whatever else shares the SIMD
 		const bool top_edge = my > r0;
-		Db2GroupLds<PL> &L = S.g[g];
-		const Db2GroupLds<PL> &LU = S.g[g > 0 ? g - 1 : 0];
+		DbrRowLds<PL> &L = S.g[g];
+		const DbrRowLds<PL> &LU = S.g[g > 0 ? g - 1 : 0];
 		const int e = lane & 3, q4 = lane >> 2; // luma: quad = line (vertical edges) / column (horizontal edges), lane of the quad = edge
 		for (int mx = 0; mx < p.mb_w; mx++) {
 			const int t = mx + g;
 			const bool left_edge = mx > 0;
-			const int slot = t % 3, pslot = (t + 2) % 3;
-			lds_wait_ge(&S.staged, t + 1, xw);
+			const int slot = t & 3, pslot = (t + 3) & 3;
+			lds_wait_ge1(&S.staged, t + 1, xw);
 			// thresholds by edge class: the picture's, or this macroblock's (MODE 3)
 			int ayL = p.alpha_y, byL = p.beta_y, ayT = p.alpha_y, byT = p.beta_y, ayI = p.alpha_y, byI = p.beta_y;
 			int acL = p.alpha_c, bcL = p.beta_c, acT = p.alpha_c, bcT = p.beta_c, acI = p.alpha_c, bcI = p.beta_c;
@@ -209,7 +260,7 @@ DEVI void deblock_rows_body(const Params &p)
 				if (e == 0 && left_edge) {
 					*(uint32_t *)(row - 4) = Aout;
 					if (q4 >= 12)
-						*(uint32_t *)(L.bot[(mx - 1) & 3] + (q4 - 12) * 16 + 12) = Aout;
+						*(uint32_t *)(L.bot[(mx - 1) & (DBR_RING - 1)] + (q4 - 12) * 16 + 12) = Aout;
 				}
 			}
 			if (DO_C && lane < 32) {
@@ -234,7 +285,7 @@ DEVI void deblock_rows_body(const Params &p)
 				if (e2 == 0 && left_edge) {
 					row[-4 + c] = (uint8_t)p1;
 					if (r >= 6) {
-						uint8_t *bp = L.botc[(mx - 1) & 3] + (r - 6) * 16 + 12;
+						uint8_t *bp = L.botc[(mx - 1) & (DBR_RING - 1)] + (r - 6) * 16 + 12;
 						bp[c] = (uint8_t)p1;
 						bp[2 + c] = (uint8_t)p0;
 					}
@@ -242,49 +293,49 @@ DEVI void deblock_rows_body(const Params &p)
 			}
 			lds_signal(&S.vdone[g], mx + 1, lane);
 			// rows above: the row above is through (mx, y-1) and through the vertical edges of (mx+1, y-1), the last
-			// thing to touch the bottom rows of (mx, y-1)
+			// thing to touch the bottom rows of (mx, y-1); row 0 of a band has them from the courier
 			if (g > 0) {
 				if (mx + 1 < p.mb_w)
-					lds_wait_ge(&S.vdone[g - 1], mx + 2, xw);
+					lds_wait_ge1(&S.vdone[g - 1], mx + 2, xw);
 				else
-					lds_wait_ge(&S.filt[g - 1], mx + 1, xw);
+					lds_wait_ge1(&S.filt[g - 1], mx + 1, xw);
+			} else if (from_above) {
+				lds_wait_ge1(&S.topready, mx + 1, xw);
 			} else {
 				WAVE_SYNC();
 			}
+			const int rs = mx & (DBR_RING - 1);
 			if (DO_Y) {
-				// ---- horizontal edges: quad = sample column q4; rows above from the row above's bottom rows (row 0 of a
-				// band: staged into the tile by the mover, from the band above) ----
+				// ---- horizontal edges: quad = sample column q4; the 4 rows above come from the bottom rows of the row above ----
 				uint8_t *col = L.y[slot] + 16 + q4;
-				const uint8_t *tsrc = g > 0 ? LU.bot[mx & 3] + q4 : col;
-				const int tstr = g > 0 ? 16 : DT_STRIDE;
+				const uint8_t *tsrc = (g > 0 ? LU.bot[rs] : S.top[rs]) + q4;
 				const uint32_t code = (L.bsh[slot][q4] >> (8 * e)) & 0xffu;
 				if (__any(code & 0x80u)) {
 					uint8_t *bp = col + (4 + 4 * e) * DT_STRIDE;
 					uint32_t B = (uint32_t)bp[0] | (uint32_t)bp[DT_STRIDE] << 8 | (uint32_t)bp[2 * DT_STRIDE] << 16 | (uint32_t)bp[3 * DT_STRIDE] << 24;
-					const uint32_t A0 = (uint32_t)tsrc[0] | (uint32_t)tsrc[tstr] << 8 | (uint32_t)tsrc[2 * tstr] << 16 | (uint32_t)tsrc[3 * tstr] << 24;
+					const uint32_t A0 = (uint32_t)tsrc[0] | (uint32_t)tsrc[16] << 8 | (uint32_t)tsrc[32] << 16 | (uint32_t)tsrc[48] << 24;
 					uint32_t Aout = A0;
 					edge_quad<SM>(A0, B, Aout, code, e, e ? ayI : ayT, e ? byI : byT);
 					bp[0] = (uint8_t)B;
 					bp[DT_STRIDE] = (uint8_t)(B >> 8);
 					bp[2 * DT_STRIDE] = (uint8_t)(B >> 16);
 					bp[3 * DT_STRIDE] = (uint8_t)(B >> 24);
-					if (e == 0 && top_edge) {
+					if (e == 0 && top_edge) { // into the tile, which is where the write-back takes them
 						col[0] = (uint8_t)Aout;
 						col[DT_STRIDE] = (uint8_t)(Aout >> 8);
 						col[2 * DT_STRIDE] = (uint8_t)(Aout >> 16);
 						col[3 * DT_STRIDE] = (uint8_t)(Aout >> 24);
 					}
-				} else if (g > 0 && top_edge && lane < 4) {
-					// nothing to filter: the rows above still go into the tile, which is where the write-back takes them
-					*(u32x4 *)(L.y[slot] + lane * DT_STRIDE + 16) = *(const u32x4 *)(LU.bot[mx & 3] + lane * 16);
+				} else if (top_edge && lane < 4) {
+					*(u32x4 *)(L.y[slot] + lane * DT_STRIDE + 16) = *(const u32x4 *)((g > 0 ? LU.bot[rs] : S.top[rs]) + lane * 16);
 				}
 			}
 			if (DO_C && lane < 32) {
 				// ---- horizontal chroma edges (y = 0, 4): lane = (byte column b, edge e2) ----
 				const int b = lane >> 1, e2 = lane & 1;
 				uint8_t *col = L.c[slot] + 16 + b;
-				const uint8_t *pa = e2 ? col + 4 * DC_STRIDE : g > 0 ? LU.botc[mx & 3] + b : col;
-				const int ps = e2 || g == 0 ? DC_STRIDE : 16;
+				const uint8_t *pa = e2 ? col + 4 * DC_STRIDE : (g > 0 ? LU.botc[rs] : S.top[rs]) + b;
+				const int ps = e2 ? DC_STRIDE : 16;
 				uint8_t *qa = col + (2 + 4 * e2) * DC_STRIDE;
 				const uint32_t code = (L.bsc[slot][b] >> (16 + 8 * e2)) & 0xffu;
 				const int p1 = pa[0];
@@ -303,40 +354,175 @@ DEVI void deblock_rows_body(const Params &p)
 					col[0] = (uint8_t)p1;
 			}
 			WAVE_SYNC();
-			// bottom rows for the row below (its last columns are patched by the next macroblock's vertical edges)
+			// bottom rows for the row below (their last columns are patched by the next macroblock's vertical edges);
+			// row 3's go to the band below: its ring slot must have been sent on
+			if (g == 3 && feeds_next && mx >= DBR_RING)
+				lds_wait_ge1(&S.pushed, mx - DBR_RING + 1, xw);
 			if (DO_Y && lane < 4)
-				*(u32x4 *)(L.bot[mx & 3] + lane * 16) = *(const u32x4 *)(L.y[slot] + (16 + lane) * DT_STRIDE + 16);
+				*(u32x4 *)(L.bot[rs] + lane * 16) = *(const u32x4 *)(L.y[slot] + (16 + lane) * DT_STRIDE + 16);
 			if (DO_C && lane < 2)
-				*(u32x4 *)(L.botc[mx & 3] + lane * 16) = *(const u32x4 *)(L.c[slot] + (8 + lane) * DC_STRIDE + 16);
+				*(u32x4 *)(L.botc[rs] + lane * 16) = *(const u32x4 *)(L.c[slot] + (8 + lane) * DC_STRIDE + 16);
 			lds_signal(&S.filt[g], mx + 1, lane);
 		}
 		return;
 	}
 
-	// ============================== mover wave ==============================
-	// (the mover of k_deblock2_planes: its 4 lane groups are the 4 rows of the band, at step t group g is at macroblock
-	// t - g; see there for the frame pipelining and the two ways of counting progress)
+	const int nsteps = p.mb_w + 3;
+	const int y0b = r0 + 4 * band;
+	if (wave == 6) {
+		// ============================== courier ==============================
+		// out: macroblock mx of row 3 is final once the row is through the vertical edges of mx + 1 (or through the row);
+		// in: what the band above has published. Up to 4 macroblocks a trip each way, lane group k = macroblock, lane l of
+		// the group = 8-byte granule of the plane (luma: 4 rows x 2, chroma: 2 rows x 2, as WF_HBUF_GRANULES lays them out)
+		const int k = lane >> 4, l = lane & 15;
+		const bool my_gran = DO_Y ? l < 8 : (l >= 8 && l < WF_HBUF_GRANULES);
+		const int gl = DO_Y ? l : l - 8; // granule of this plane: row gl >> 1, half gl & 1
+		uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + band) * p.mb_w * WF_HBUF_GRANULES;
+		const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + (band > 0 ? band - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
+		const DbrRowLds<PL> &L3 = S.g[3];
+		int pushed = feeds_next ? 0 : p.mb_w, flagged = pushed;
+		int pulled = from_above ? 0 : p.mb_w, avail = 0;
+		uint32_t spins = 0;
+		uint64_t t0 = 0;
+		while (pushed < p.mb_w || flagged < p.mb_w || pulled < p.mb_w) {
+			bool moved = false;
+			if (pushed < p.mb_w) {
+				const int vd = __hip_atomic_load(&S.vdone[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				const int ft = __hip_atomic_load(&S.filt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+				const int fin = ft >= p.mb_w ? p.mb_w : (vd >= 2 ? min(vd - 1, ft) : 0); // macroblocks whose bottom rows are final
+				const int n = min(fin - pushed, 4);
+				if (n > 0) {
+					if (k < n && my_gran) {
+						const int mx = pushed + k;
+						const uint8_t *src = DO_Y ? L3.bot[mx & (DBR_RING - 1)] + (gl >> 1) * 16 + (gl & 1) * 8
+									  : L3.botc[mx & (DBR_RING - 1)] + (gl >> 1) * 16 + (gl & 1) * 8;
+						xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
+					}
+					pushed += n;
+					moved = true;
+				}
+			}
+			uint64_t inreg = 0;
+			int n_in = 0;
+			uint32_t av = 0;
+			bool polled = false;
+			if (pulled < p.mb_w) {
+				if (pulled < avail) {
+					// room in the ring: row 0 has filtered what was there 8 macroblocks ago
+					const int f0 = __hip_atomic_load(&S.filt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					n_in = min(min(avail, f0 + DBR_RING) - pulled, 4);
+					if (n_in > 0) {
+						if (k < n_in && my_gran)
+							inreg = xload64(hb_in + (size_t)(pulled + k) * WF_HBUF_GRANULES + l);
+					} else {
+						n_in = 0;
+					}
+				} else {
+					av = xload32(&xprog[band - 1]);
+					polled = true;
+				}
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (pushed > flagged) { // the payload stores of this trip (and before) have been performed
+				if (lane == 0)
+					xstore32(&xprog[band], (uint32_t)pushed);
+				flagged = pushed;
+				// the ring slots are free again
+				lds_signal(&S.pushed, pushed, lane);
+			}
+			if (n_in > 0) {
+				if (k < n_in && my_gran)
+					*(uint64_t *)(S.top[(pulled + k) & (DBR_RING - 1)] + (gl >> 1) * 16 + (gl & 1) * 8) = inreg;
+				pulled += n_in;
+				lds_signal(&S.topready, pulled, lane);
+				moved = true;
+			}
+			if (polled && (int)av > avail) {
+				avail = (int)av > p.mb_w ? p.mb_w : (int)av;
+				moved = true;
+			}
+			if (moved) {
+				spins = 0;
+				t0 = 0;
+				continue;
+			}
+			if (wait_expired(++spins, t0) || xload32(xabort) || __hip_atomic_load(&S.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+				xstore32(xabort, 1u);
+				__hip_atomic_store(&S.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_store(xerr, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				break;
+			}
+			__builtin_amdgcn_s_sleep(2);
+		}
+		return;
+	}
+
+	// ============================== stager and writer ==============================
+	// their 4 lane groups are the 4 rows of the band: at step t group g is at macroblock t - g (see k_deblock2_planes for
+	// the frame pipelining and the two ways of counting progress)
 	const int g = lane >> 4, l = lane & 15;
 	const int my = r0 + 4 * band + g;
 	const bool row_ok = my < r1;
 	const bool top_edge = my > r0;
-	Db2GroupLds<PL> &L = S.g[g];
+	DbrRowLds<PL> &L = S.g[g];
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
-	const int nsteps = p.mb_w + 3;
-	const bool feeds_next = g == 3 && band + 1 < nbands; // its last 4 rows are stored by whoever filters below
-	const bool xwg_band = band > 0;
-	const bool xwg_top = g == 0 && xwg_band;
-	const bool is_xprod = feeds_next;
+	auto rows_at = [&](const int *ctr, int t) { // every row has its macroblock of step t behind the counter
+		const int done = t - g + 1;
+		lds_wait_ge_lanes(ctr + g, row_ok ? (done < 0 ? 0 : done > p.mb_w ? p.mb_w : done) : 0, xw);
+	};
+
+	if (wave == 5) {
+		// ============================== writer ==============================
+		uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
+		auto publish_diag = [&](uint32_t d) { // every macroblock of this band with x + y < d is written back
+			if (!my_prog)
+				return;
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			if (lane == 0)
+				__hip_atomic_store(my_prog, p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		};
+		const bool keep_bottom = g == 3 && feeds_next;
+		for (int t = 0; t < nsteps; t++) {
+			rows_at(S.filt, t);
+			if ((t & 7) == 0 && t >= 8) // steps < t have been written back: x + y < t + y0b
+				publish_diag((uint32_t)(t + y0b));
+			const int mx = t - g;
+			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
+			const bool left_edge = mx > 0;
+			const int slot = t & 3;
+			const int x0 = mx * 16, y0 = my * 16;
+			if (act) {
+				if (DO_Y && !(keep_bottom && l >= 12)) {
+					*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
+					if (left_edge)
+						*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
+				}
+				if (DO_C && l < 8 && !(keep_bottom && l >= 6)) {
+					*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
+					if (left_edge)
+						*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
+				}
+				if (top_edge) {
+					if (DO_Y && l < 4)
+						*(u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + l * DT_STRIDE + 16);
+					else if (DO_C && l >= 4 && l < 6)
+						*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16);
+				}
+			}
+			lds_signal(&S.written, t + 1, lane); // (the tile has been read: its slot may be staged again)
+		}
+		publish_diag((uint32_t)PROG_ALL);
+		return;
+	}
+
+	// ============================== stager ==============================
 	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
 	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
-	uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + band) * p.mb_w * WF_HBUF_GRANULES;
-	const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + (band > 0 ? band - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
-	uint32_t xseen = 0;
-	const int y0b = r0 + 4 * band;
 	const int diag0 = 2 * y0b;
 	uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
-	uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
 	auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
 		const bool idr_pic = IDR || (QPM && p.is_idr); // (mode 3 serves the IDR pictures of its sessions too)
 		const uint32_t need = idr_pic ? (uint32_t)(t + 3 + diag0 + 4)  // x + 2*y: group 3 is 3 diagonals ahead of group 0
@@ -374,49 +560,29 @@ DEVI void deblock_rows_body(const Params &p)
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	};
-	auto publish_diag = [&](uint32_t d) { // every macroblock of this band with x + y < d is written back
-		if (!my_prog)
-			return;
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		if (lane == 0)
-			__hip_atomic_store(my_prog, p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	};
 	const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
-	struct MoverRegs {
+	struct StageRegs {
 		u32x4 in, c;
-		uint64_t topx;
 		uint32_t mv, mvt; // motion-vector dword of MbInfo, kept opaque until staged
 		uint32_t ty, tyt; // MIXED: its first dword (type in the low byte)
 		uint8_t qc, qt;   // MODE 3: QP the macroblock, and the one above it, is quantised with (qp_t)
 		uint8_t nz, nzt;
-		bool top_ok;
 	};
-	MoverRegs RA{}, RB{};
+	StageRegs R0{}, R1{}, R2{}, R3{};
 	uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
 	int mvl = 0;
 	bool intra_left = false, pcm_left = false;
 	int eff_left = 0, teff_left = 0; // MODE 3: QP_Y the decoder holds for the macroblock staged last, and for the one above that
-	int pending_x = -1;
 
-	auto load_step = [&](int t, bool block, MoverRegs &R) { // global loads for step t
-		const int nmx = t - g, mx0 = t;
+	auto load_step = [&](int t, StageRegs &R) { // global loads for step t
+		if (t >= nsteps)
+			return;
+		const int nmx = t - g;
 		const bool nact = row_ok && nmx >= 0 && nmx < p.mb_w;
 		const int cmx = nact ? nmx : 0;
 		const size_t a = row_mb + cmx;
 		const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
-		if (t < nsteps)
-			wait_analysis(t);
-		// readiness of the rows above first: its acquire must not sit behind this step's own loads
-		R.top_ok = true;
-		if (xwg_band && mx0 < p.mb_w) { // rows above come from the band above, another workgroup
-			const uint32_t need = (uint32_t)mx0 + 1u;
-			if (xseen < need)
-				xseen = xload32(&xprog[band - 1]);
-			if (xseen < need && block)
-				xseen = xwait(&xprog[band - 1], xabort, xerr, need);
-			R.top_ok = xseen >= need;
-		}
+		wait_analysis(t);
 		if (DO_Y)
 			R.in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
 		if (DO_C)
@@ -440,15 +606,13 @@ DEVI void deblock_rows_body(const Params &p)
 			R.ty = ((const uint32_t *)&p.mbi[a])[0];
 			R.tyt = ((const uint32_t *)&p.mbi[(top_edge && row_ok) ? a - p.mb_w : a])[0];
 		}
-		if (xwg_top && R.top_ok && nact && ((DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES)))
-			R.topx = xload64(hb_in + (size_t)cmx * WF_HBUF_GRANULES + l);
 	};
 
-	auto stage_step = [&](int t, const MoverRegs &R) { // registers -> tile slot t%3 + edge codes
+	auto stage_step = [&](int t, const StageRegs &R) { // registers -> tile slot t & 3 + edge codes
 		const int mx = t - g;
 		const bool act = row_ok && mx >= 0 && mx < p.mb_w;
 		const bool left_edge = mx > 0;
-		const int slot = t % 3;
+		const int slot = t & 3;
 		uint32_t nz_cur = 0, nz_top = 0;
 		int mvc = 0, mvt = 0;
 		if (!IDR) {
@@ -464,12 +628,6 @@ DEVI void deblock_rows_body(const Params &p)
 				*(u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16) = R.in;
 			if (DO_C && l < 8)
 				*(u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16) = R.c;
-			if (xwg_top) { // rows above from the band above (inside a band the filter waves fetch them)
-				if (DO_Y && l < 8)
-					*(uint64_t *)(L.y[slot] + (l >> 1) * DT_STRIDE + 16 + (l & 1) * 8) = R.topx;
-				else if (DO_C && l >= 8 && l < 12)
-					*(uint64_t *)(L.c[slot] + ((l - 8) >> 1) * DC_STRIDE + 16 + (l & 1) * 8) = R.topx;
-			}
 			if (IDR) { // all intra: bS 4 (strong) on macroblock edges, 3 inside
 				const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
 				wv = in_y | (left_edge ? 0x80u : 0u);
@@ -568,88 +726,34 @@ DEVI void deblock_rows_body(const Params &p)
 			L.bsc[slot][l] = wc;
 	};
 
-	auto writeback_step = [&](int t) { // filtered tile of step t -> memory, next band
-		const int mx = t - g;
-		const bool act = row_ok && mx >= 0 && mx < p.mb_w;
-		const bool left_edge = mx > 0;
-		const int slot = t % 3;
-		const int x0 = mx * 16, y0 = my * 16;
-		if (!act)
+	auto stager_iter = [&](int t, StageRegs &R) { // R holds step t+1 and is refilled with step t+5
+		if (t + 1 >= nsteps)
 			return;
-		if (DO_Y && !(feeds_next && l >= 12)) {
-			*(u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16);
-			if (left_edge)
-				*(uint32_t *)(rec_y + (size_t)(y0 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.y[slot] + (4 + l) * DT_STRIDE + 12);
-		}
-		if (DO_C && l < 8 && !(feeds_next && l >= 6)) {
-			*(u32x4 *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16);
-			if (left_edge)
-				*(uint32_t *)(rec_uv + (size_t)(my * 8 + l) * p.cw + x0 - 4) = *(const uint32_t *)(L.c[slot] + (2 + l) * DC_STRIDE + 12);
-		}
-		if (top_edge) {
-			if (DO_Y && l < 4)
-				*(u32x4 *)(rec_y + (size_t)(y0 - 4 + l) * p.cw + x0) = *(const u32x4 *)(L.y[slot] + l * DT_STRIDE + 16);
-			else if (DO_C && l >= 4 && l < 6)
-				*(u32x4 *)(rec_uv + (size_t)(my * 8 - 2 + l - 4) * p.cw + x0) = *(const u32x4 *)(L.c[slot] + (l - 4) * DC_STRIDE + 16);
-		}
-		if (is_xprod) {
-			const bool my_gran = (DO_Y && l < 8) || (DO_C && l >= 8 && l < WF_HBUF_GRANULES);
-			if (left_edge && my_gran) {
-				const uint8_t *src = l < 8 ? L.bot[(mx - 1) & 3] + (l >> 1) * 16 + (l & 1) * 8
-							   : L.botc[(mx - 1) & 3] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
-				xstore64(hb_out + (size_t)(mx - 1) * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
-			}
-			if (mx == p.mb_w - 1 && my_gran) {
-				const uint8_t *src = l < 8 ? L.bot[mx & 3] + (l >> 1) * 16 + (l & 1) * 8
-							   : L.botc[mx & 3] + ((l - 8) >> 1) * 16 + (l & 1) * 8;
-				xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
-			}
-			pending_x = mx == p.mb_w - 1 ? p.mb_w : mx;
-		}
+		// slot (t + 1) & 3 held step t - 3: written back, and read as "the tile to the left" by the vertical edges of step t - 2
+		if (t >= 3)
+			lds_wait_ge1(&S.written, t - 2, xw);
+		if (t >= 2)
+			rows_at(S.vdone, t - 2);
+		stage_step(t + 1, R);
+		// fault injection (tests): from step 8 of the first band on, this stager stops reporting
+		const bool lost = p.fault_inject == 1 && unit == 0 && band == 0 && t >= 8;
+		lds_signal(&S.staged, lost ? 1 : t + 2, lane);
+		load_step(t + 5, R); // may wait for this frame's analysis: after the filter waves have their tiles
 	};
-
-	auto publish = [&]() { // everything issued an iteration ago has completed by now
-		if (band + 1 < nbands) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (is_xprod && l == 0 && pending_x >= 0)
-				xstore32(&xprog[band], (uint32_t)pending_x);
-			pending_x = -1;
-		}
-	};
-
-	auto mover_iter = [&](int t, MoverRegs &R) { // R holds step t+1 and is refilled with step t+3
-		if (t >= 1) { // every row has filtered its macroblock of step t-1
-			const int done = t - g;
-			lds_wait_ge_lanes(&S.filt[g], row_ok ? (done < 0 ? 0 : done > p.mb_w ? p.mb_w : done) : 0, xw);
-		}
-		publish();
-		if ((t & 7) == 0 && t >= 8) // steps <= t-2 were written back an iteration ago
-			publish_diag((uint32_t)(t - 1 + y0b)); // every macroblock of the band with x + y < that
-		if (t + 1 < nsteps) {
-			if (!R.top_ok)
-				load_step(t + 1, true, R);
-			stage_step(t + 1, R);
-			// fault injection (tests): from step 8 of the first band on, this mover stops reporting
-			const bool lost = p.fault_inject == 1 && unit == 0 && band == 0 && t >= 8;
-			lds_signal(&S.staged, lost ? 1 : t + 2, lane);
-			load_step(t + 3, false, R); // may wait for this frame's analysis: after the filter waves have their tiles
-		}
-		if (t >= 1)
-			writeback_step(t - 1);
-	};
-	// prologue: step 0 staged, loads of steps 1 and 2 in flight
-	load_step(0, true, RA);
-	load_step(1, false, RB);
-	stage_step(0, RA);
-	load_step(2, false, RA);
+	// prologue: step 0 staged, loads of steps 1..4 in flight
+	load_step(0, R0);
+	load_step(1, R1);
+	load_step(2, R2);
+	load_step(3, R3);
+	stage_step(0, R0);
+	load_step(4, R0);
 	lds_signal(&S.staged, 1, lane);
-	for (int t = 0; t <= nsteps; t += 2) {
-		mover_iter(t, RB);
-		if (t + 1 <= nsteps)
-			mover_iter(t + 1, RA);
+	for (int t = 0; t < nsteps; t += 4) {
+		stager_iter(t, R1);
+		stager_iter(t + 1, R2);
+		stager_iter(t + 2, R3);
+		stager_iter(t + 3, R0);
 	}
-	publish();
-	publish_diag((uint32_t)PROG_ALL);
 }
 
 // grid: the luma bands of every unit, then the chroma bands (db_bands workgroups per unit and plane)
@@ -685,11 +789,27 @@ __global__ __launch_bounds__(64 * DBR_WAVES) void k_deblock_rows(Params p)
 int launch_deblock_rows(const Params &p, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
-	const size_t lds = sizeof(DbrShared<1>) > sizeof(DbrShared<2>) ? sizeof(DbrShared<1>) : sizeof(DbrShared<2>);
+	// db_rows 2 (few units): enough unused dynamic LDS that a band has its CU to itself -- a filter wave that shares its
+	// SIMD with the waves of k_inter or of the intra wavefront runs at a fraction of its speed, and so do they
+	constexpr size_t lds_min = sizeof(DbrShared<1>) > sizeof(DbrShared<2>) ? sizeof(DbrShared<1>) : sizeof(DbrShared<2>);
+	constexpr size_t lds_alone = 144 * 1024;
+	static_assert(lds_min <= 64 * 1024, "a workgroup's tiles");
+	const size_t lds = (size_t)p.db_rows * 1024 > lds_alone ? lds_alone : (size_t)p.db_rows * 1024 < lds_min ? lds_min : (size_t)p.db_rows * 1024;
+	static bool attr_set = false;
+	if (!attr_set) {
+		if (hipFuncSetAttribute((const void *)k_deblock_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock_rows<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
+		    hipFuncSetAttribute((const void *)k_deblock_rows<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess)
+			return -1;
+		attr_set = true;
+	}
 	const dim3 grid((unsigned)(2 * p.n_streams * p.slice_num * p.db_bands)), block(64 * DBR_WAVES);
 	if (p.roi_off) // regions of interest: thresholds per macroblock; an IDR picture is "every macroblock intra" there
 		hipLaunchKernelGGL((k_deblock_rows<3>), grid, block, lds, s, p);
-	else if (p.pcm && p.is_idr)
+	else if (p.pcm && p.is_idr) // I_PCM macroblocks may be among them: their edges are left alone
 		hipLaunchKernelGGL((k_deblock_rows<5>), grid, block, lds, s, p);
 	else if (p.pcm)
 		hipLaunchKernelGGL((k_deblock_rows<4>), grid, block, lds, s, p);

@@ -20,7 +20,7 @@ struct PlanIn {
 	int pinned_slot_bytes;  // bytes of pinned bytestream buffer one ring slot takes per stream
 	// development switches (CEDAR_*): INT32_MIN = not set
 	int env_row_pipe, env_pipe_depth, env_wf_split, env_wf_split_intra, env_db_pairs, env_deblock_streams,
-	    env_deblock_planes, env_inter_bands, env_defer, env_cohorts;
+	    env_deblock_planes, env_inter_bands, env_defer, env_cohorts, env_deblock_rows;
 };
 constexpr int PLAN_UNSET = -2147483647 - 1;
 constexpr int CEDAR_PLAN_MAX_DEPTH = 16; // = CEDAR_ENC_PIPELINE_DEPTH of the public header (asserted in enc_session.cpp)
@@ -34,6 +34,8 @@ struct Plan {
 	int want_row_pipe;      // frames pipelined on the device, if the streams turn out to overlap
 	int db_streams_wanted;  // deblock streams to probe for
 	int defer_wanted;       // one unit: the tail of a P picture may be held back (wants a third deblock stream)
+	int db_rows;            // deblocking with a wave per macroblock row (k_deblock_rows), a workgroup per band of 4 rows and plane
+	int db_bands;           // ... bands of the tallest slice = its workgroups per unit and plane
 };
 
 struct PlanProbe {
@@ -144,12 +146,28 @@ inline Plan plan_static(const PlanIn &in)
 	// next (DeferredTail in enc_session.cpp), which wants a third deblock stream. 1080p, M MB/s: 5 stripes / 2
 	// streams 36.0; 8 stripes none held, 3 streams 36.4; 8 stripes 3 held, 2 streams 37.6; 8 stripes 3 held, 3 streams
 	// 42.1-43.6. CEDAR_DEFER=0 switches it off.
+	// Which deblock kernel. k_deblock_rows gives every band of 4 rows a workgroup of 7 waves and every macroblock row a
+	// wave: one picture's wavefront takes 0.26 ms instead of 0.40 (1080p), but it spends more instructions per
+	// macroblock and wants its CUs mostly to itself -- for few units. Many units have their parallelism across
+	// pictures (32 x 1080p: 149 M MB/s with it against 171 M with k_deblock2_planes' fewer, fatter waves), and with
+	// frames pipelined their resident workgroups (3 frames' worth) would leave k_inter no CU to run on.
+	// CEDAR_DEBLOCK_ROWS: 0 never, 2 whatever the unit count (development).
+	int nb_lo, nb_hi;
+	plan_band_range(in, nb_lo, nb_hi);
+	p.db_bands = nb_hi;
+	const bool rows_fit = 2 * n_units * nb_hi <= 80;
+	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && rows_fit) : rows_fit) &&
+		    (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16; // (a progress word per band in the sync region)
 	p.defer_wanted = n_units == 1 && !(set(in.env_defer) && in.env_defer == 0);
-	p.db_streams_wanted = set(in.env_deblock_streams) ? in.env_deblock_streams : p.defer_wanted ? 3 : 2;
+	// (with k_deblock_rows two pictures' deblocking in flight are enough and nothing is held back: 1080p 47.3 M MB/s
+	// with 2 streams, 46.2 with 3 and 3 of 8 stripes held back, 30.9 with 1)
+	p.db_streams_wanted = set(in.env_deblock_streams) ? in.env_deblock_streams : p.db_rows ? 2 : p.defer_wanted ? 3 : 2;
 	// Frame pipelining needs kernels of the analysis and of the deblock streams on the GPU at the same time, and it
 	// must leave the GPU mostly free: a pipelined deblock kernel is resident (one CU per workgroup) while it waits
 	// for its frame's analysis, so the deblock workgroups of all frames in flight may only take half of the CUs.
+	// (k_deblock_rows: a band claims enough LDS that no second band shares its CU, the analysis may)
 	p.want_row_pipe = set(in.env_row_pipe) ? in.env_row_pipe != 0
+			  : p.db_rows	       ? 2 * n_units * nb_hi * p.db_streams_wanted <= in.cus * 3 / 4
 					       : n_units <= 8 && 2 * n_units * p.wf_split * p.db_streams_wanted <= in.cus / 2;
 	return p;
 }
@@ -167,7 +185,7 @@ inline PlanRun plan_run(const PlanIn &in, const Plan &p, const PlanProbe &pr)
 	}
 	const int n_units = p.n_units, n_mbs = in.mb_w * rows;
 	r.row_pipe = p.want_row_pipe && pr.holds_pipe_token && pr.db_streams_usable >= 1;
-	r.db_streams = pr.db_streams_usable >= 1 && p.want_row_pipe && pr.holds_pipe_token ? pr.db_streams_usable : 1;
+	r.db_streams = pr.db_streams_usable >= 1 && p.want_row_pipe && pr.holds_pipe_token ? (pr.db_streams_usable < p.db_streams_wanted ? pr.db_streams_usable : p.db_streams_wanted) : 1;
 	// every stripe costs a gate and two dependent launches: small pictures take fewer (854x480 13.1 -> 13.5 M MB/s
 	// with 3, 1080p equal from 3 to 8 while nothing is held back)
 	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 ? 5 : 3);

@@ -885,7 +885,8 @@ static PlanIn plan_input(int mb_w, int mb_h, int slice_count, int slice_first, i
 	const long long slot = (long long)mb_w * mb_h * 1024 + 4096;
 	return PlanIn{ mb_w, mb_h, slice_count, slice_first, slice_num, n_streams, cus, (int)(slot < (1ll << 20) ? (1ll << 20) : slot),
 		       env("CEDAR_ROW_PIPE"), env("CEDAR_PIPE_DEPTH"), env("CEDAR_WF_SPLIT"), env("CEDAR_WF_SPLIT_INTRA"), env("CEDAR_DB_PAIRS"),
-		       env("CEDAR_DEBLOCK_STREAMS"), env("CEDAR_DEBLOCK_PLANES"), env("CEDAR_INTER_BANDS"), env("CEDAR_DEFER"), env("CEDAR_COHORTS") };
+		       env("CEDAR_DEBLOCK_STREAMS"), env("CEDAR_DEBLOCK_PLANES"), env("CEDAR_INTER_BANDS"), env("CEDAR_DEFER"), env("CEDAR_COHORTS"),
+		       env("CEDAR_DEBLOCK_ROWS") };
 }
 
 extern "C" int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar_enc_plan_result *r)
@@ -898,7 +899,7 @@ extern "C" int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar
 	const Plan p = plan_static(in);
 	const PlanRun run = plan_run(in, p, PlanProbe{ q->db_streams_usable, q->holds_pipe_token });
 	*r = cedar_enc_plan_result{ p.error, p.depth, p.wf_split, p.wf_split_intra, p.db_pairs, p.split_planes, p.want_row_pipe,
-				    p.db_streams_wanted, run.row_pipe, run.db_streams, run.inter_bands, run.defer_default, run.cohorts };
+				    p.db_streams_wanted, run.row_pipe, run.db_streams, run.inter_bands, run.defer_default, run.cohorts, p.db_rows };
 	return 0;
 }
 
@@ -1164,19 +1165,9 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	e->wf_split = plan.wf_split;
 	e->wf_split_intra = plan.wf_split_intra;
 	e->db_pairs = plan.db_pairs;
-	{
-		const char *envr = getenv("CEDAR_DEBLOCK_ROWS");
-		e->db_rows = envr && atoi(envr) != 0; // (development: off unless asked for)
-		e->db_bands = 1;
-		for (int s2 = ext.slice_first; s2 < ext.slice_first + ext.slice_num; s2++) {
-			int a, b;
-			slice_rows(mb_h, ext.slice_count, s2, &a, &b);
-			e->db_bands = std::max(e->db_bands, (b - a + 3) / 4);
-		}
-		if ((int64_t)n_units * e->db_bands > WF_SYNC_WORDS - 16)
-			e->db_rows = false; // (a progress word per band: more units x bands than the sync region holds)
-		e->hb_slots = std::max(WF_MAX_SPLIT - 1, e->db_rows ? e->db_bands - 1 : 0);
-	}
+	e->db_rows = plan.db_rows != 0;
+	e->db_bands = plan.db_bands;
+	e->hb_slots = std::max(WF_MAX_SPLIT - 1, e->db_rows ? e->db_bands - 1 : 0);
 	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
 		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
@@ -1414,12 +1405,11 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			// diagonal stripe_s[j + 1] + 4, in every band that has such diagonals) on what is published of the
 			// previous picture's analysis when that gate runs: its stripes up to kd + j - 1 are in front of the gate,
 			// but the end of a stripe is published by the gate of the NEXT one, so diagonal stripe_s[kd + j - 1] it is.
-			// How far ahead of the asked diagonal the analysis must be: the progress words move every 8 steps (+8),
-			// a mover waits for the analysis of 3 steps ahead (+4), and every band runs behind the band above it --
-			// k_deblock_rows: a band is a workgroup and its rows above cross the hand-off buffer, 6 steps behind the
-			// band above = 2 diagonals per band. (k_deblock2_planes, bands inside one workgroup: the margin it has
-			// always run with, found by experiment.)
-			const int slack = e->db_rows ? 2 * bands_max + 16 : bands_max + 14;
+			// How far ahead of the asked diagonal the analysis must be: the progress words move every 8 steps (+8), a
+			// stager waits for the analysis of 5 steps ahead (+5), and -- k_deblock_rows -- every band is on the SAME
+			// diagonal as the band above (one macroblock behind its last row, like the rows of a band). (k_deblock2_planes,
+			// bands inside one workgroup, every band a diagonal behind: the margin it has always run with.)
+			const int slack = e->db_rows ? 4 + 8 + 5 + 3 : bands_max + 14;
 			for (int j = 0; j < kd && kd < nb; j++)
 				if (e->stripe_s[j + 1] + slack > e->stripe_s[std::min(nb, kd + j - (e->db_rows ? 1 : 0))])
 					kd = nb;
@@ -1487,7 +1477,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.wf_split = e->wf_split;
 	P.db_pairs = e->db_pairs;
 	P.wf_hb_slots = e->hb_slots;
-	P.db_rows = e->db_rows ? 1 : 0;
+	P.db_rows = e->db_rows ? (getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : 96) : 0; // (KiB of LDS a band claims: see launch_deblock_rows)
 	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;
 	{

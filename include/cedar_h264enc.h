@@ -322,6 +322,7 @@ struct cedar_enc_plan_result {
 	int depth, wf_split, wf_split_intra, db_pairs, split_planes;
 	int want_row_pipe, db_streams_wanted;   /* before the probes */
 	int row_pipe, db_streams, inter_bands, defer_default, cohorts; /* after them */
+	int deblock_rows;                       /* 1: deblocking with a wave per macroblock row (few units), 0: wave pairs per band */
 };
 int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar_enc_plan_result *r);
 

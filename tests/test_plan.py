@@ -18,11 +18,11 @@ class Query(ctypes.Structure):
 class Result(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("error", "depth", "wf_split", "wf_split_intra", "db_pairs", "split_planes",
                                             "want_row_pipe", "db_streams_wanted", "row_pipe", "db_streams", "inter_bands",
-                                            "defer_default", "cohorts")]
+                                            "defer_default", "cohorts", "deblock_rows")]
 
 
 ENV = ("CEDAR_ROW_PIPE", "CEDAR_PIPE_DEPTH", "CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DB_PAIRS", "CEDAR_DEBLOCK_STREAMS",
-       "CEDAR_DEBLOCK_PLANES", "CEDAR_INTER_BANDS", "CEDAR_DEFER", "CEDAR_COHORTS")
+       "CEDAR_DEBLOCK_PLANES", "CEDAR_INTER_BANDS", "CEDAR_DEFER", "CEDAR_COHORTS", "CEDAR_DEBLOCK_ROWS")
 
 
 @pytest.fixture
@@ -45,7 +45,25 @@ def plan(monkeypatch):
     return run
 
 
-def test_one_1080p_stream_is_pipelined_with_held_back_stripes(plan):
+def test_few_units_deblock_with_a_wave_per_macroblock_row(plan):
+    """k_deblock_rows: a workgroup per band of 4 rows and plane, as long as two pictures' worth of them leave the analysis
+    most of the chip; two deblock streams, nothing held back. Many units keep the wave pairs of k_deblock2_planes."""
+    r = plan()
+    assert r.deblock_rows == 1 and (r.want_row_pipe, r.db_streams_wanted) == (1, 2)
+    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 5, 0, 1)
+    assert plan(usable=1).db_streams == 1 and plan(usable=0).row_pipe == 0
+    for kw, rows in ((dict(w=854, h=480), 1), (dict(w=3840, h=2160), 1), (dict(w=3840, h=2160, slices=4), 1),   # 16 / 68 / 72 workgroups
+                     (dict(streams=2), 1), (dict(streams=3), 0), (dict(streams=32), 0), (dict(w=3840, h=2160, slices=4, streams=2), 0),
+                     (dict(w=320, h=240, streams=10), 1), (dict(w=320, h=240, streams=11), 0)):                   # 4 bands: 80 / 88
+        assert plan(**kw).deblock_rows == rows, kw
+    assert plan(deblock_rows=0).deblock_rows == 0 and plan(streams=32, deblock_rows=2).deblock_rows == 1
+    assert plan(streams=3, deblock_rows=1).deblock_rows == 0          # (1 = the default rule)
+    assert plan(cus=64).want_row_pipe == 0 and plan(cus=96).want_row_pipe == 1   # 2 x 34 workgroups on 3/4 of the CUs
+    assert plan(deblock_streams=3).db_streams_wanted == 3
+
+
+def test_one_1080p_stream_is_pipelined_with_held_back_stripes(plan, monkeypatch):
+    monkeypatch.setenv("CEDAR_DEBLOCK_ROWS", "0")   # the wave-pair kernel's policy
     r = plan()
     assert (r.depth, r.wf_split, r.db_pairs, r.split_planes) == (16, 8, 8, 1)
     assert (r.want_row_pipe, r.db_streams_wanted) == (1, 3)
@@ -65,7 +83,8 @@ def test_one_1080p_stream_is_pipelined_with_held_back_stripes(plan):
     assert plan(pipe_depth=7).depth == 7
 
 
-def test_small_pictures_take_three_stripes_and_hold_nothing_back(plan):
+def test_small_pictures_take_three_stripes_and_hold_nothing_back(plan, monkeypatch):
+    monkeypatch.setenv("CEDAR_DEBLOCK_ROWS", "0")
     r = plan(w=854, h=480)
     assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default) == (1, 3, 3, 0)
     r = plan(w=320, h=240)
@@ -74,7 +93,8 @@ def test_small_pictures_take_three_stripes_and_hold_nothing_back(plan):
     assert (r.row_pipe, r.inter_bands, r.defer_default, r.depth) == (1, 8, 3, 16)   # 33 MB of pinned bytestream a slot: 16 of them just fit 512 MB
 
 
-def test_units_decide_the_deblock_form_the_split_and_the_pipelining(plan):
+def test_units_decide_the_deblock_form_the_split_and_the_pipelining(plan, monkeypatch):
+    monkeypatch.setenv("CEDAR_DEBLOCK_ROWS", "0")
     want = {  # streams: (wf_split, db_pairs, want_row_pipe, split_planes, cohorts)
         1: (8, 8, 1, 1, 1), 2: (8, 8, 1, 1, 1), 3: (4, 8, 1, 1, 1), 5: (4, 8, 1, 1, 1), 6: (2, 8, 1, 1, 1), 8: (2, 8, 1, 1, 1),
         9: (9, 2, 0, 1, 1), 16: (9, 2, 0, 1, 1), 31: (9, 2, 0, 1, 1), 32: (9, 2, 0, 0, 2), 64: (9, 2, 0, 0, 2), 200: (9, 2, 0, 0, 2),
@@ -106,7 +126,8 @@ def test_a_band_needs_a_wave_pair_where_rows_are_long(plan):
     assert plan(w=3840, h=16 * 4 * 8 * 16 + 64).error == 1   # 513 bands: more than 16 workgroups x 8 pairs can give a pair each
 
 
-def test_slices_and_slice_shards(plan):
+def test_slices_and_slice_shards(plan, monkeypatch):
+    monkeypatch.setenv("CEDAR_DEBLOCK_ROWS", "0")
     r = plan(w=3840, h=2160, slices=4)                 # configs[3] on one GPU: 4 units of 34 / 34 / 34 / 33 rows
     assert (r.wf_split, r.db_pairs, r.want_row_pipe, r.db_streams_wanted, r.defer_default) == (4, 8, 1, 2, 0)
     assert r.wf_split_intra == 5                       # 9 bands, two triples per workgroup
