@@ -36,6 +36,7 @@ struct Plan {
 	int defer_wanted;       // one unit: the tail of a P picture may be held back (wants a third deblock stream)
 	int db_rows;            // deblocking with a wave per macroblock row (k_deblock_rows), a workgroup per band of 4 rows and plane
 	int db_bands;           // ... bands of the tallest slice = its workgroups per unit and plane
+	int db_lds_kb;          // ... KiB of LDS a workgroup claims: 96 = no second band on its CU, 16 = what its tiles take
 };
 
 struct PlanProbe {
@@ -148,16 +149,21 @@ inline Plan plan_static(const PlanIn &in)
 	// 42.1-43.6. CEDAR_DEFER=0 switches it off.
 	// Which deblock kernel. k_deblock_rows gives every band of 4 rows a workgroup of 7 waves and every macroblock row a
 	// wave: one picture's wavefront takes 0.26 ms instead of 0.40 (1080p), but it spends more instructions per
-	// macroblock and wants its CUs mostly to itself -- for few units. Many units have their parallelism across
-	// pictures (32 x 1080p: 149 M MB/s with it against 171 M with k_deblock2_planes' fewer, fatter waves), and with
-	// frames pipelined their resident workgroups (3 frames' worth) would leave k_inter no CU to run on.
-	// CEDAR_DEBLOCK_ROWS: 0 never, 2 whatever the unit count (development).
+	// macroblock and wants its CU mostly to itself (db_lds_kb: enough LDS that no second band, and no intra workgroup,
+	// shares it; the analysis may). Two pictures' deblocking are resident at a time and spin until their analysis
+	// comes: together they may take 3/4 of the CUs -- one or two 1080p streams, a 4K picture in 1 or 4 slices.
+	// More units have their parallelism across pictures: 32 x 1080p back to back 149 M MB/s with it against 171 M with
+	// k_deblock2_planes' fewer, fatter waves; 7 or 8 x 1080p pipelined (238+ workgroups a picture, several to a CU)
+	// crawl: every band of the picture in front stood between steps 32 and 48 when the next picture's gate gave up
+	// after 3 s (5 and 6 streams ran, at 79 M MB/s: no gain). CEDAR_DEBLOCK_ROWS: 0 never, 2 whatever the unit count.
 	int nb_lo, nb_hi;
 	plan_band_range(in, nb_lo, nb_hi);
 	p.db_bands = nb_hi;
-	const bool rows_fit = 2 * n_units * nb_hi <= 80;
+	const int wgs2 = 2 * 2 * n_units * nb_hi; // workgroups of two pictures, both planes
+	const bool rows_fit = n_units <= 8 && wgs2 <= in.cus * 3 / 4;
 	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && rows_fit) : rows_fit) &&
 		    (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16; // (a progress word per band in the sync region)
+	p.db_lds_kb = wgs2 <= in.cus * 3 / 4 ? 96 : 16;
 	p.defer_wanted = n_units == 1 && !(set(in.env_defer) && in.env_defer == 0);
 	// (with k_deblock_rows two pictures' deblocking in flight are enough and nothing is held back: 1080p 47.3 M MB/s
 	// with 2 streams, 46.2 with 3 and 3 of 8 stripes held back, 30.9 with 1)
@@ -167,7 +173,7 @@ inline Plan plan_static(const PlanIn &in)
 	// for its frame's analysis, so the deblock workgroups of all frames in flight may only take half of the CUs.
 	// (k_deblock_rows: a band claims enough LDS that no second band shares its CU, the analysis may)
 	p.want_row_pipe = set(in.env_row_pipe) ? in.env_row_pipe != 0
-			  : p.db_rows	       ? 2 * n_units * nb_hi * p.db_streams_wanted <= in.cus * 3 / 4
+			  : p.db_rows	       ? rows_fit
 					       : n_units <= 8 && 2 * n_units * p.wf_split * p.db_streams_wanted <= in.cus / 2;
 	return p;
 }

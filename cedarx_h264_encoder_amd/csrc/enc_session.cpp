@@ -301,6 +301,7 @@ struct cedar_enc {
 	int db_pairs = 8;
 	bool db_rows = true;   // deblocking with a wave per macroblock row (k_deblock_rows); CEDAR_DEBLOCK_ROWS=0: the band-pair kernel
 	int db_bands = 1;      // ... its workgroups per unit and plane: the bands of 4 rows of the tallest slice
+	int db_lds_kb = 16;    // ... KiB of LDS each claims
 	int hb_slots = WF_MAX_SPLIT - 1; // workgroup boundaries per unit the hand-off buffers have room for
 	// Pipelined P pictures: the last stripes of a picture's analysis (from defer_from on), its final gate
 	// and its entropy launches are held back and enqueued BETWEEN the first stripes of the next picture:
@@ -1166,6 +1167,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	e->wf_split_intra = plan.wf_split_intra;
 	e->db_pairs = plan.db_pairs;
 	e->db_rows = plan.db_rows != 0;
+	e->db_lds_kb = plan.db_lds_kb;
 	e->db_bands = plan.db_bands;
 	e->hb_slots = std::max(WF_MAX_SPLIT - 1, e->db_rows ? e->db_bands - 1 : 0);
 	for (int i = 0; i < e->depth; i++) {
@@ -1477,7 +1479,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.wf_split = e->wf_split;
 	P.db_pairs = e->db_pairs;
 	P.wf_hb_slots = e->hb_slots;
-	P.db_rows = e->db_rows ? (getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : 96) : 0; // (KiB of LDS a band claims: see launch_deblock_rows)
+	P.db_rows = e->db_rows ? (getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb) : 0; // (KiB of LDS a band claims: see launch_deblock_rows)
 	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;
 	{
