@@ -372,7 +372,8 @@ def run_rank(args, rank, world, local_rank):
     def kernel_line(k, ms):
         alg = KERNEL_BYTES_PER_MB[k] * mb_per_launch + (nbytes / max(1, args.steps) if k == "entropy" else 0)
         ach = alg / (ms * 1e-3) / 1e9
-        line = {"kernel": KERNEL_NAME[k], "work_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
+        name = "k_deblock_rows" if k == "deblock" and st.get("deblock_rows") else KERNEL_NAME[k]
+        line = {"kernel": name, "work_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "hbm_GBs": round(ach, 2), "hbm_frac": ach / HBM_PEAK_GBS}
         if k == "inter":
             slots = INTER_VALU_SLOTS_PER_MB * mb_per_launch / (ms * 1e-3)
@@ -386,6 +387,8 @@ def run_rank(args, rank, world, local_rank):
             nsteps = mb_w + (mb_h - 1) * (1 if k == "deblock" else 2)
             line["true_bound"] = {"kind": "dependency latency: anti-diagonal wavefront", "wavefront_steps": nsteps,
                                   "us_per_step": round(ms * 1e3 / nsteps, 3)}
+            if k == "deblock" and st.get("deblock_rows"):   # a workgroup (CU) per band of 4 rows: rows above cross L2
+                line["true_bound"]["band_boundaries"] = max(0, (mb_h + 3) // 4 - 1)
         else:
             line["true_bound"] = {"kind": "hbm (latency at this size)", "frac": ach / HBM_PEAK_GBS}
         return line
@@ -412,7 +415,7 @@ def run_rank(args, rank, world, local_rank):
         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
         "true_bound": dom["true_bound"],
         "wf_split": st.get("wf_split"),
-        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams")},
+        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams", "deblock_rows")},
         "pipeline_achieved_GBs": round(pipe_bytes / dt_max / 1e9, 3),
         "pipeline_frac": pipe_bytes / dt_max / 1e9 / HBM_PEAK_GBS,
         # every stage with frames back to back (duration = work), against its own bound

@@ -50,6 +50,7 @@ constexpr int PROG_BANDS = 128;     // deblock bands (4 macroblock rows) per uni
 constexpr int PROG_ALL = 0xffff;     // progress value: everything through
 constexpr int INTER_WAVES = 4;       // macroblocks (waves) per k_inter workgroup: a 1080p picture is workgroup-launch bound at 1
 constexpr int IN_K_STREAMS = 8;     // up to this many streams pass their frame pointers as kernel arguments
+constexpr int DBR_HB_GRANULES = 24;  // k_deblock_rows: 4 luma rows x 4 words + 2 chroma rows x 4 words per macroblock
 constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
 // Regions of interest (cedar_enc_config_ext.roi): macroblocks differ in QP, so nothing derived from
@@ -145,6 +146,8 @@ struct Params {
 	int32_t wf_hb_slots;             // workgroup boundaries per unit the hand-off buffers have room for
 	int32_t db_rows;                 // > 0: deblocking with a wave per macroblock row (k_deblock_rows), KiB of LDS a workgroup claims; a workgroup per band of 4 rows ...
 	int32_t db_bands;                // ... and plane, this many per unit (the bands of the session's tallest slice)
+	uint64_t *db_hbuf;               // [n_units][db_bands][mb_w][DBR_HB_GRANULES] k_deblock_rows: bottom rows of a band for the band below,
+	uint32_t db_tag;                 // ... every 8-byte granule = 4 bytes of samples | this frame's tag << 32 (never 0; the buffer starts zeroed)
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
 	// picture along diagonals (absolute macroblock coordinates), so progress is counted in
 	// diagonals: "every macroblock with s < D is through" -- s = x + y for the deblock kernel and

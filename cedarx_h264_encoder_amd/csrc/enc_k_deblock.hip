@@ -212,7 +212,6 @@ DEVI void deblock_rows_body(const Params &p)
 	const int nbands = (r1 - r0 + 3) >> 2;
 	if (band >= nbands) // (slices of a picture differ by one row: the launch has the bands of the tallest)
 		return;
-	uint32_t *xprog = sync + 16 + unit * NB; // [band]: macroblocks of the band's last row whose bottom rows are in the hand-off buffer
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	const WaitCtx xw{xerr, &S.abort, xabort};
 	const bool feeds_next = band + 1 < nbands; // the last 4 rows of the band's row 3 are stored by whoever filters below
@@ -369,91 +368,57 @@ DEVI void deblock_rows_body(const Params &p)
 
 	const int nsteps = p.mb_w + 3;
 	const int y0b = r0 + 4 * band;
+	// The bottom rows of a band's last row cross to the band below (another workgroup, another CU) through db_hbuf:
+	// 8-byte granules, 4 bytes of samples under this frame's tag, written with write-through atomic stores by the
+	// writer as soon as they are final and polled by the courier of the band below -- the payload says itself that it
+	// has arrived: no progress word, no waiting for stores to complete before one may be raised, two trips through L2
+	// per band instead of four. Luma: granule l = row l >> 2, word l & 3; chroma: granules 16 + (row r, word w) = 16 + 4r + w.
+	uint64_t *hb_out = p.db_hbuf + ((size_t)unit * NB + band) * p.mb_w * DBR_HB_GRANULES;
+	const uint64_t *hb_in = p.db_hbuf + ((size_t)unit * NB + (band > 0 ? band - 1 : 0)) * p.mb_w * DBR_HB_GRANULES;
+	constexpr int NGR = DO_Y ? 16 : 8, GR0 = DO_Y ? 0 : 16; // granules of this plane per macroblock, the first of them
 	if (wave == 6) {
 		// ============================== courier ==============================
-		// out: macroblock mx of row 3 is final once the row is through the vertical edges of mx + 1 (or through the row);
-		// in: what the band above has published. Up to 4 macroblocks a trip each way, lane group k = macroblock, lane l of
-		// the group = 8-byte granule of the plane (luma: 4 rows x 2, chroma: 2 rows x 2, as WF_HBUF_GRANULES lays them out)
+		// up to 4 macroblocks a trip, lane group k = macroblock, lane l of the group = granule
 		const int k = lane >> 4, l = lane & 15;
-		const bool my_gran = DO_Y ? l < 8 : (l >= 8 && l < WF_HBUF_GRANULES);
-		const int gl = DO_Y ? l : l - 8; // granule of this plane: row gl >> 1, half gl & 1
-		uint64_t *hb_out = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + band) * p.mb_w * WF_HBUF_GRANULES;
-		const uint64_t *hb_in = p.wf_hbuf + ((size_t)unit * p.wf_hb_slots + (band > 0 ? band - 1 : 0)) * p.mb_w * WF_HBUF_GRANULES;
-		const DbrRowLds<PL> &L3 = S.g[3];
-		int pushed = feeds_next ? 0 : p.mb_w, flagged = pushed;
-		int pulled = from_above ? 0 : p.mb_w, avail = 0;
+		const bool my_gran = l < NGR;
+		int pulled = from_above ? 0 : p.mb_w;
 		uint32_t spins = 0;
 		uint64_t t0 = 0;
-		while (pushed < p.mb_w || flagged < p.mb_w || pulled < p.mb_w) {
-			bool moved = false;
-			if (pushed < p.mb_w) {
-				const int vd = __hip_atomic_load(&S.vdone[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				const int ft = __hip_atomic_load(&S.filt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-				const int fin = ft >= p.mb_w ? p.mb_w : (vd >= 2 ? min(vd - 1, ft) : 0); // macroblocks whose bottom rows are final
-				const int n = min(fin - pushed, 4);
-				if (n > 0) {
-					if (k < n && my_gran) {
-						const int mx = pushed + k;
-						const uint8_t *src = DO_Y ? L3.bot[mx & (DBR_RING - 1)] + (gl >> 1) * 16 + (gl & 1) * 8
-									  : L3.botc[mx & (DBR_RING - 1)] + (gl >> 1) * 16 + (gl & 1) * 8;
-						xstore64(hb_out + (size_t)mx * WF_HBUF_GRANULES + l, *(const uint64_t *)src);
-					}
-					pushed += n;
-					moved = true;
-				}
-			}
-			uint64_t inreg = 0;
+		while (pulled < p.mb_w) {
+			// room in the ring: row 0 has filtered what was there 8 macroblocks ago
+			const int f0 = __hip_atomic_load(&S.filt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const int room = min(min(p.mb_w, f0 + DBR_RING) - pulled, 4);
 			int n_in = 0;
-			uint32_t av = 0;
-			bool polled = false;
-			if (pulled < p.mb_w) {
-				if (pulled < avail) {
-					// room in the ring: row 0 has filtered what was there 8 macroblocks ago
-					const int f0 = __hip_atomic_load(&S.filt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					n_in = min(min(avail, f0 + DBR_RING) - pulled, 4);
-					if (n_in > 0) {
-						if (k < n_in && my_gran)
-							inreg = xload64(hb_in + (size_t)(pulled + k) * WF_HBUF_GRANULES + l);
-					} else {
-						n_in = 0;
-					}
-				} else {
-					av = xload32(&xprog[band - 1]);
-					polled = true;
-				}
-			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (pushed > flagged) { // the payload stores of this trip (and before) have been performed
-				if (lane == 0)
-					xstore32(&xprog[band], (uint32_t)pushed);
-				flagged = pushed;
-				// the ring slots are free again
-				lds_signal(&S.pushed, pushed, lane);
+			if (room > 0) {
+				uint64_t v = 0;
+				const bool mine = k < room && my_gran;
+				if (mine)
+					v = xload64(hb_in + (size_t)(pulled + k) * DBR_HB_GRANULES + GR0 + l);
+				const uint64_t ok = __ballot(!mine || (uint32_t)(v >> 32) == p.db_tag); // a macroblock is there when all its granules are
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					if (n_in == j && j < room && ((ok >> (16 * j)) & 0xffffu) == 0xffffu)
+						n_in = j + 1;
+				if (k < n_in && my_gran)
+					*(uint32_t *)(S.top[(pulled + k) & (DBR_RING - 1)] + 4 * l) = (uint32_t)v; // (row l >> 2, word l & 3: 16 bytes a row)
 			}
 			if (n_in > 0) {
-				if (k < n_in && my_gran)
-					*(uint64_t *)(S.top[(pulled + k) & (DBR_RING - 1)] + (gl >> 1) * 16 + (gl & 1) * 8) = inreg;
 				pulled += n_in;
 				lds_signal(&S.topready, pulled, lane);
-				moved = true;
-			}
-			if (polled && (int)av > avail) {
-				avail = (int)av > p.mb_w ? p.mb_w : (int)av;
-				moved = true;
-			}
-			if (moved) {
 				spins = 0;
 				t0 = 0;
 				continue;
 			}
-			if (wait_expired(++spins, t0) || xload32(xabort) || __hip_atomic_load(&S.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+			if (wait_expired(++spins, t0) || ((spins & 15u) == 0 && (xload32(xabort) || __hip_atomic_load(&S.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)))) {
 				xstore32(xabort, 1u);
 				__hip_atomic_store(&S.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				__hip_atomic_store(xerr, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				break;
 			}
-			__builtin_amdgcn_s_sleep(2);
+			if (room > 0)
+				__builtin_amdgcn_s_sleep(2);
+			else
+				__builtin_amdgcn_s_sleep(8);
 		}
 		return;
 	}
@@ -485,8 +450,19 @@ DEVI void deblock_rows_body(const Params &p)
 				__hip_atomic_store(my_prog, p.prog_tag | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		};
 		const bool keep_bottom = g == 3 && feeds_next;
+		const DbrRowLds<PL> &L3 = S.g[3];
+		auto push = [&](int mx) { // the bottom rows of macroblock mx of row 3, final, to the band below (lane group 3: a granule a lane)
+			if (g == 3 && l < NGR) {
+				const uint32_t w = DO_Y ? *(const uint32_t *)(L3.bot[mx & (DBR_RING - 1)] + 4 * l) : *(const uint32_t *)(L3.botc[mx & (DBR_RING - 1)] + 4 * l);
+				xstore64(hb_out + (size_t)mx * DBR_HB_GRANULES + GR0 + l, (uint64_t)w | (uint64_t)p.db_tag << 32);
+			}
+			lds_signal(&S.pushed, mx + 1, lane); // (read: the ring slot is free)
+		};
 		for (int t = 0; t < nsteps; t++) {
 			rows_at(S.filt, t);
+			// row 3 is through macroblock t - 3 and through the vertical edges of it: macroblock t - 4 is final
+			if (feeds_next && t >= 4)
+				push(t - 4);
 			if ((t & 7) == 0 && t >= 8) // steps < t have been written back: x + y < t + y0b
 				publish_diag((uint32_t)(t + y0b));
 			const int mx = t - g;
@@ -514,6 +490,8 @@ DEVI void deblock_rows_body(const Params &p)
 			}
 			lds_signal(&S.written, t + 1, lane); // (the tile has been read: its slot may be staged again)
 		}
+		if (feeds_next)
+			push(p.mb_w - 1); // (nothing to its right patches it)
 		publish_diag((uint32_t)PROG_ALL);
 		return;
 	}

@@ -287,6 +287,7 @@ struct cedar_enc {
 	uint32_t *d_abort_all = nullptr; // Params::abort_all
 	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint64_t *d_wf_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {};
+	uint64_t *d_db_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {}; // k_deblock_rows: tagged bottom rows, band to band
 	uint8_t *d_dummy_rec = nullptr;  // 24 rows: what idle k_inter waves reconstruct into
 	uint32_t *d_stripe_tab = nullptr; // [inter_bands][row_num + 1] running macroblock counts of the diagonal stripes
 	std::vector<int> stripe_s;        // [inter_bands + 1] stripe boundaries (diagonals)
@@ -418,7 +419,7 @@ void free_all(cedar_enc *e)
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
 		F(e->d_qp_eff[i]); F(e->d_qp_t[i]);
-		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
+		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_db_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
 	for (int l = 0; l < ENT_LANES; l++) {
 		F(e->d_slot[l]); F(e->d_mb_bits[l]); F(e->d_skip[l]); F(e->d_bit_off[l]); F(e->d_run[l]); F(e->d_unit_bits[l]);
@@ -1173,6 +1174,11 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
 		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
+		if (e->db_rows) { // (tags decide what is this frame's: memory that held another session's must not look like it)
+			const size_t n_hb = (size_t)n_units * e->db_bands * mb_w * DBR_HB_GRANULES;
+			if ((rc = dalloc(e, &e->d_db_hbuf[i], n_hb))) return rc;
+			HIP_TRY(e, hipMemset(e->d_db_hbuf[i], 0, n_hb * sizeof(uint64_t)));
+		}
 		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 3 * n_units * PROG_BANDS))) return rc;
 		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 3 * (size_t)n_units * PROG_BANDS)));
 	}
@@ -1276,11 +1282,13 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// Look-ahead for IDR pictures: two more streams -- the IDR picture's analysis (busy for
 		// milliseconds) and the input of all frames (which must never queue behind that, nor behind
 		// a gate on s_main) -- dealt by assign_stream_roles; each must run beside every stream in use.
-		// CEDAR_IDR_DEBLOCK_INLINE=0 also puts the IDR picture's deblocking on a stream of its own,
-		// resident beside the intra wavefront (measured slower: one more queue that blocks a pipe).
+		// The IDR picture's deblocking: on a stream of its own, resident beside the intra wavefront it follows band by
+		// band (k_deblock_rows: 1080p K 300 47.0 -> 48.0 M MB/s, the driver's K 20 34.8 -> 38.3 M: its 0.3 ms no
+		// longer come after the intra kernel's 1.9 ms), or behind it on the same stream (k_deblock2_planes, whose
+		// whole-CU workgroups measured slower beside it: one more queue that blocks a pipe). CEDAR_IDR_DEBLOCK_INLINE.
 		const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
 		e->lookahead = false;
-		e->idr_deblock_inline = !envi || atoi(envi) != 0;
+		e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows;
 		// (sessions whose frames run back to back take the IDR picture out of line too: nothing polls
 		// there, the P picture after it waits for its events, and with 4 frames in flight it gets a
 		// three-frame head start)
@@ -1468,6 +1476,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.abort_all = e->d_abort_all;
 	P.wf_sync = e->d_wf_sync[0];
 	P.wf_hbuf = e->d_wf_hbuf[0];
+	P.db_hbuf = e->d_db_hbuf[0];
+	P.db_tag = 0;
 	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES;
 	P.prog_inter = nullptr;
 	P.prog_db = nullptr;
@@ -1639,6 +1649,8 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	Q.out_cap = (int32_t)((size_t)n * e->stream_out_cap);
 	Q.wf_sync += (size_t)c * 3 * WF_SYNC_WORDS;
 	Q.wf_hbuf += u0 * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
+	if (Q.db_hbuf)
+		Q.db_hbuf += u0 * e->db_bands * P.mb_w * DBR_HB_GRANULES;
 	Q.wf_hbuf_intra += u0 * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
 	return Q;
 }
@@ -1828,6 +1840,8 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.coef = e->d_coef[ds];
 	P.wf_sync = e->d_wf_sync[ds];
 	P.wf_hbuf = e->d_wf_hbuf[ds];
+	P.db_hbuf = e->d_db_hbuf[ds];
+	P.db_tag = seq;
 	P.wf_hbuf_intra = e->d_wf_hbuf[ds] + (size_t)S * e->ext.slice_num * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
 	P.out = e->d_out[ds];
 	const int prev = e->prev_slot;
@@ -2707,6 +2721,7 @@ extern "C" int cedar_enc_get_stats(cedar_enc *e, struct cedar_enc_stats *out)
 	*out = e->stats;
 	out->wf_split = e->wf_split;
 	out->deblock_planes_split = e->split_planes ? 1 : 0;
+	out->deblock_rows = e->db_rows ? 1 : 0;
 	out->frames_pipelined = e->row_pipe ? 1 : 0;
 	out->idr_lookahead = e->lookahead ? 1 : 0;
 	out->depth = e->depth;
