@@ -398,7 +398,8 @@ def run_rank(args, rank, world, local_rank):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("%s@%dx%dx%d" % (stage, W, H, S))
+            tkey = "deblock_rows" if stage == "deblock" and st.get("deblock_rows") else stage
+            traffic = json.load(open(tpath)).get("%s@%dx%dx%d" % (tkey, W, H, S))
         except Exception:  # noqa: BLE001
             traffic = None
     first = st["first_frame"]
