@@ -547,10 +547,7 @@ DEVI void deblock_rows_body(const Params &p)
 		uint8_t nz, nzt;
 	};
 	StageRegs R0{}, R1{}, R2{}, R3{};
-	uint32_t nz_left = 0; // of the macroblock staged last (the left neighbour of the next)
-	int mvl = 0;
-	bool intra_left = false, pcm_left = false;
-	int eff_left = 0, teff_left = 0; // MODE 3: QP_Y the decoder holds for the macroblock staged last, and for the one above that
+	EdgeCarry carry; // of the macroblock staged last (the left neighbour of the next)
 
 	auto load_step = [&](int t, StageRegs &R) { // global loads for step t
 		if (t >= nsteps)
@@ -606,95 +603,8 @@ DEVI void deblock_rows_body(const Params &p)
 				*(u32x4 *)(L.y[slot] + (4 + l) * DT_STRIDE + 16) = R.in;
 			if (DO_C && l < 8)
 				*(u32x4 *)(L.c[slot] + (2 + l) * DC_STRIDE + 16) = R.c;
-			if (IDR) { // all intra: bS 4 (strong) on macroblock edges, 3 inside
-				const uint32_t in_y = (cod_y >> 24) * 0x01010100u, in_c = cod_c >> 24;
-				wv = in_y | (left_edge ? 0x80u : 0u);
-				wh = in_y | (top_edge ? 0x80u : 0u);
-				wc = (left_edge ? 0x80u : 0u) | in_c << 8 | (top_edge ? 0x80u : 0u) << 16 | in_c << 24;
-			} else {
-				// edge code by strength for the macroblock's left edge, top edge, inner edges (MODE 3: its own tc0)
-				uint32_t cyL = cod_y, cyT = cod_y, cyI = cod_y, ccL = cod_c, ccT = cod_c, ccI = cod_c;
-				if (QPM) {
-					// QP_Y as the decoder holds it: a macroblock without mb_qp_delta keeps that of the one before it in
-					// its row; thresholds from the mean across a macroblock edge (8.7.2.2), per plane
-					auto coded = [](uint32_t w0) { return (int)(int8_t)(w0 & 0xffu) == MB_I16x16 || ((w0 >> 24) & 0x3fu) != 0; };
-					const int eff = (mx == 0 || coded(R.ty)) ? (int)R.qc : eff_left;
-					const int teff = (mx == 0 || coded(R.tyt)) ? (int)R.qt : teff_left;
-					auto qpc_of = [&](int q) { return (int)((S.qdb[q] >> 40) & 0xffu); };
-					const int ce = qpc_of(eff);
-					const uint64_t yL = S.qdb[(eff_left + eff + 1) >> 1], yT = S.qdb[(teff + eff + 1) >> 1], yI = S.qdb[eff];
-					const uint64_t cL = S.qdb[(qpc_of(eff_left) + ce + 1) >> 1], cT = S.qdb[(qpc_of(teff) + ce + 1) >> 1], cI = S.qdb[ce];
-					auto code3 = [](uint64_t r) { // tc0 of bS 1..3 -> edge codes 0x80 | tc0 in bytes 1..3
-						return (uint32_t)((r >> 8) & 0xffffff00ull) | 0x80808000u;
-					};
-					cyL = code3(yL); cyT = code3(yT); cyI = code3(yI);
-					ccL = code3(cL); ccT = code3(cT); ccI = code3(cI);
-					if (l == 0)
-						*(u32x4 *)L.ab[slot] = u32x4{ (uint32_t)(yL & 0xffffu) | (uint32_t)(yT & 0xffffu) << 16, (uint32_t)(yI & 0xffffu),
-									      (uint32_t)(cL & 0xffffu) | (uint32_t)(cT & 0xffffu) << 16, (uint32_t)(cI & 0xffffu) };
-					eff_left = eff;
-					teff_left = teff;
-				}
-				const int k = l >> 2, ks = (l & 7) >> 1;
-				int bv[4], bh[4];
-				// vectors are in quarter samples: bS 1 from a difference of a whole sample on (8.7.2.1)
-				const int mvd_l = mv_far(mvc, mvl), mvd_t = mv_far(mvc, mvt);
-				const int nzv0 = (int)(((nz_cur >> (4 * k)) | (nz_left >> (4 * k + 3))) & 1u);
-				bv[0] = (2 * nzv0 + ((1 - nzv0) & mvd_l)) & -(int)left_edge;
-				const int nzh0 = (int)(((nz_cur >> k) | (nz_top >> (12 + k))) & 1u);
-				bh[0] = (2 * nzh0 + ((1 - nzh0) & mvd_t)) & -(int)top_edge;
-#pragma unroll
-				for (int e = 1; e < 4; e++) {
-					bv[e] = 2 * (int)(((nz_cur >> (4 * k + e)) | (nz_cur >> (4 * k + e - 1))) & 1u);
-					bh[e] = 2 * (int)(((nz_cur >> (4 * e + k)) | (nz_cur >> (4 * e - 4 + k))) & 1u);
-				}
-				const int nzc0 = (int)(((nz_cur >> (4 * ks)) | (nz_left >> (4 * ks + 3))) & 1u);
-				const int bsc0 = (2 * nzc0 + ((1 - nzc0) & mvd_l)) & -(int)left_edge;
-				const int bsc2 = 2 * (int)(((nz_cur >> (4 * ks + 2)) | (nz_cur >> (4 * ks + 1))) & 1u);
-#pragma unroll
-				for (int e = 0; e < 4; e++) {
-					wv |= (((e == 0 ? cyL : cyI) >> (8 * bv[e])) & 0xffu) << (8 * e);
-					wh |= (((e == 0 ? cyT : cyI) >> (8 * bh[e])) & 0xffu) << (8 * e);
-				}
-				wc = ((ccL >> (8 * bsc0)) & 0xffu) | ((ccI >> (8 * bsc2)) & 0xffu) << 8 |
-				     ((ccT >> (8 * bh[0])) & 0xffu) << 16 | ((ccI >> (8 * bh[2])) & 0xffu) << 24;
-				if (MIXED) { // an intra macroblock on either side: bS 4 on the macroblock edge (code 0xC0), 3 inside
-					const bool ic = (int)(int8_t)(R.ty & 0xffu) < MB_P16x16, it = (int)(int8_t)(R.tyt & 0xffu) < MB_P16x16;
-					if (ic) {
-						const uint32_t in_y = (cyI >> 24) * 0x01010100u, in_c = ccI >> 24;
-						wv = (wv & 0xffu) | in_y;
-						wh = (wh & 0xffu) | in_y;
-						wc = (wc & 0x00ff00ffu) | in_c << 8 | in_c << 24;
-					}
-					if (left_edge && (ic || intra_left)) {
-						wv = (wv & ~0xffu) | 0xC0u;
-						wc = (wc & ~0xffu) | 0xC0u;
-					}
-					if (top_edge && (ic || it)) {
-						wh = (wh & ~0xffu) | 0xC0u;
-						wc = (wc & ~0xff0000u) | 0xC00000u;
-					}
-					intra_left = ic;
-				}
-			}
-			if (PCM) {
-				// I_PCM (only pictures at whose QP no edge of such a macroblock is filtered at all): its own edges, inner
-				// ones included, and its neighbours' edges towards it are left alone
-				const bool pc = (int)(int8_t)(R.ty & 0xffu) == MB_IPCM, pt = top_edge && (int)(int8_t)(R.tyt & 0xffu) == MB_IPCM;
-				if (pc)
-					wv = wh = wc = 0;
-				if (pcm_left) {
-					wv &= ~0xffu;
-					wc &= ~0xffu;
-				}
-				if (pt) {
-					wh &= ~0xffu;
-					wc &= ~0xff0000u;
-				}
-				pcm_left = pc;
-			}
-			nz_left = nz_cur;
-			mvl = mvc;
+			edge_codes<IDR, MIXED, QPM, PCM>(EdgeIn{nz_cur, nz_top, mvc, mvt, R.ty, R.tyt, (int)R.qc, (int)R.qt, mx, l, left_edge, top_edge, cod_y, cod_c},
+							 carry, S.qdb, L.ab[slot], wv, wh, wc);
 		}
 		if (DO_Y) {
 			L.bsv[slot][l] = wv;

@@ -1327,7 +1327,7 @@ def test_regions_of_interest_equal_the_oracle(ce, w, h, qp, roi, keyint, slices,
             ce.CedarEncoder(width=w, height=h, **bad)
 
 
-@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2", "refresh", "roi"])
+@pytest.mark.parametrize("mode", ["plain", "narrow", "wide", "r2", "refresh", "roi", "roi-pairs", "wide-rows", "narrow-rows"])
 def test_fuzz_sweep_against_oracle(mode):
     """tools/fuzz_parity.py with a fixed seed: random geometry (every other picture 1-3 macroblocks
     wide or high in "narrow"), QP, GOP length, slices, streams (up to 33 in "wide"), search range,
@@ -1336,6 +1336,13 @@ def test_fuzz_sweep_against_oracle(mode):
     import subprocess
     import sys
     env = dict(os.environ)
+    # the two deblock kernels: the session picks one by its unit count (enc_plan.h); "-pairs" runs everything on the wave
+    # pairs of k_deblock2_planes, "-rows" everything on k_deblock_rows, lock-step streams and GOP lanes included
+    n_cases = 25
+    if mode.endswith("-pairs") or mode.endswith("-rows"):
+        env["CEDAR_DEBLOCK_ROWS"] = "0" if mode.endswith("-pairs") else "2"
+        mode = mode.rsplit("-", 1)[0]
+        n_cases = 15
     if mode == "narrow":
         env["FUZZ_NARROW"] = "1"
     if mode == "wide":
@@ -1347,7 +1354,7 @@ def test_fuzz_sweep_against_oracle(mode):
     if mode == "roi":       # ... and regions of interest on top of all of it
         env["FUZZ_R2"] = env["FUZZ_REFRESH"] = env["FUZZ_ROI"] = env["FUZZ_MAD"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", "25"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20261003", str(n_cases)],
                        capture_output=True, text=True, env=env, timeout=300, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    assert "25 cases bit-exact" in r.stdout
+    assert "%d cases bit-exact" % n_cases in r.stdout
