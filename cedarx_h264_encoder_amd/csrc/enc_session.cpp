@@ -244,6 +244,10 @@ struct cedar_enc {
 	uint32_t fault_at = 0;       // tests (CEDAR_FAULT_INJECT_AT)
 	int64_t rc_bits[64] = {};    // rate control: bits of the access unit of frame (index % 64) ...
 	int rc_qp[64] = {};          // ... and the QP it was coded at
+	bool rc_lanes = false;       // rate control of a gop_parallel session: one QP per group of G GOPs ...
+	int64_t grp_sum[32] = {};    // ... per group (index = group % 32) the bits of its frames, each scaled to the configured QP,
+	int grp_n[32] = {};          // how many frames that is,
+	long grp_id1[32] = {};       // and which group it is, + 1 (0: none yet)
 	bool rc_multi = false;       // rate control over several lock-step streams: the law runs per stream, the
 	std::vector<int64_t> rc_bits_s; // kernels take the picture's QP per stream (Params::qp_s); [stream][64] as above
 	std::vector<int> rc_qp_s;
@@ -740,6 +744,25 @@ int rc_pick_qp(int qp0, int64_t target, const int64_t *bits, const int *qps, lon
 	return qp < 1 ? 1 : qp > 47 ? 47 : qp;
 }
 
+// The law of a session that codes G closed GOPs side by side: nothing inside a group can steer it (the later GOPs of a
+// group are coded beside the earlier ones), so there is ONE QP per group, from the mean bits per frame -- scaled to the
+// configured QP as above -- of the group 1 + ceil(16 / keyint) groups back: the nearest group all of whose lock-step steps
+// have been collected when the first step of this one is submitted, whatever the caller's pipelining (16 steps in flight at
+// most). Scalar twin: rc_pick_qp_group in oracle/h264o_enc.c (h264o_config.rc_lanes).
+int rc_group_lag(int keyint) { return 1 + (CEDAR_ENC_PIPELINE_DEPTH + keyint - 1) / keyint; }
+int rc_pick_qp_group(int qp0, int64_t target, const int64_t *sum, const int *cnt, const long *id1, long m, int keyint)
+{
+	const long r = m - rc_group_lag(keyint);
+	if (r < 0 || target <= 0 || id1[r & 31] != r + 1 || cnt[r & 31] <= 0)
+		return qp0;
+	const int64_t avg = sum[r & 31] / cnt[r & 31];
+	int d = -46;
+	while (d < 46 && rc_pow2_6_q16(d) * target < (avg << 16))
+		d++;
+	const int qp = qp0 + d;
+	return qp < 1 ? 1 : qp > 47 ? 47 : qp;
+}
+
 void fill_static_params(cedar_enc *e)
 {
 	Params &P = e->P;
@@ -980,8 +1003,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		return fail(e, -EINVAL, "pcm must be 0 (I_PCM where a macroblock could pass 3200 bits) or -1 (never)");
 	if (ext.strict_mb_bits == 2 && (S_user != 1 || G != 1 || ext.slice_num != ext.slice_count))
 		return fail(e, -EINVAL, "requantising oversize pictures wants one stream, whole pictures, no GOP lanes (one QP per launch)");
-	if (ext.bitrate < 0 || (ext.bitrate > 0 && (G != 1 || ext.slice_num != ext.slice_count)))
-		return fail(e, -EINVAL, "rate control wants whole pictures and no GOP lanes (its law looks back in frame order)");
+	if (ext.bitrate < 0 || (ext.bitrate > 0 && (ext.slice_num != ext.slice_count || (G != 1 && S_user != 1))))
+		return fail(e, -EINVAL, "rate control wants whole pictures; with GOP lanes (one QP per group of lanes) one stream");
 	if (mb_h > 512 * ext.slice_count)
 		return fail(e, -EINVAL, "picture too tall for one slice");
 	if (ext.first_frame_index < 0 || ext.first_frame_index % cfg->keyframe_interval)
@@ -1001,7 +1024,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	const bool row_rule = e->mb_qp;
 	// rate control over several streams: every stream its own QP per picture, i.e. the kernels that look the
 	// QP up per macroblock (but no QP differs inside a picture: no row rule)
-	e->rc_multi = ext.bitrate > 0 && ext.n_streams > 1;
+	e->rc_multi = ext.bitrate > 0 && ext.n_streams > 1 && G == 1;
+	e->rc_lanes = ext.bitrate > 0 && G > 1; // one QP per group of G GOPs (rc_pick_qp_group)
 	e->mb_qp = e->mb_qp || e->rc_multi;
 	e->pcm_session = ext.pcm >= 0 && !e->mb_qp && ext.intra_refresh == 0;
 	if (e->rc_multi) {
@@ -1810,8 +1834,10 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.refresh_t = e->frame_p_count; // P pictures since the IDR (cyclic intra refresh)
 	f.qp_bump = replay ? replay->qp_bump : 0;
 	if (e->rc_target > 0 || f.qp_bump)
-		set_qp_params(P, (e->rc_target > 0 ? rc_pick_qp(e->cfg.qp, e->rc_target, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyframe_interval)
-						   : e->cfg.qp) + f.qp_bump,
+		set_qp_params(P, (e->rc_lanes	   ? rc_pick_qp_group(e->cfg.qp, e->rc_target, e->grp_sum, e->grp_n, e->grp_id1,
+								      e->frame_count / e->cfg.keyframe_interval, e->cfg.keyframe_interval)
+				  : e->rc_target > 0 ? rc_pick_qp(e->cfg.qp, e->rc_target, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyframe_interval)
+						     : e->cfg.qp) + f.qp_bump,
 			      e->chroma_qp_offset);
 	f.qp = P.qp;
 	P.pcm = e->pcm_session && picture_takes_pcm(P.qp, e->chroma_qp_offset) ? 1 : 0;
@@ -2395,6 +2421,19 @@ static int collect_frame(cedar_enc *e)
 	e->last_total = total;
 	e->rc_bits[f.before.frame_count & 63] = (int64_t)total * 8;
 	e->rc_qp[f.before.frame_count & 63] = f.qp;
+	if (e->rc_lanes) { // (a lock-step step = one frame of every lane of its group)
+		const long m = f.before.frame_count / e->cfg.keyframe_interval;
+		if (e->grp_id1[m & 31] != m + 1) {
+			e->grp_id1[m & 31] = m + 1;
+			e->grp_sum[m & 31] = 0;
+			e->grp_n[m & 31] = 0;
+		}
+		for (int s = 0; s < S; s++)
+			if (f.lane_gidx[s] >= 0) { // (idle lanes of the last group code a frame nobody reads)
+				e->grp_sum[m & 31] += ((int64_t)e->res_size[s] * 8 * rc_pow2_6_q16(f.qp - e->cfg.qp)) >> 16;
+				e->grp_n[m & 31]++;
+			}
+	}
 	if (e->rc_multi)
 		for (int s = 0; s < S; s++) {
 			e->rc_bits_s[(size_t)s * 64 + (f.before.frame_count & 63)] = (int64_t)e->res_size[s] * 8;

@@ -129,8 +129,11 @@ struct cedar_enc_config_ext {
 				frames at least CEDAR_ENC_PIPELINE_DEPTH + 1 back -- so the bytes do not
 				depend on how many frames the caller keeps in flight. qp is the starting
 				point. With n_streams > 1 the law runs per stream (every stream towards this
-				target, its own QP per picture). All slices, no gop_parallel (the law looks
-				back in frame order). 0: fixed QP, as the reference (cedar.c:1165-1168)       */
+				target, its own QP per picture). With gop_parallel = G (one stream) the law
+				is per group of G GOPs -- one QP for the group, from the mean bits per frame
+				of the group 1 + ceil(16 / keyframe_interval) groups back, the nearest one
+				every step of which has left the session by then. All slices.
+				0: fixed QP, as the reference (cedar.c:1165-1168)                             */
 	int intra_refresh;   /* N >= 3: cyclic intra refresh -- the VE has a register for it that the reference
 				never writes (cedar_regs.h:43 CEDAR_H264ENC_CYCLICINTRAREFRESH, SURVEY
 				8(f)-4). In the t-th P picture after an IDR the macroblocks with

@@ -83,6 +83,7 @@ int main(int argc, char **argv)
 	cfg.subpel = env_int("H264ENC_SUBPEL", 0);
 	cfg.pcm = env_int("H264ENC_PCM", 0); /* -1: no I_PCM macroblocks */
 	cfg.scene_cut = env_int("H264ENC_SCENE_CUT", 0);
+	cfg.rc_lanes = env_int("H264ENC_GOP_PARALLEL", 0); /* (only the rate control law knows about GOP lanes: the bytes of a fixed-QP stream do not) */
 	cfg.bitrate = env_int("H264ENC_BITRATE", 0);
 	cfg.strict_mb_bits = env_int("H264ENC_STRICT_MB_BITS", 0);
 	cfg.intra_refresh = env_int("H264ENC_INTRA_REFRESH", 0);

@@ -77,6 +77,10 @@ typedef struct h264o_config {
 	int pcm;              /* 0 (default): a macroblock whose macroblock_layer() could pass the 3200 bits of H.264 A.3.1 is
 	                       * coded I_PCM -- its source samples, raw -- in the sessions that take it (one QP per picture of
 	                       * at most 30, no cyclic refresh: DESIGN.md 3.6); -1: never, strict_mb_bits says what happens */
+	int rc_lanes;         /* > 1 (with bitrate): the rate control law of a session that codes this many closed GOPs side by side
+	                       * (gop_parallel of the HIP path): one QP per GROUP of rc_lanes GOPs, taken from the bits of the
+	                       * group 1 + ceil(16 / keyint) groups back -- the nearest one every frame of which has left a
+	                       * session with 16 steps in flight; qp before that. 0, 1: the law by frames (bitrate above) */
 } h264o_config;
 
 /* per-macroblock record kept for parity debugging against the HIP path */

@@ -45,6 +45,9 @@ struct h264o_enc {
 	uint8_t *qp_eff; /* [mb] QP_Y the decoder holds for it (7.4.5: a macroblock without mb_qp_delta keeps its predecessor's) */
 	int64_t rc_bits[64]; /* rate control history, index = frame number % 64: bits of the access unit ... */
 	int rc_qp[64];       /* ... and the QP it was coded at */
+	int64_t grp_sum[32]; /* rc_lanes: per group of rc_lanes GOPs (index = group % 32) the bits of its frames, each scaled to the configured QP ... */
+	int grp_n[32];       /* ... how many frames that is ... */
+	long grp_id1[32];    /* ... and which group it is, + 1 (0: none yet) */
 	int closed_loop; /* env H264O_CLOSED_LOOP_INTRA=1 (tools/rd_record.py only): intra modes decided on reconstructed neighbours */
 	int max_mb_bits; /* largest macroblock_layer() of the last frame (A.3.1: at most 3200 bits) */
 	uint8_t cbp_code_intra[48], cbp_code_inter[48];
@@ -2081,7 +2084,8 @@ h264o_enc *h264o_open(const h264o_config *cfg, int *err)
 			return NULL;
 	if (cfg->intra_refresh < 0 || (cfg->intra_refresh > 0 && cfg->intra_refresh < 3) || cfg->intra_refresh > 65535)
 		return NULL;
-	if (cfg->scene_cut < 0 || cfg->scene_cut > 100 || cfg->pcm < -1 || cfg->pcm > 0)
+	if (cfg->scene_cut < 0 || cfg->scene_cut > 100 || cfg->pcm < -1 || cfg->pcm > 0 || cfg->rc_lanes < 0 ||
+	    (cfg->rc_lanes > 1 && (cfg->scene_cut > 0 || cfg->strict_mb_bits == 2)))
 		return NULL;
 	if (cfg->search_range < 0 || cfg->search_range > 16)
 		return NULL;
@@ -2201,6 +2205,31 @@ static int rc_pick_qp(int qp0, int64_t target, const int64_t *bits, const int *q
 	return qp < 1 ? 1 : qp > 47 ? 47 : qp;
 }
 
+/* The law of a session that codes G closed GOPs side by side (h264o_config.rc_lanes; gop_parallel of the HIP path, whose
+ * lock-step step q holds frame q % keyint of the G GOPs of group q / keyint): frames of later GOPs of a group are coded
+ * beside the earlier ones, so nothing inside a group can steer it. ONE QP per group, from the mean bits per frame (scaled
+ * to the configured QP as above) of the group RC_GROUP_LAG groups back: the nearest group all of whose steps have been
+ * collected when the first step of this one is submitted, whatever the caller's pipelining (16 steps in flight at most). */
+static int rc_group_lag(int keyint)
+{
+	return 1 + (RC_LAG + keyint - 1) / keyint;
+}
+
+static int rc_pick_qp_group(int qp0, int64_t target, const int64_t *sum, const int *cnt, const long *id1, long m, int keyint)
+{
+	const long r = m - rc_group_lag(keyint);
+	int64_t avg;
+	int d = -46, qp;
+
+	if (r < 0 || target <= 0 || id1[r & 31] != r + 1 || cnt[r & 31] <= 0)
+		return qp0;
+	avg = sum[r & 31] / cnt[r & 31];
+	while (d < 46 && rc_pow2_6_q16(d) * target < (avg << 16))
+		d++;
+	qp = qp0 + d;
+	return qp < 1 ? 1 : qp > 47 ? 47 : qp;
+}
+
 static void pad_source(h264o_enc *e, const uint8_t *luma, const uint8_t *chroma)
 {
 	int w = e->cfg.width, h = e->cfg.height, x, y;
@@ -2262,7 +2291,11 @@ restart: /* cfg.scene_cut: the analysis of a P picture may ask for an IDR pictur
 		const int64_t fn = e->cfg.fps_num > 0 && e->cfg.fps_den > 0 ? e->cfg.fps_num : 30;
 		const int64_t fd = e->cfg.fps_num > 0 && e->cfg.fps_den > 0 ? e->cfg.fps_den : 1;
 
-		e->qp = rc_pick_qp(e->cfg.qp, (int64_t)e->cfg.bitrate * fd / fn, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyint);
+		if (e->cfg.rc_lanes > 1)
+			e->qp = rc_pick_qp_group(e->cfg.qp, (int64_t)e->cfg.bitrate * fd / fn, e->grp_sum, e->grp_n, e->grp_id1,
+						 e->frame_count / ((long)e->cfg.rc_lanes * e->cfg.keyint), e->cfg.keyint);
+		else
+			e->qp = rc_pick_qp(e->cfg.qp, (int64_t)e->cfg.bitrate * fd / fn, e->rc_bits, e->rc_qp, e->frame_count, e->cfg.keyint);
 	}
 	o_hdr = o;
 again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is coded again, 6 QP steps coarser */
@@ -2458,6 +2491,17 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 
 	e->rc_bits[e->frame_count & 63] = (int64_t)o * 8;
 	e->rc_qp[e->frame_count & 63] = e->qp;
+	if (e->cfg.bitrate > 0 && e->cfg.rc_lanes > 1) {
+		const long m = e->frame_count / ((long)e->cfg.rc_lanes * e->cfg.keyint);
+
+		if (e->grp_id1[m & 31] != m + 1) {
+			e->grp_id1[m & 31] = m + 1;
+			e->grp_sum[m & 31] = 0;
+			e->grp_n[m & 31] = 0;
+		}
+		e->grp_sum[m & 31] += ((int64_t)o * 8 * rc_pow2_6_q16(e->qp - e->cfg.qp)) >> 16;
+		e->grp_n[m & 31]++;
+	}
 	/* cedar.c:1193-1201 */
 	e->max_mb_bits = max_mb_bits;
 	e->last_idr = idr;

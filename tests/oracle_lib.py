@@ -20,7 +20,7 @@ class Config(ctypes.Structure):
         "width", "height", "qp", "keyint", "profile_idc", "level_idc",
         "search_range", "slice_count", "chroma_qp_offset", "repeat_headers", "aud", "fps_num", "fps_den",
         "subpel", "bitrate", "strict_mb_bits", "intra_refresh", "roi_count")] + [
-        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5), ("scene_cut", ctypes.c_int), ("pcm", ctypes.c_int)]
+        ("roi", (ctypes.c_int * 5) * 4), ("mad_th", ctypes.c_int * 4), ("mad_dqp", ctypes.c_int * 5), ("scene_cut", ctypes.c_int), ("pcm", ctypes.c_int), ("rc_lanes", ctypes.c_int)]
 
 
 class MB(ctypes.Structure):

@@ -878,8 +878,32 @@ def test_rate_control_follows_the_oracle_at_any_depth(ce, w, h, target):
     assert got == want
     with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target) as enc:
         assert [enc.encode_frame(y, uv) for y, uv in frames[:24]] == want[:24]
-    with pytest.raises(ce.EncoderError):     # the law looks back in frame order: no GOP lanes
-        ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, gop_parallel=2)
+    with pytest.raises(ce.EncoderError):     # GOP lanes have a law of their own (below), for one stream
+        ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, gop_parallel=2, n_streams=2)
+
+
+@pytest.mark.parametrize("w,h,keyint,G,target,n", [(320, 240, 6, 2, 5480000, 100), (192, 112, 4, 3, 1480000, 120), (640, 368, 25, 2, 16750000, 230)])
+def test_rate_control_with_gop_lanes_is_a_law_per_group(ce, w, h, keyint, G, target, n):
+    """bitrate x gop_parallel (one stream): the later GOPs of a group of G are coded beside the earlier ones, so nothing
+    inside a group can steer it -- one QP per group, from the mean bits per frame of the group 1 + ceil(16 / keyint)
+    groups back (every step of which has been collected when this group's first step is submitted, whatever the
+    pipelining). The scalar twin runs the same law serially (h264o_config.rc_lanes): same QPs, same bytes, and the
+    stream still leaves in frame order."""
+    frames = [ol.gen_frame("BC"[(f // 7) % 2], w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=keyint, bitrate=target, rc_lanes=G))
+    want, qps = [], []
+    for y, uv in frames:
+        want.append(oe.encode(y, uv))
+        qps.append(oe.frame_qp())
+    lag = 1 + (16 + keyint - 1) // keyint
+    assert set(qps[:lag * G * keyint]) == {30} and len(set(qps)) > 1           # the law sets in after `lag` groups ...
+    assert all(len(set(qps[i:i + G * keyint])) == 1 for i in range(0, n, G * keyint))   # ... and a group has one QP
+    with ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=keyint, bitrate=target, gop_parallel=G) as enc:
+        got = _encode_gop_parallel(enc, frames)
+    assert got == want
+    dec = ol.OracleDecoder()
+    for au in got:
+        assert dec.decode(au) == 1
 
 
 @pytest.mark.parametrize("w,h,S,target,extra", [(320, 240, 3, 500000, {}), (192, 112, 9, 150000, {}),

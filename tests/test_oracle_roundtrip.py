@@ -147,6 +147,38 @@ def test_rate_control_reaches_the_target_and_stays_decodable():
         assert 0.80 * target <= rate <= 1.02 * target, (target, rate, qps[::10])
 
 
+def test_rate_control_by_groups_of_gop_lanes():
+    """h264o_config.rc_lanes = G (the law of a gop_parallel session): one QP per group of G GOPs, the
+    configured one for the first 1 + ceil(16 / keyint) groups, then what the group that far back says; streams stay
+    decodable by both decoders, and rc_lanes 0 / 1 is the law by frames."""
+    import numpy as np
+    from tests.indep import h264_refdec as rd
+    w, h, K, G, n = 192, 112, 4, 3, 132
+    frames = [ol.gen_frame("BC"[(f // 7) % 2], w, h, f) for f in range(n)]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=K, bitrate=1480000, rc_lanes=G))
+    dec, pdec = ol.OracleDecoder(), rd.Decoder()
+    qps = []
+    for f, (y, uv) in enumerate(frames):
+        au = oe.encode(y, uv)
+        qps.append(oe.frame_qp())
+        assert dec.decode(au) == 1
+        ry, ruv = oe.recon()
+        dy, duv = dec.picture()
+        assert np.array_equal(dy, ry) and np.array_equal(duv, ruv)
+        pic = pdec.decode(au)[0]
+        if f % 11 == 0:
+            assert pic.luma_bytes() == ry.tobytes()
+    lag = 1 + (16 + K - 1) // K
+    groups = [qps[i:i + G * K] for i in range(0, n, G * K)]
+    assert all(len(set(g)) == 1 for g in groups)
+    assert [g[0] for g in groups[:lag]] == [30] * lag and len({g[0] for g in groups}) > 2
+    by_frames = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=K, bitrate=1480000))
+    one_lane = ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=K, bitrate=1480000, rc_lanes=1))
+    assert all(by_frames.encode(y, uv) == one_lane.encode(y, uv) for y, uv in frames[:40])
+    with pytest.raises(Exception):
+        ol.OracleEncoder(ol.default_config(w, h, qp=30, keyint=K, bitrate=1480000, rc_lanes=2, scene_cut=30))
+
+
 @pytest.mark.parametrize("w,h,n,slices,subpel,pattern,keyint", [
     (96, 64, 3, 1, 0, "B", 12), (112, 80, 5, 2, 2, "B", 25), (64, 48, 4, 1, 0, "A", 8),
     (48, 48, 7, 1, 1, "C", 30), (16, 16, 3, 1, 0, "C", 6), (160, 32, 3, 2, 2, "B", 9)])
