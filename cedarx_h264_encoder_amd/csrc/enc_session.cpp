@@ -748,7 +748,7 @@ int rc_pick_qp(int qp0, int64_t target, const int64_t *bits, const int *qps, lon
 // group are coded beside the earlier ones), so there is ONE QP per group, from the mean bits per frame -- scaled to the
 // configured QP as above -- of the group 1 + ceil(16 / keyint) groups back: the nearest group all of whose lock-step steps
 // have been collected when the first step of this one is submitted, whatever the caller's pipelining (16 steps in flight at
-// most). Scalar twin: rc_pick_qp_group in oracle/h264o_enc.c (h264o_config.rc_lanes).
+// most). DESIGN.md 3.2; the scalar checker of the tests runs the same law serially.
 int rc_group_lag(int keyint) { return 1 + (CEDAR_ENC_PIPELINE_DEPTH + keyint - 1) / keyint; }
 int rc_pick_qp_group(int qp0, int64_t target, const int64_t *sum, const int *cnt, const long *id1, long m, int keyint)
 {
