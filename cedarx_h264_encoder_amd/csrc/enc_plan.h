@@ -148,22 +148,29 @@ inline Plan plan_static(const PlanIn &in)
 	// streams 36.0; 8 stripes none held, 3 streams 36.4; 8 stripes 3 held, 2 streams 37.6; 8 stripes 3 held, 3 streams
 	// 42.1-43.6. CEDAR_DEFER=0 switches it off.
 	// Which deblock kernel. k_deblock_rows gives every band of 4 rows a workgroup of 7 waves and every macroblock row a
-	// wave: one picture's wavefront takes 0.26 ms instead of 0.40 (1080p), but it spends more instructions per
-	// macroblock and wants its CU mostly to itself (db_lds_kb: enough LDS that no second band, and no intra workgroup,
-	// shares it; the analysis may). Two pictures' deblocking are resident at a time and spin until their analysis
-	// comes: together they may take 3/4 of the CUs -- one or two 1080p streams, a 4K picture in 1 or 4 slices.
-	// More units have their parallelism across pictures: 32 x 1080p back to back 149 M MB/s with it against 171 M with
-	// k_deblock2_planes' fewer, fatter waves; 7 or 8 x 1080p pipelined (238+ workgroups a picture, several to a CU)
-	// crawl: every band of the picture in front stood between steps 32 and 48 when the next picture's gate gave up
-	// after 3 s (5 and 6 streams ran, at 79 M MB/s: no gain). CEDAR_DEBLOCK_ROWS: 0 never, 2 whatever the unit count.
+	// wave: one picture's wavefront takes 0.21 ms instead of 0.40 (1080p), but it spends more instructions per
+	// macroblock. Two kinds of session get it (1080p, M MB/s, same run each):
+	// * frames PIPELINED, the workgroups of two pictures on 3/4 of the CUs, every band claiming enough LDS that no second
+	//   band and no intra workgroup shares its CU (db_lds_kb 96; the analysis may): one or two 1080p streams (43 -> 50,
+	//   62.5 -> 63.9), a 4K picture in 1 or 4 slices. Two pictures' deblocking are resident at a time and spin until
+	//   their analysis comes, which is why not more: 7 or 8 x 1080p pipelined (238+ workgroups a picture, several to a
+	//   CU) crawl -- every band of the picture in front stood between steps 32 and 48 when the next picture's gate gave up
+	//   after 3 s; 5 and 6 streams ran, at 79 M, no gain.
+	// * 6 to 23 units, frames BACK TO BACK (nothing resident waits for anything; LDS as the tiles need, 16 KB): 6 streams
+	//   91 -> 104, 8: 107 -> 126, 12: 128 -> 151, 16: 143 -> 161, 24: 163 = 163; one stream as 8 GOP lanes 97 -> 116.
+	//   Below 6 the wave pairs with pipelined frames win (3: 76 against 64, 4: 89 against 79).
+	// From 24 units on the parallelism is across pictures and the step is the sum of k_inter, deblocking and entropy on
+	// the same VALUs: 32 x 1080p 171.0 with it against 171.5 with k_deblock2_planes' fewer, fatter waves and cohorts.
+	// CEDAR_DEBLOCK_ROWS: 0 never, 2 whatever the unit count (development).
 	int nb_lo, nb_hi;
 	plan_band_range(in, nb_lo, nb_hi);
 	p.db_bands = nb_hi;
 	const int wgs2 = 2 * 2 * n_units * nb_hi; // workgroups of two pictures, both planes
 	const bool rows_fit = n_units <= 8 && wgs2 <= in.cus * 3 / 4;
-	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && rows_fit) : rows_fit) &&
+	const bool rows_b2b = !rows_fit && n_units >= 6 && n_units < 24;
+	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && (rows_fit || rows_b2b)) : rows_fit || rows_b2b) &&
 		    (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16; // (a progress word per band in the sync region)
-	p.db_lds_kb = wgs2 <= in.cus * 3 / 4 ? 96 : 16;
+	p.db_lds_kb = rows_fit ? 96 : 16;
 	p.defer_wanted = n_units == 1 && !(set(in.env_defer) && in.env_defer == 0);
 	// (with k_deblock_rows two pictures' deblocking in flight are enough and nothing is held back: 1080p 47.3 M MB/s
 	// with 2 streams, 46.2 with 3 and 3 of 8 stripes held back, 30.9 with 1)

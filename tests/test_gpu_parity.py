@@ -882,7 +882,7 @@ def test_rate_control_follows_the_oracle_at_any_depth(ce, w, h, target):
         ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, gop_parallel=2, n_streams=2)
 
 
-@pytest.mark.parametrize("w,h,keyint,G,target,n", [(320, 240, 6, 2, 5480000, 100), (192, 112, 4, 3, 1480000, 120), (640, 368, 25, 2, 16750000, 230)])
+@pytest.mark.parametrize("w,h,keyint,G,target,n", [(320, 240, 6, 2, 5480000, 100), (192, 112, 4, 3, 1480000, 120), (640, 368, 25, 2, 16750000, 160)])
 def test_rate_control_with_gop_lanes_is_a_law_per_group(ce, w, h, keyint, G, target, n):
     """bitrate x gop_parallel (one stream): the later GOPs of a group of G are coded beside the earlier ones, so nothing
     inside a group can steer it -- one QP per group, from the mean bits per frame of the group 1 + ceil(16 / keyint)
@@ -1362,11 +1362,11 @@ def test_fuzz_sweep_against_oracle(mode):
     env = dict(os.environ)
     # the two deblock kernels: the session picks one by its unit count (enc_plan.h); "-pairs" runs everything on the wave
     # pairs of k_deblock2_planes, "-rows" everything on k_deblock_rows, lock-step streams and GOP lanes included
-    n_cases = 25
+    n_cases = 14
     if mode.endswith("-pairs") or mode.endswith("-rows"):
         env["CEDAR_DEBLOCK_ROWS"] = "0" if mode.endswith("-pairs") else "2"
         mode = mode.rsplit("-", 1)[0]
-        n_cases = 15
+        n_cases = 9
     if mode == "narrow":
         env["FUZZ_NARROW"] = "1"
     if mode == "wide":

@@ -52,15 +52,17 @@ def test_few_units_deblock_with_a_wave_per_macroblock_row(plan):
     assert r.deblock_rows == 1 and (r.want_row_pipe, r.db_streams_wanted) == (1, 2)
     assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 5, 0, 1)
     assert plan(usable=1).db_streams == 1 and plan(usable=0).row_pipe == 0
-    for kw, rows in ((dict(w=854, h=480), 1), (dict(w=3840, h=2160), 1), (dict(w=3840, h=2160, slices=4), 1),   # 2 pictures: 32 / 136 / 144 workgroups
-                     (dict(streams=2), 1), (dict(streams=3), 0), (dict(streams=32), 0),                                  # 136 / 204 (3/4 x 256 = 192)
-                     (dict(w=3840, h=2160, slices=4, streams=2), 0),
-                     (dict(w=320, h=240, streams=8), 1), (dict(w=320, h=240, streams=9), 0)):                            # 128; more than 8 units run back to back
-        assert plan(**kw).deblock_rows == rows, kw
+    for kw, rows, pipe in ((dict(w=854, h=480), 1, 1), (dict(w=3840, h=2160), 1, 1), (dict(w=3840, h=2160, slices=4), 1, 1),   # 2 pictures: 32 / 136 / 144 workgroups
+                           (dict(streams=2), 1, 1), (dict(streams=3), 0, 1), (dict(streams=5), 0, 1),                             # 136 / 204 (3/4 x 256 = 192): wave pairs
+                           (dict(streams=6), 1, 0), (dict(streams=8), 1, 0), (dict(streams=23), 1, 0),                            # 6 .. 23 units: rows, frames back to back
+                           (dict(streams=24), 0, 0), (dict(streams=32), 0, 0),
+                           (dict(w=3840, h=2160, slices=4, streams=2), 1, 0), (dict(w=320, h=240, streams=8), 1, 1), (dict(w=320, h=240, streams=9), 1, 0)):
+        r = plan(**kw)
+        assert (r.deblock_rows, r.want_row_pipe) == (rows, pipe), kw
     assert plan(deblock_rows=0).deblock_rows == 0 and plan(streams=32, deblock_rows=2).deblock_rows == 1
     assert plan(streams=3, deblock_rows=1).deblock_rows == 0          # (1 = the default rule)
     assert plan(cus=64).deblock_rows == 0 and plan(cus=96).deblock_rows == 1   # 2 x 34 workgroups on 3/4 of the CUs
-    assert plan(cus=96).want_row_pipe == 1
+    assert plan(cus=96).want_row_pipe == 1 and plan(streams=8, deblock_rows=0).want_row_pipe == 1
     assert plan(deblock_streams=3).db_streams_wanted == 3
 
 
