@@ -201,7 +201,10 @@ inline PlanRun plan_run(const PlanIn &in, const Plan &p, const PlanProbe &pr)
 	r.db_streams = pr.db_streams_usable >= 1 && p.want_row_pipe && pr.holds_pipe_token ? (pr.db_streams_usable < p.db_streams_wanted ? pr.db_streams_usable : p.db_streams_wanted) : 1;
 	// every stripe costs a gate and two dependent launches: small pictures take fewer (854x480 13.1 -> 13.5 M MB/s
 	// with 3, 1080p equal from 3 to 8 while nothing is held back)
-	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 ? 5 : 3);
+	// (k_deblock_rows: 3 at any size -- 1080p, 8 / 3 runs each, the driver's K 20 arguments and the default K 300: 5 stripes
+	// 38.4 / 50.2 M MB/s, 4: 40.5 / 50.5, 3: 41.0 / 51.0, 2: 43.0 / 49.0, 1: 34.1 / 35.1; every stripe is two launches of
+	// the 85 us a submit takes, and the K 20 region waits for its IDR picture's submit)
+	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 && !p.db_rows ? 5 : 3);
 	r.defer_default = 0;
 	if (r.row_pipe && p.defer_wanted && r.db_streams >= 3 && n_mbs >= 4000) {
 		if (!set(in.env_inter_bands))

@@ -50,7 +50,8 @@ def test_few_units_deblock_with_a_wave_per_macroblock_row(plan):
     most of the chip; two deblock streams, nothing held back. Many units keep the wave pairs of k_deblock2_planes."""
     r = plan()
     assert r.deblock_rows == 1 and (r.want_row_pipe, r.db_streams_wanted) == (1, 2)
-    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 5, 0, 1)
+    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 3, 0, 1)
+    assert plan(w=3840, h=2160).inter_bands == 3 and plan(inter_bands=5).inter_bands == 5
     assert plan(usable=1).db_streams == 1 and plan(usable=0).row_pipe == 0
     for kw, rows, pipe in ((dict(w=854, h=480), 1, 1), (dict(w=3840, h=2160), 1, 1), (dict(w=3840, h=2160, slices=4), 1, 1),   # 2 pictures: 32 / 136 / 144 workgroups
                            (dict(streams=2), 1, 1), (dict(streams=3), 0, 1), (dict(streams=5), 0, 1),                             # 136 / 204 (3/4 x 256 = 192): wave pairs
