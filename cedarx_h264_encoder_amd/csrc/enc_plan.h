@@ -153,11 +153,10 @@ inline Plan plan_static(const PlanIn &in)
 	// * frames PIPELINED, the workgroups of two pictures on 3/4 of the CUs, every band claiming enough LDS that no second
 	//   band and no intra workgroup shares its CU (db_lds_kb 96; the analysis may): one or two 1080p streams (43 -> 50,
 	//   62.5 -> 63.9), a 4K picture in 1 or 4 slices. Two pictures' deblocking are resident at a time and spin until
-	//   their analysis comes, which is why not more: a workgroup is 7 waves of 72 registers, 4 of them fill a CU, and 8 x
-	//   1080p are 544 workgroups a picture -- two pictures' worth are the chip's wave slots: the later bands of the picture
-	//   in front never become resident, k_inter finds no SIMD with registers to spare, and the next picture's gate gives up
-	//   after 3 s with every band of the picture in front between steps 32 and 48 (4, 5, 7, 8 streams; 3 run, at 80 M
-	//   against 82 with the wave pairs). Waiting at wave priority 0 instead of 3 changes none of it.
+	//   their analysis comes, which is why not more: with 4, 5, 7 or 8 x 1080p pipelined (544 resident workgroups of 7 waves
+	//   at 8 streams, several to a CU) the next picture's gate gives up after 3 s with every band of the picture in front
+	//   between steps 32 and 48 and the later units' bands not yet started -- the cause is not established (waiting at
+	//   wave priority 0 instead of 3 changes nothing; 3 streams run, at 80 M against 82 with the wave pairs).
 	// * 6 to 23 units, frames BACK TO BACK (nothing resident waits for anything; LDS as the tiles need, 16 KB): 6 streams
 	//   91 -> 104, 8: 107 -> 126, 12: 128 -> 151, 16: 143 -> 161, 24: 163 = 163; one stream as 8 GOP lanes 97 -> 116.
 	//   Below 6 the wave pairs with pipelined frames win (3: 76 against 64, 4: 89 against 79).
