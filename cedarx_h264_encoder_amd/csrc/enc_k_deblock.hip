@@ -499,45 +499,7 @@ DEVI void deblock_rows_body(const Params &p)
 	// ============================== stager ==============================
 	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
 	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
-	const int diag0 = 2 * y0b;
-	uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
-	auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
-		const bool idr_pic = IDR || (QPM && p.is_idr); // (mode 3 serves the IDR pictures of its sessions too)
-		const uint32_t need = idr_pic ? (uint32_t)(t + 3 + diag0 + 4)  // x + 2*y: group 3 is 3 diagonals ahead of group 0
-					      : (uint32_t)(t + y0b + 1);       // x + y: all four rows are on t + y0
-		if (inter_seen >= need)
-			return;
-		const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
-		if (idr_pic && p.prog_intra) { // the band itself, the one above (top rows) and the one below (its consumers)
-			w0 = p.prog_intra + unit * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1);
-			w1 = band > 0 ? w0 - 1 : w0;
-			w2 = band + 1 < nbands && band + 1 < PROG_BANDS ? w0 + 1 : w0;
-		}
-		uint32_t spins = 0;
-		uint64_t t0 = 0;
-		while (true) {
-			const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t want = p.prog_tag | need;
-			if ((int32_t)(v0 - want) >= 0 && (int32_t)(v1 - want) >= 0 && (int32_t)(v2 - want) >= 0) {
-				const uint32_t a = v0 & 0xffffu, b = v1 & 0xffffu, c = v2 & 0xffffu;
-				inter_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
-				break;
-			}
-			if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-				__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				inter_seen = 0x7fffffffu;
-				break;
-			}
-			if (spins < 8)
-				__builtin_amdgcn_s_sleep(16);
-			else
-				__builtin_amdgcn_s_sleep(127);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	};
+	AnalysisWait aw{p.prog_inter ? 0u : 0x7fffffffu, IDR || (QPM && p.is_idr), y0b, unit, band, nbands}; // (mode 3 serves the IDR pictures of its sessions too)
 	const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
 	struct StageRegs {
 		u32x4 in, c;
@@ -557,7 +519,7 @@ DEVI void deblock_rows_body(const Params &p)
 		const int cmx = nact ? nmx : 0;
 		const size_t a = row_mb + cmx;
 		const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
-		wait_analysis(t);
+		wait_analysis(p, aw, t, xerr);
 		if (DO_Y)
 			R.in = *(const u32x4 *)(rec_y + (size_t)(y0 + l) * p.cw + x0);
 		if (DO_C)

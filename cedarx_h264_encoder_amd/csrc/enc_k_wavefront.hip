@@ -405,55 +405,8 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		// (Counting everything in x + 2*y is true too, but it asks the analysis of a P picture to be 3
 		// diagonals per band AHEAD of where the band is -- 52 for the bottom band of a 1080p picture.)
 		const int y0b = r0 + 4 * band;
-		const int diag0 = 2 * y0b;
-		uint32_t inter_seen = p.prog_inter ? 0u : 0x7fffffffu; // diagonals of this frame known to be analysed
+		AnalysisWait aw{p.prog_inter ? 0u : 0x7fffffffu, IDR || (QPM && p.is_idr), y0b, unit, band, nbands}; // (mode 3 serves the IDR pictures of its sessions too)
 		uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
-		auto wait_analysis = [&](int t) { // the macroblocks of step t (and their left / upper neighbours) are analysed
-			// Intra prediction reads UNFILTERED neighbours and deblocking works in place: filtering
-			// (x, y) changes all of it, row 15 and column 15 included, which intra (x+1, y),
-			// (x-1, y+1), (x, y+1) and (x+1, y+1) still need: in an intra picture the deblock
-			// wavefront stays behind the last of them, three more diagonals.
-			const bool idr_pic = IDR || (QPM && p.is_idr); // (mode 3 serves the IDR pictures of its sessions too)
-			const uint32_t need = idr_pic ? (uint32_t)(t + 3 + diag0 + 4)  // x + 2*y: group 3 is 3 diagonals ahead of group 0
-						      : (uint32_t)(t + y0b + 1);       // x + y: all four rows are on t + y0
-			if (inter_seen >= need)
-				return;
-			// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the
-			// intra wavefront publishes per band; this band's rows and the row above them count.
-			const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
-			if (idr_pic && p.prog_intra) { // the band itself, the one above (top rows) and the one below (its consumers)
-				w0 = p.prog_intra + unit * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1);
-				w1 = band > 0 ? w0 - 1 : w0;
-				w2 = band + 1 < nbands && band + 1 < PROG_BANDS ? w0 + 1 : w0;
-			}
-			uint32_t spins = 0;
-			uint64_t t0 = 0;
-			while (true) {
-				const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const uint32_t want = p.prog_tag | need;
-				if ((int32_t)(v0 - want) >= 0 && (int32_t)(v1 - want) >= 0 && (int32_t)(v2 - want) >= 0) {
-					const uint32_t a = v0 & 0xffffu, b = v1 & 0xffffu, c = v2 & 0xffffu;
-					inter_seen = a < b ? (a < c ? a : c) : (b < c ? b : c);
-					break;
-				}
-				// (a 3 us sleep per look: the clock is read every 256th, i.e. every ~0.8 ms)
-				if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-					__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-					__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					inter_seen = 0x7fffffffu;
-					break;
-				}
-				// a kernel that waits for its frame's analysis is resident for a long time, and every
-				// poll is a trip to memory: after a few quick looks, look every ~3 us
-				if (spins < 8)
-					__builtin_amdgcn_s_sleep(16);
-				else
-					__builtin_amdgcn_s_sleep(127);
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		};
 		auto publish_diag = [&](uint32_t d) { // every macroblock of this band with x + 2*y < d is written back
 			if (!my_prog)
 				return;
@@ -488,7 +441,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 			const size_t a = row_mb + cmx;
 			const int x0 = cmx * 16, y0 = (row_ok ? my : r0) * 16;
 			if (t < nsteps)
-				wait_analysis(t);
+				wait_analysis(p, aw, t, xerr);
 			// readiness of the rows above first: its acquire must not sit behind this step's own loads
 			R.top_ok = true;
 			if (xwg_band && mx0 < p.mb_w) { // rows above live in another workgroup

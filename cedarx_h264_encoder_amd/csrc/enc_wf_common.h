@@ -324,4 +324,59 @@ DEVI void edge_codes(const EdgeIn &in, EdgeCarry &cy, const uint64_t *qdb, uint3
 	mvl = mvc;
 }
 
+// ---- a deblock band waits for its frame's analysis (the loading wave of both deblock kernels) ----
+// Frame pipelining: this frame's analysis runs ahead on another stream in diagonal stripes, or -- an IDR picture -- as the
+// intra wavefront, and publishes how far it is. A band of 4 rows sweeps with ONE macroblock of lag per row: at step t its
+// rows are at x + y = t + y0b, which is what a P picture's analysis (stripes of x + y, published by k_gate) is asked
+// for. The intra wavefront needs TWO macroblocks of lag per row (x + 2*y) and publishes per band in that measure; intra
+// prediction reads UNFILTERED neighbours and deblocking works in place, so in an intra picture the deblock wavefront
+// also stays behind (x+1, y+1): three more diagonals. `seen` caches what the analysis was last known to have reached.
+struct AnalysisWait {
+	uint32_t seen;      // diagonals of this frame known to be analysed (0x7fffffff: frames are not pipelined, or a wait ran out)
+	bool idr_pic;       // the picture is all intra: ask the intra wavefront's band words, in x + 2*y
+	int y0b, unit, band, nbands;
+};
+DEVI void wait_analysis(const Params &p, AnalysisWait &a, int t, uint32_t *xerr)
+{
+	const uint32_t need = a.idr_pic ? (uint32_t)(t + 3 + 2 * a.y0b + 4)  // x + 2*y: group 3 is 3 diagonals ahead of group 0
+					: (uint32_t)(t + a.y0b + 1);         // x + y: all four rows are on t + y0b
+	if (a.seen >= need)
+		return;
+	// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the intra wavefront publishes per
+	// band; this band, the one above (its rows above) and the one below (its consumers) count.
+	const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
+	if (a.idr_pic && p.prog_intra) {
+		w0 = p.prog_intra + a.unit * PROG_BANDS + (a.band < PROG_BANDS ? a.band : PROG_BANDS - 1);
+		w1 = a.band > 0 ? w0 - 1 : w0;
+		w2 = a.band + 1 < a.nbands && a.band + 1 < PROG_BANDS ? w0 + 1 : w0;
+	}
+	uint32_t spins = 0;
+	uint64_t t0 = 0;
+	while (true) {
+		const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t want = p.prog_tag | need;
+		if ((int32_t)(v0 - want) >= 0 && (int32_t)(v1 - want) >= 0 && (int32_t)(v2 - want) >= 0) {
+			const uint32_t x = v0 & 0xffffu, y = v1 & 0xffffu, z = v2 & 0xffffu;
+			a.seen = x < y ? (x < z ? x : z) : (y < z ? y : z);
+			break;
+		}
+		// (a 3 us sleep per look: the clock is read every 256th, i.e. every ~0.8 ms)
+		if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			a.seen = 0x7fffffffu;
+			break;
+		}
+		// a kernel that waits for its frame's analysis is resident for a long time, and every poll is a trip to memory:
+		// after a few quick looks, look every ~3 us
+		if (spins < 8)
+			__builtin_amdgcn_s_sleep(16);
+		else
+			__builtin_amdgcn_s_sleep(127);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 } // namespace cedar
