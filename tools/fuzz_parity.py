@@ -112,7 +112,12 @@ for case in range(n_cases):
         enc.flush()
         while q:
             enc.collect(); got.append([enc.output(s) for s in range(S)]); q -= 1
+        st = enc.stats()
     if got != want:
-        sys.exit("MISMATCH seed %d case %d: %dx%d qp %d keyint %d slices %d streams %d pattern %s %s depth %d" % (
-            seed, case, w, h, qp, keyint, slices, S, pat, kw, depth))
+        # (which access unit, and under which schedule: an intermittent mismatch should leave something to go on)
+        where = [(f, s, len(got[f][s]), len(want[f][s])) for f in range(min(len(got), len(want))) for s in range(S) if got[f][s] != want[f][s]]
+        sys.exit("MISMATCH seed %d case %d: %dx%d qp %d keyint %d slices %d streams %d lanes %d pattern %s %s depth %d; %d of %d frames collected, "
+                 "first differing (frame, stream, bytes, oracle's bytes) %s of %d; deblock_rows %s pipelined %s look-ahead %s" % (
+            seed, case, w, h, qp, keyint, slices, S, G, pat, kw, depth, len(got), len(want), where[:3], len(where),
+            st["deblock_rows"], st["frames_pipelined"], st["idr_lookahead"]))
 print("seed %d: %d cases bit-exact in %.0f s" % (seed, n_cases, time.time() - t0))
