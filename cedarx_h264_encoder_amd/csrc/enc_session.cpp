@@ -2553,6 +2553,11 @@ static int mux_submit(cedar_enc *e)
 			int rc2;
 			if ((rc2 = dalloc(e, &m.d_store_y, (size_t)m.cap * m.S * ysz)) || (rc2 = dalloc(e, &m.d_store_uv, (size_t)m.cap * m.S * csz)))
 				return rc2;
+			// dalloc clears what it allocates on the NULL stream, and the session's streams do not wait for that one: the
+			// copy of this very frame below overtook the clear now and then and frame 0 of every stream went into the
+			// encoder partly zeroed (round 3's fuzz: 1 session in ~1000 with IDR look-ahead, 9 in 10 without; CONFIG's
+			// own allocations are followed by a device-wide synchronisation)
+			HIP_TRY(e, hipStreamSynchronize(nullptr));
 		}
 		uint8_t *dy = m.d_store_y + (ring * m.S + s) * ysz, *duv = m.d_store_uv + (ring * m.S + s) * csz;
 		HIP_TRY(e, hipMemcpyAsync(dy, e->h_luma + (size_t)s * ysz, (size_t)e->cfg.src_width * e->cfg.src_height, hipMemcpyHostToDevice, s_in));

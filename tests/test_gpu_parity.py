@@ -882,6 +882,22 @@ def test_rate_control_follows_the_oracle_at_any_depth(ce, w, h, target):
         ce.CedarEncoder(width=w, height=h, qp=30, keyframe_interval=25, bitrate=target, gop_parallel=2, n_streams=2)
 
 
+def test_gop_lanes_first_submit_does_not_race_the_ring_allocation(ce, monkeypatch):
+    """A gop_parallel session fed through the pinned buffers allocates its device-side frame ring at the first submit; the
+    allocator's hipMemset runs on the null stream and the copy of that very frame on a non-blocking one, so the clear
+    could land on top of frame 0 (round 3's fuzz, seed 303 case 72: 1 session in ~1000; without IDR look-ahead 9 in 10).
+    Thirty short sessions of the kind that showed it, look-ahead off: every access unit the oracle's."""
+    monkeypatch.setenv("CEDAR_LOOKAHEAD", "0")
+    w, h, K, G = 32, 16, 5, 6
+    kw = dict(subpel=1, mad_th=[1, 5, 10, 12], mad_dqp=[0, -9, -10, 3, 3])
+    for it in range(30):
+        frames = [ol.gen_frame("C", w, h, f, 31 * it) for f in range(8)]
+        oe = ol.OracleEncoder(ol.default_config(w, h, qp=1, keyint=K, **kw))
+        want = [oe.encode(y, uv) for y, uv in frames]
+        with ce.CedarEncoder(width=w, height=h, qp=1, keyframe_interval=K, gop_parallel=G, **kw) as enc:
+            assert _encode_gop_parallel(enc, frames) == want, it
+
+
 @pytest.mark.parametrize("w,h,keyint,G,target,n", [(320, 240, 6, 2, 5480000, 100), (192, 112, 4, 3, 1480000, 120), (640, 368, 25, 2, 16750000, 160)])
 def test_rate_control_with_gop_lanes_is_a_law_per_group(ce, w, h, keyint, G, target, n):
     """bitrate x gop_parallel (one stream): the later GOPs of a group of G are coded beside the earlier ones, so nothing
