@@ -520,6 +520,7 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 		for (int j = i + 1; j < NP; j++)
 			slow[i][j] = slow[j][i] = slow[i][j] > slow[j][i] ? slow[i][j] : slow[j][i];
 	HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
 	int best[NROLE] = { 0, 1, 2, 3, 5, 6, 4 }, cur[NROLE];
 	double best_cost = 1e30;
 	bool taken[NP] = {};
@@ -1277,6 +1278,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			}
 		}
 		HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
 		const PlanRun run = plan_run(pin, plan, PlanProbe{ usable, e->holds_pipe_token ? 1 : 0 });
 		e->row_pipe = run.row_pipe != 0;
 		e->db_streams = run.db_streams;
@@ -1341,6 +1343,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 				}
 			}
 			HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
 			if (got.size() >= (e->idr_deblock_inline ? 2u : 3u)) {
 				e->s_idr = got[0];
 				e->s_in = got[1];
@@ -2298,6 +2301,7 @@ static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again =
 	for (int l = 0; l < e->ent_lanes; l++)
 		HIP_TRY(e, hipMemset(e->d_stream_size[l], 0, sizeof(uint32_t) * MAX_COHORTS * (e->ext.n_streams + 4)));
 	HIP_TRY(e, hipMemset(e->d_abort_all, 0, sizeof(uint32_t)));
+	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (hipMemset runs on the null stream, which the session's streams do not wait for)
 	for (const ReplayIn &r : later) {
 		const int rc = submit_frame(e, &r);
 		if (rc)
