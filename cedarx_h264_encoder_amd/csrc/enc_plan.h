@@ -172,6 +172,10 @@ inline Plan plan_static(const PlanIn &in)
 	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && (rows_fit || rows_b2b)) : rows_fit || rows_b2b) &&
 		    (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16; // (a progress word per band in the sync region)
 	p.db_lds_kb = rows_fit ? 96 : 16;
+	// (9 to 23 units back to back on it: 6 frames in flight instead of 4 -- 16 x 1080p 160.3 -> 168.6 M MB/s, 8 and 12 no
+	// more; 8 streams, which come out at 8 by the 512 MB rule above, gain nothing from 6, 8 or 12)
+	if (p.db_rows && rows_b2b && n_units > 8 && !set(in.env_pipe_depth) && !set(in.env_row_pipe))
+		p.depth = 6;
 	p.defer_wanted = n_units == 1 && !(set(in.env_defer) && in.env_defer == 0);
 	// (with k_deblock_rows two pictures' deblocking in flight are enough and nothing is held back: 1080p 47.3 M MB/s
 	// with 2 streams, 46.2 with 3 and 3 of 8 stripes held back, 30.9 with 1)

@@ -60,6 +60,7 @@ def test_few_units_deblock_with_a_wave_per_macroblock_row(plan):
                            (dict(w=3840, h=2160, slices=4, streams=2), 1, 0), (dict(w=320, h=240, streams=8), 1, 1), (dict(w=320, h=240, streams=9), 1, 0)):
         r = plan(**kw)
         assert (r.deblock_rows, r.want_row_pipe) == (rows, pipe), kw
+    assert [plan(streams=n).depth for n in (6, 8, 9, 16, 23, 24)] == [10, 8, 6, 6, 6, 4]   # (<= 8 units: the 512 MB ring; 9 .. 23 on this kernel: 6)
     assert plan(deblock_rows=0).deblock_rows == 0 and plan(streams=32, deblock_rows=2).deblock_rows == 1
     assert plan(streams=3, deblock_rows=1).deblock_rows == 0          # (1 = the default rule)
     assert plan(cus=64).deblock_rows == 0 and plan(cus=96).deblock_rows == 1   # 2 x 34 workgroups on 3/4 of the CUs
