@@ -158,7 +158,8 @@ inline Plan plan_static(const PlanIn &in)
 	//   between steps 32 and 48 and the later units' bands not yet started -- the cause is not established (waiting at
 	//   wave priority 0 instead of 3 changes nothing; 3 streams run, at 80 M against 82 with the wave pairs).
 	// * 6 to 23 units, frames BACK TO BACK (nothing resident waits for anything; LDS as the tiles need, 16 KB): 6 streams
-	//   91 -> 104, 8: 107 -> 126, 12: 128 -> 151, 16: 143 -> 161, 24: 163 = 163; one stream as 8 GOP lanes 97 -> 116.
+	//   91 -> 104, 8: 107 -> 130, 12: 128 -> 156, 16: 143 -> 168 (6 frames in flight, below), 24: 163 = 163; one stream as
+	//   8 GOP lanes 97 -> 119.
 	//   Below 6 the wave pairs with pipelined frames win (3: 76 against 64, 4: 89 against 79).
 	// From 24 units on the parallelism is across pictures and the step is the sum of k_inter, deblocking and entropy on
 	// the same VALUs: 32 x 1080p 171.0 with it against 171.5 with k_deblock2_planes' fewer, fatter waves and cohorts.

@@ -206,6 +206,17 @@ def test_hip_cli_gop_parallel_subpel_and_first_frame(tmp_path):
     r = subprocess.run([HIPCLI, "-", str(w), str(h), str(out2)], input=raw[2 * K * fsz:4 * K * fsz], capture_output=True, env=env2, timeout=200)
     assert r.returncode == 0, r.stderr[-500:]
     assert out2.read_bytes() == b"".join(aus[2 * K:4 * K])
+    # rate control with GOP lanes (one QP per group of lanes): both command lines take the same two variables
+    frames3, K3 = 110, 4
+    raw3 = _raw("C", 192, 112, frames3)
+    env3 = dict(os.environ, H264ENC_QP="30", H264ENC_KEYINT=str(K3), H264ENC_BITRATE="1480000", H264ENC_GOP_PARALLEL="3")
+    a, b = tmp_path / "rc_hip.264", tmp_path / "rc_cpu.264"
+    assert subprocess.run([HIPCLI, "-", "192", "112", str(a)], input=raw3, capture_output=True, env=env3, timeout=200).returncode == 0
+    assert subprocess.run([SCALAR, "-", "192", "112", str(b)], input=raw3, capture_output=True, env=env3, timeout=200).returncode == 0
+    assert a.read_bytes() == b.read_bytes()
+    fixed = tmp_path / "fixed.264"
+    assert subprocess.run([SCALAR, "-", "192", "112", str(fixed)], input=raw3, capture_output=True, env=dict(env3, H264ENC_BITRATE="0"), timeout=200).returncode == 0
+    assert fixed.read_bytes() != b.read_bytes()   # (the law did act: 110 frames are 9 groups of 12, it sets in at the sixth)
 
 
 @pytest.mark.gpu
