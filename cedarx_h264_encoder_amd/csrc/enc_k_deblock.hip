@@ -639,12 +639,12 @@ __global__ __launch_bounds__(64 * DBR_WAVES) void k_deblock_rows(Params p)
 int launch_deblock_rows(const Params &p, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
-	// db_rows 2 (few units): enough unused dynamic LDS that a band has its CU to itself -- a filter wave that shares its
-	// SIMD with the waves of k_inter or of the intra wavefront runs at a fraction of its speed, and so do they
+	// db_lds_kb (few units: 96): enough unused dynamic LDS that no second band and no intra workgroup shares the CU -- a
+	// filter wave that shares its SIMD with another band's or with the intra wavefront's runs at a fraction of its speed
 	constexpr size_t lds_min = sizeof(DbrShared<1>) > sizeof(DbrShared<2>) ? sizeof(DbrShared<1>) : sizeof(DbrShared<2>);
 	constexpr size_t lds_alone = 144 * 1024;
 	static_assert(lds_min <= 64 * 1024, "a workgroup's tiles");
-	const size_t lds = (size_t)p.db_rows * 1024 > lds_alone ? lds_alone : (size_t)p.db_rows * 1024 < lds_min ? lds_min : (size_t)p.db_rows * 1024;
+	const size_t want = (size_t)p.db_lds_kb * 1024, lds = want > lds_alone ? lds_alone : want < lds_min ? lds_min : want;
 	static bool attr_set = false;
 	if (!attr_set) {
 		if (hipFuncSetAttribute((const void *)k_deblock_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||

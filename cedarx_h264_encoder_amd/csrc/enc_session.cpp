@@ -1516,7 +1516,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.wf_split = e->wf_split;
 	P.db_pairs = e->db_pairs;
 	P.wf_hb_slots = e->hb_slots;
-	P.db_rows = e->db_rows ? (getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb) : 0; // (KiB of LDS a band claims: see launch_deblock_rows)
+	P.db_rows = e->db_rows ? 1 : 0;
+	P.db_lds_kb = getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb; // (see launch_deblock_rows)
 	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;
 	{
