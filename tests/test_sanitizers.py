@@ -59,3 +59,26 @@ def test_sub_sample_rate_control_and_bit_cap_paths_are_sanitizer_clean(san_tools
     r = subprocess.run([dec, str(out), str(tmp_path / "o.nv12")], capture_output=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
+
+
+def test_group_rate_control_path_is_sanitizer_clean(san_tools, tmp_path):
+    """round 3: the rate control law of GOP lanes (one QP per group, h264o_config.rc_lanes; H264ENC_GOP_PARALLEL on the
+    scalar command line) through the sanitizer build, long enough for the law to act and for its ring of groups to be used."""
+    enc, dec = san_tools
+    w, h, n, K, G = 64, 48, 150, 2, 2
+    clip = b"".join(np.concatenate(ol.gen_frame("CB"[(f // 5) % 2], w, h, f)).tobytes() for f in range(n))
+    out = tmp_path / "o.264"
+    env = dict(os.environ, H264ENC_QP="28", H264ENC_KEYINT=str(K), H264ENC_BITRATE="400000", H264ENC_GOP_PARALLEL=str(G),
+               ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([enc, "-", str(w), str(h), str(out)], input=clip, capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
+    oe = ol.OracleEncoder(ol.default_config(w, h, qp=28, keyint=K, bitrate=400000, rc_lanes=G))
+    want, qps = b"", set()
+    for f in range(n):
+        want += oe.encode(*ol.gen_frame("CB"[(f // 5) % 2], w, h, f))
+        qps.add(oe.frame_qp())
+    assert out.read_bytes() == want and len(qps) > 1     # 37 groups of 4 frames: the ring of 32 wraps, the law sets in at group 9
+    r = subprocess.run([dec, str(out), str(tmp_path / "o.nv12")], capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
