@@ -1309,12 +1309,15 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// milliseconds) and the input of all frames (which must never queue behind that, nor behind
 		// a gate on s_main) -- dealt by assign_stream_roles; each must run beside every stream in use.
 		// The IDR picture's deblocking: on a stream of its own, resident beside the intra wavefront it follows band by
-		// band (k_deblock_rows: 1080p K 300 47.0 -> 48.0 M MB/s, the driver's K 20 34.8 -> 38.3 M: its 0.3 ms no
-		// longer come after the intra kernel's 1.9 ms), or behind it on the same stream (k_deblock2_planes, whose
-		// whole-CU workgroups measured slower beside it: one more queue that blocks a pipe). CEDAR_IDR_DEBLOCK_INLINE.
+		// band (k_deblock_rows, GOPs of 20 pictures and more: 1080p keyint 25, K 300 47.0 -> 48.0 M MB/s, the driver's K 20
+		// 34.8 -> 38.3 M: its 0.3 ms no longer come after the intra kernel's 1.9 ms), or behind it on the same stream --
+		// k_deblock2_planes, whose whole-CU workgroups measured slower beside it (one more queue that blocks a pipe), and
+		// SHORT GOPs on either kernel: the stream that would carry it carries every other IDR picture instead (s_idr2),
+		// and a stream of short GOPs is bound by its IDR pictures (keyint 1 / 4 / 8 / 12: 7.2 / 25.1 / 44.5 / 46.2 M MB/s
+		// behind against 4.1 / 15.1 / 29.3 / 42.2 beside). CEDAR_IDR_DEBLOCK_INLINE.
 		const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
 		e->lookahead = false;
-		e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows;
+		e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows || cfg->keyframe_interval < 20;
 		// (sessions whose frames run back to back take the IDR picture out of line too: nothing polls
 		// there, the P picture after it waits for its events, and with 4 frames in flight it gets a
 		// three-frame head start)
