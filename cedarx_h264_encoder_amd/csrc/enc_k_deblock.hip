@@ -17,12 +17,13 @@
 //   4 filter waves  one per row, one per SIMD; they only touch LDS
 //   stager          stages samples and edge codes 1 step ahead of the filter waves (4 rows in its 4 lane groups, at step
 //                   t group g is at macroblock t - g), with the loads of 5 steps ahead in flight
-//   writer          writes filtered tiles back to memory as the rows finish them, publishes the band's progress
-//   courier         the only one that talks to other workgroups: pushes the bottom rows of the band's last row into the
-//                   write-through hand-off buffer as soon as they are final and raises the band's progress word; polls
-//                   the band above's word and pulls its rows into an LDS ring the filter wave of row 0 reads
+//   writer          writes filtered tiles back to memory as the rows finish them, publishes the band's progress for
+//                   the next frame's analysis, and pushes the bottom rows of the band's last row into the hand-off
+//                   buffer as soon as they are final: 8-byte write-through granules, 4 bytes of samples under the frame's tag
+//   courier         polls those granules of the band above (the payload says itself that it has arrived: no progress
+//                   word) and pulls them into an LDS ring the filter wave of row 0 reads
 // Rows inside a band hand their bottom rows on through LDS (`bot`), one macroblock behind each other; a band follows the
-// band above by that same macroblock plus the courier's two trips through L2 (~3 us), not by steps of its own.
+// band above by that same macroblock plus two trips through L2 (~3 us), not by steps of its own.
 // Luma and chroma are independent given the edge codes: a workgroup filters one plane (chroma: 32 lanes of each wave).
 // Every wait is a bounded spin. Bytes are those of k_deblock2_planes (tests/test_gpu_parity.py runs both).
 //
