@@ -246,6 +246,22 @@ DEVI bool wait_expired(uint32_t spins, uint64_t &t0)
 	return now - t0 > WAIT_LIMIT_TICKS;
 }
 
+// development (CEDAR_DEBUG_HANG): who started / published / finished when, in 100 MHz ticks. One lane calls.
+DEVI void dbg_event(const Params &p, uint32_t code, uint32_t a, uint32_t b)
+{
+	if (!p.dbg_log)
+		return;
+	const uint32_t i = atomicAdd(p.dbg_log, 1u);
+	if (i >= (uint32_t)DBG_LOG_ENTRIES)
+		return;
+	const uint64_t t = __builtin_amdgcn_s_memrealtime();
+	uint32_t *e = p.dbg_log + 4 + 4 * (size_t)i;
+	e[0] = code | a << 8;
+	e[1] = b;
+	e[2] = (uint32_t)t;
+	e[3] = (uint32_t)(t >> 32);
+}
+
 DEVI int mv_bits(int d)
 {
 	int a = iabs(d);

@@ -51,6 +51,7 @@ constexpr int PROG_ALL = 0xffff;     // progress value: everything through
 constexpr int INTER_WAVES = 4;       // macroblocks (waves) per k_inter workgroup: a 1080p picture is workgroup-launch bound at 1
 constexpr int IN_K_STREAMS = 8;     // up to this many streams pass their frame pointers as kernel arguments
 constexpr int DBR_HB_GRANULES = 24;  // k_deblock_rows: 4 luma rows x 4 words + 2 chroma rows x 4 words per macroblock
+constexpr int DBG_LOG_ENTRIES = 16384; // Params::dbg_log
 constexpr int WF_HBUF_GRANULES = 12; // 8-byte granules per macroblock: 4x16 B luma + 2x16 B chroma
 
 // Regions of interest (cedar_enc_config_ext.roi): macroblocks differ in QP, so nothing derived from
@@ -149,6 +150,10 @@ struct Params {
 	int32_t db_bands;                // ... and plane, this many per unit (the bands of the session's tallest slice)
 	uint64_t *db_hbuf;               // [n_units][db_bands][mb_w][DBR_HB_GRANULES] k_deblock_rows: bottom rows of a band for the band below,
 	uint32_t db_tag;                 // ... every 8-byte granule = 4 bytes of samples | this frame's tag << 32 (never 0; the buffer starts zeroed)
+	int32_t ir_rows;                 // 1: intra reconstruction as a wavefront of 4x4 blocks, a wave per macroblock row (k_intra_rows) ...
+	int32_t ir_bands;                // ... a workgroup per band of 4 rows and plane: the bands of the session's tallest slice
+	int32_t ir_lds_kb;               // ... KiB of LDS each claims (as db_lds_kb)
+	uint64_t *ir_hbuf;               // [n_units][2 planes][ir_bands][4 * mb_w] k_intra_rows: the last row of a band for the band below, tagged with db_tag
 	// Frame pipelining (nullptr = frames run back to back). The wavefront kernels sweep the
 	// picture along diagonals (absolute macroblock coordinates), so progress is counted in
 	// diagonals: "every macroblock with s < D is through" -- s = x + y for the deblock kernel and
@@ -160,6 +165,7 @@ struct Params {
 	uint32_t *prog_inter;            // [1] D of this frame's analysis + reconstruction (all streams)
 	uint32_t *prog_db;               // [2][n_units][PROG_BANDS] D of every deblock band written back: luma, then chroma
 	uint32_t *prog_intra;            // [n_units][PROG_BANDS] D of every intra-reconstruction band written back (IDR pictures)
+	uint32_t *prog_intra_c;          // the same for the chroma planes where they are bands of their own (k_intra_rows); nullptr: prog_intra speaks for both
 	const uint32_t *prev_db;         // the previous frame's prog_db (what k_gate waits for)
 	uint32_t prog_tag, prev_tag;
 	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + y < s1 (stripe_s1 <= 0: the whole picture)
@@ -177,6 +183,7 @@ struct Params {
 	uint32_t done_tag;
 	int32_t db_self_reset;
 	int32_t fault_inject;            // tests only (CEDAR_FAULT_INJECT): 1 a deblock mover, 2 an intra mover stops reporting
+	uint32_t *dbg_log;               // development (CEDAR_DEBUG_HANG): [0] entries written, [4 + 4 i ..] { code | a << 8, b, s_memrealtime }; nullptr: off
 	// strides (elements of the respective type)
 	int64_t plane_y_stride, plane_uv_stride; // bytes per stream
 	int32_t unit_mb_cap;             // max macroblocks of one unit
@@ -237,6 +244,7 @@ struct Launch {
 };
 
 int launch_deblock_rows(const Params &p, void *stream); // enc_k_deblock.hip (Launch::deblock when Params::db_rows)
+int launch_intra_rows(const Params &p, void *stream);   // enc_k_intra.hip (Launch::intra_recon when Params::ir_rows)
 
 // host-built table for the 4x4 intra predictors: entry = kind<<4 | k
 // kind 0 copy E[k], 1 (E[k]+E[k+1]+1)>>1, 2 (E[k-1]+2E[k]+E[k+1]+2)>>2, 3 DC

@@ -215,6 +215,8 @@ DEVI void deblock_rows_body(const Params &p)
 		return;
 	uint32_t *xabort = sync + 1, *xerr = p.wf_err;
 	const WaitCtx xw{xerr, &S.abort, xabort};
+	if (threadIdx.x == 0)
+		dbg_event(p, 5, p.db_tag, (uint32_t)band | (uint32_t)PL << 8 | (uint32_t)unit << 16);
 	const bool feeds_next = band + 1 < nbands; // the last 4 rows of the band's row 3 are stored by whoever filters below
 	const bool from_above = band > 0;          // row 0 takes the rows above it from the band above
 
@@ -494,13 +496,15 @@ DEVI void deblock_rows_body(const Params &p)
 		if (feeds_next)
 			push(p.mb_w - 1); // (nothing to its right patches it)
 		publish_diag((uint32_t)PROG_ALL);
+		if (lane == 0)
+			dbg_event(p, 6, p.db_tag, (uint32_t)band | (uint32_t)PL << 8 | (uint32_t)unit << 16);
 		return;
 	}
 
 	// ============================== stager ==============================
 	const uint32_t cod_y = (0x80u | p.tc0_y[0]) << 8 | (0x80u | p.tc0_y[1]) << 16 | (0x80u | p.tc0_y[2]) << 24;
 	const uint32_t cod_c = (0x80u | p.tc0_c[0]) << 8 | (0x80u | p.tc0_c[1]) << 16 | (0x80u | p.tc0_c[2]) << 24;
-	AnalysisWait aw{p.prog_inter ? 0u : 0x7fffffffu, IDR || (QPM && p.is_idr), y0b, unit, band, nbands}; // (mode 3 serves the IDR pictures of its sessions too)
+	AnalysisWait aw{p.prog_inter ? 0u : 0x7fffffffu, IDR || (QPM && p.is_idr), y0b, unit, band, nbands, PL}; // (mode 3 serves the IDR pictures of its sessions too)
 	const size_t row_mb = (size_t)st * p.n_mb + (size_t)(row_ok ? my : r0) * p.mb_w;
 	struct StageRegs {
 		u32x4 in, c;

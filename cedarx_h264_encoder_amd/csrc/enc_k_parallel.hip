@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void k_input(Params p)
 	// kernel's own stream
 	if (blockIdx.y == 0 && st == 0 && seg == 0 && p.cut_votes) // scene cuts: this frame's count starts at zero
 		p.cut_votes[0] = 0;
-	if (blockIdx.y == 0 && st == 0 && p.wf_split_intra > 1) {
+	if (blockIdx.x == 0 && blockIdx.y == 0 && st == 0 && threadIdx.x == 0)
+		dbg_event(p, 1, p.db_tag, 0);
+	if (blockIdx.y == 0 && st == 0 && (p.wf_split_intra > 1 || p.ir_rows)) {
 		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
 		for (int i = seg; i < used; i += gridDim.x * blockDim.x)
 			p.wf_sync[i] = 0;
@@ -286,6 +288,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		dbg_event(p, 9, p.db_tag, (uint32_t)p.stripe_s0);
 	uint8_t *const arena = sa_arena[wave];
 	uint8_t *const s_ref = arena + IA_REF, *const s_cur = arena + IA_CUR, *const s_curc = arena + IA_CURC;
 	uint8_t *const s_s8 = arena + IA_U;                              // search only
@@ -1011,6 +1015,8 @@ int Launch::inter(const Params &p, void *stream, int n_mbs)
 __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d)
 {
 	const int lane = threadIdx.x;
+	if (lane == 0)
+		dbg_event(p, 7, p.db_tag, (uint32_t)(publish_d & 0xffff) | (uint32_t)need_d << 16);
 	if (lane == 0 && publish_d >= 0 && p.prog_inter) // the launches before this one have completed (stream order)
 		__hip_atomic_store(p.prog_inter, p.prog_tag | (uint32_t)publish_d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	if (need_d <= 0 || !p.prev_db)
@@ -1048,6 +1054,8 @@ __global__ __launch_bounds__(64) void k_gate(Params p, int publish_d, int need_d
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	if (lane == 0)
+		dbg_event(p, 8, p.db_tag, (uint32_t)need_d);
 }
 
 // k_copy_out: the frame's bitstreams (compact, all streams back to back) and their sizes go
@@ -1201,6 +1209,8 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 	__shared__ __attribute__((aligned(16))) int16_t s_lv[24][16]; // ... and the open loop's levels, zig-zag
 
 	const int lane = threadIdx.x;
+	if (blockIdx.x == 0 && lane == 0)
+		dbg_event(p, 2, p.db_tag, 0);
 	int mx, my, st;
 	xcd_mb(p, mx, my, st);
 	const int x0 = mx * 16, y0 = my * 16;

@@ -405,7 +405,7 @@ DEVI void deblock2_body(const Params &p, const int wg)
 		// (Counting everything in x + 2*y is true too, but it asks the analysis of a P picture to be 3
 		// diagonals per band AHEAD of where the band is -- 52 for the bottom band of a 1080p picture.)
 		const int y0b = r0 + 4 * band;
-		AnalysisWait aw{p.prog_inter ? 0u : 0x7fffffffu, IDR || (QPM && p.is_idr), y0b, unit, band, nbands}; // (mode 3 serves the IDR pictures of its sessions too)
+		AnalysisWait aw{p.prog_inter ? 0u : 0x7fffffffu, IDR || (QPM && p.is_idr), y0b, unit, band, nbands, PL}; // (mode 3 serves the IDR pictures of its sessions too)
 		uint32_t *const my_prog = p.prog_db ? p.prog_db + ((PL == 2 ? p.n_streams * p.slice_num : 0) + unit) * PROG_BANDS + (band < PROG_BANDS ? band : PROG_BANDS - 1) : nullptr;
 		auto publish_diag = [&](uint32_t d) { // every macroblock of this band with x + 2*y < d is written back
 			if (!my_prog)
@@ -1484,6 +1484,8 @@ int Launch::deblock(const Params &p, void *stream, int planes)
 
 int Launch::intra_recon(const Params &p, void *stream)
 {
+	if (p.ir_rows)
+		return launch_intra_rows(p, stream);
 	dim3 grid(p.n_streams * p.slice_num * p.wf_split_intra);
 	// wavefront workgroups are throughput-bound on their CU: enough (unused dynamic) LDS that
 	// two of them can never share one CU (160 KiB per CU)

@@ -12,6 +12,8 @@
 
 namespace cedar {
 
+constexpr int PLAN_UNSET_INIT = -2147483647 - 1;
+
 struct PlanIn {
 	int mb_w, mb_h;
 	int slice_count, slice_first, slice_num;
@@ -21,8 +23,10 @@ struct PlanIn {
 	// development switches (CEDAR_*): INT32_MIN = not set
 	int env_row_pipe, env_pipe_depth, env_wf_split, env_wf_split_intra, env_db_pairs, env_deblock_streams,
 	    env_deblock_planes, env_inter_bands, env_defer, env_cohorts, env_deblock_rows;
+	int env_intra_rows = PLAN_UNSET_INIT; // CEDAR_INTRA_ROWS
+	int mb_qp = 0;          // the session's macroblocks differ in QP (regions of interest, MAD classes, rate control over several streams)
 };
-constexpr int PLAN_UNSET = -2147483647 - 1;
+constexpr int PLAN_UNSET = PLAN_UNSET_INIT;
 constexpr int CEDAR_PLAN_MAX_DEPTH = 16; // = CEDAR_ENC_PIPELINE_DEPTH of the public header (asserted in enc_session.cpp)
 
 struct Plan {
@@ -37,6 +41,9 @@ struct Plan {
 	int db_rows;            // deblocking with a wave per macroblock row (k_deblock_rows), a workgroup per band of 4 rows and plane
 	int db_bands;           // ... bands of the tallest slice = its workgroups per unit and plane
 	int db_lds_kb;          // ... KiB of LDS a workgroup claims: 96 = no second band on its CU, 16 = what its tiles take
+	int ir_rows;            // intra reconstruction as a wavefront of 4x4 blocks, a wave per macroblock row (k_intra_rows)
+	int ir_lds_kb;          // ... KiB of LDS a band claims (its bands are db_bands); 0: what it needs
+	int idr_beside_ok;      // an IDR picture's deblocking may be resident beside its intra wavefront (a third picture of deblock workgroups)
 };
 
 struct PlanProbe {
@@ -167,12 +174,37 @@ inline Plan plan_static(const PlanIn &in)
 	int nb_lo, nb_hi;
 	plan_band_range(in, nb_lo, nb_hi);
 	p.db_bands = nb_hi;
-	const int wgs2 = 2 * 2 * n_units * nb_hi; // workgroups of two pictures, both planes
-	const bool rows_fit = n_units <= 8 && wgs2 <= in.cus * 3 / 4;
+	// Which intra kernel. k_intra_rows steps in 4x4 blocks, a wave per macroblock row (enc_k_intra.hip): a 1080p I picture
+	// is ~1150 block times instead of 254 macroblock times of ten blocks each. Sessions whose macroblocks differ in QP keep
+	// k_intra_recon2 (the chain waves hold the quantiser of the picture in registers); so do pictures wider than 4480
+	// samples (its row buffers must leave room for a deblock workgroup on the same CU, below). CEDAR_INTRA_ROWS=0: never.
+	p.ir_rows = (set(in.env_intra_rows) ? in.env_intra_rows != 0 : 1) && !in.mb_qp && in.mb_w <= 280 && (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16;
+	p.ir_lds_kb = 0;
+	// WHO MAY BE RESIDENT AND WAITING. A pipelined deblock kernel sits on its CUs and polls until its picture's analysis
+	// comes; what it waits for -- the analysis of its picture, behind it the deblocking of the picture before, behind that
+	// an IDR picture's intra wavefront -- must find room whatever is resident. The hardware deals the workgroups of a launch
+	// round-robin over the 8 XCDs and each XCD places its share IN ORDER on its own 32 CUs: a launch stalls as soon as ONE
+	// of its workgroups finds no room in ITS XCD, however empty the rest of the chip is. (Round 3's "cause not established"
+	// hang of 4 to 8 pipelined 1080p streams, and the one session in ten of 3840x2160 that ended in -EIO after 3 s in round 4:
+	// three pictures of 72 deblock workgroups claiming a CU each, then 72 intra workgroups claiming a CU each -- 288 on 256.
+	// tools/dev/hang_hunt2.sh, the device's own log under CEDAR_DEBUG_HANG.) So, for sessions that pipeline on this kernel:
+	//   * a band claims 81 KB of LDS: never two bands on a CU (a filter wave that shares its SIMD with another band's runs
+	//     at a fraction of its speed), but always room for ONE intra workgroup (k_intra_rows: what it needs, <= 79 KB, one per
+	//     CU by its registers), or two k_inter workgroups, beside it;
+	//   * the deblock workgroups of the pictures that can be resident at a time -- one per deblock stream, and a third when an
+	//     IDR picture's deblocking runs beside its intra wavefront -- are counted PER XCD, each launch rounded up, and must
+	//     leave two CUs of every XCD alone; k_intra_recon2's workgroups (which share a CU with nobody) count as well.
+	const int W_db = 2 * n_units * nb_hi; // deblock workgroups of a picture, both planes
+	const int xcd_cus = in.cus / 8;
+	auto px = [](int w) { return (w + 7) / 8; };
+	const int old_intra = p.ir_rows ? 0 : px(n_units * p.wf_split_intra);
+	const int wgs2 = 2 * W_db; // workgroups of two pictures
+	const bool rows_fit = n_units <= 8 && wgs2 <= in.cus * 3 / 4 && 2 * px(W_db) + old_intra <= xcd_cus - 2;
+	p.idr_beside_ok = rows_fit && 3 * px(W_db) + old_intra <= xcd_cus - 2;
 	const bool rows_b2b = !rows_fit && n_units >= 6 && n_units < 24;
 	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && (rows_fit || rows_b2b)) : rows_fit || rows_b2b) &&
 		    (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16; // (a progress word per band in the sync region)
-	p.db_lds_kb = rows_fit ? 96 : 16;
+	p.db_lds_kb = rows_fit ? 81 : 16;
 	// (9 to 23 units back to back on it: 6 frames in flight instead of 4 -- 16 x 1080p 160.3 -> 168.6 M MB/s, 8 and 12 no
 	// more; 8 streams, which come out at 8 by the 512 MB rule above, gain nothing from 6, 8 or 12)
 	if (p.db_rows && rows_b2b && n_units > 8 && !set(in.env_pipe_depth) && !set(in.env_row_pipe))

@@ -19,6 +19,7 @@
 
 #include <sched.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -289,9 +290,11 @@ struct cedar_enc {
 	uint8_t *d_out[CEDAR_ENC_PIPELINE_DEPTH] = {}; // compact bytestreams, one per frame in flight
 	uint8_t *d_pred4 = nullptr;
 	uint32_t *d_abort_all = nullptr; // Params::abort_all
+	uint32_t *d_dbg_log = nullptr;   // Params::dbg_log (CEDAR_DEBUG_HANG)
 	uint32_t *d_wf_sync[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint64_t *d_wf_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {};
 	uint64_t *d_db_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {}; // k_deblock_rows: tagged bottom rows, band to band
+	uint64_t *d_ir_hbuf[CEDAR_ENC_PIPELINE_DEPTH] = {}; // k_intra_rows: tagged last rows, band to band, both planes
 	uint8_t *d_dummy_rec = nullptr;  // 24 rows: what idle k_inter waves reconstruct into
 	uint32_t *d_stripe_tab = nullptr; // [inter_bands][row_num + 1] running macroblock counts of the diagonal stripes
 	std::vector<int> stripe_s;        // [inter_bands + 1] stripe boundaries (diagonals)
@@ -307,6 +310,8 @@ struct cedar_enc {
 	bool db_rows = true;   // deblocking with a wave per macroblock row (k_deblock_rows); CEDAR_DEBLOCK_ROWS=0: the band-pair kernel
 	int db_bands = 1;      // ... its workgroups per unit and plane: the bands of 4 rows of the tallest slice
 	int db_lds_kb = 16;    // ... KiB of LDS each claims
+	bool ir_rows = true;   // intra reconstruction as a wavefront of 4x4 blocks (k_intra_rows); CEDAR_INTRA_ROWS=0: k_intra_recon2
+	int ir_lds_kb = 16;
 	int hb_slots = WF_MAX_SPLIT - 1; // workgroup boundaries per unit the hand-off buffers have room for
 	// Pipelined P pictures: the last stripes of a picture's analysis (from defer_from on), its final gate
 	// and its entropy launches are held back and enqueued BETWEEN the first stripes of the next picture:
@@ -423,13 +428,13 @@ void free_all(cedar_enc *e)
 	for (int i = 0; i < CEDAR_ENC_PIPELINE_DEPTH; i++) {
 		F(e->d_src_y[i]); F(e->d_src_uv[i]); F(e->d_mbi[i]); F(e->d_i4[i]); F(e->d_nnz[i]); F(e->d_coef[i]);
 		F(e->d_qp_eff[i]); F(e->d_qp_t[i]);
-		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_db_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
+		F(e->d_wf_sync[i]); F(e->d_wf_hbuf[i]); F(e->d_db_hbuf[i]); F(e->d_ir_hbuf[i]); F(e->d_prog[i]); F(e->d_out[i]);
 	}
 	for (int l = 0; l < ENT_LANES; l++) {
 		F(e->d_slot[l]); F(e->d_mb_bits[l]); F(e->d_skip[l]); F(e->d_bit_off[l]); F(e->d_run[l]); F(e->d_unit_bits[l]);
 		F(e->d_rbsp[l]); F(e->d_esc[l]); F(e->d_nal_off[l]); F(e->d_nal_size[l]); F(e->d_stream_size[l]);
 	}
-	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab); F(e->d_abort_all);
+	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab); F(e->d_abort_all); F(e->d_dbg_log);
 	for (uint32_t *v : e->d_cut_votes)
 		F(v);
 	if (e->mux) {
@@ -909,10 +914,12 @@ static PlanIn plan_input(int mb_w, int mb_h, int slice_count, int slice_first, i
 {
 	auto env = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : PLAN_UNSET; };
 	const long long slot = (long long)mb_w * mb_h * 1024 + 4096;
-	return PlanIn{ mb_w, mb_h, slice_count, slice_first, slice_num, n_streams, cus, (int)(slot < (1ll << 20) ? (1ll << 20) : slot),
-		       env("CEDAR_ROW_PIPE"), env("CEDAR_PIPE_DEPTH"), env("CEDAR_WF_SPLIT"), env("CEDAR_WF_SPLIT_INTRA"), env("CEDAR_DB_PAIRS"),
-		       env("CEDAR_DEBLOCK_STREAMS"), env("CEDAR_DEBLOCK_PLANES"), env("CEDAR_INTER_BANDS"), env("CEDAR_DEFER"), env("CEDAR_COHORTS"),
-		       env("CEDAR_DEBLOCK_ROWS") };
+	PlanIn in{ mb_w, mb_h, slice_count, slice_first, slice_num, n_streams, cus, (int)(slot < (1ll << 20) ? (1ll << 20) : slot),
+		   env("CEDAR_ROW_PIPE"), env("CEDAR_PIPE_DEPTH"), env("CEDAR_WF_SPLIT"), env("CEDAR_WF_SPLIT_INTRA"), env("CEDAR_DB_PAIRS"),
+		   env("CEDAR_DEBLOCK_STREAMS"), env("CEDAR_DEBLOCK_PLANES"), env("CEDAR_INTER_BANDS"), env("CEDAR_DEFER"), env("CEDAR_COHORTS"),
+		   env("CEDAR_DEBLOCK_ROWS") };
+	in.env_intra_rows = env("CEDAR_INTRA_ROWS");
+	return in;
 }
 
 extern "C" int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar_enc_plan_result *r)
@@ -1043,7 +1050,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	static_assert(CEDAR_PLAN_MAX_DEPTH == CEDAR_ENC_PIPELINE_DEPTH, "enc_plan.h");
 	int cus = 0;
 	HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-	const PlanIn pin = plan_input(P.mb_w, P.mb_h, P.slice_count, ext.slice_first, ext.slice_num, S, cus);
+	PlanIn pin = plan_input(P.mb_w, P.mb_h, P.slice_count, ext.slice_first, ext.slice_num, S, cus);
+	pin.mb_qp = e->mb_qp ? 1 : 0;
 	const Plan plan = plan_static(pin);
 	if (plan.error)
 		return fail(e, -EINVAL, "picture too tall for the deblock wavefront");
@@ -1187,6 +1195,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
 	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
+	if (getenv("CEDAR_DEBUG_HANG") && (rc = dalloc(e, &e->d_dbg_log, (size_t)4 + 4 * DBG_LOG_ENTRIES))) return rc;
 	for (int i = 0; i < e->depth && ext.scene_cut > 0; i++)
 		if ((rc = dalloc(e, &e->d_cut_votes[i], (size_t)4))) return rc;
 	e->wf_split = plan.wf_split;
@@ -1196,6 +1205,8 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	e->db_lds_kb = plan.db_lds_kb;
 	e->db_bands = plan.db_bands;
 	e->hb_slots = std::max(WF_MAX_SPLIT - 1, e->db_rows ? e->db_bands - 1 : 0);
+	e->ir_rows = plan.ir_rows != 0;
+	e->ir_lds_kb = plan.ir_lds_kb;
 	for (int i = 0; i < e->depth; i++) {
 		if ((rc = dalloc(e, &e->d_wf_sync[i], (size_t)MAX_COHORTS * 3 * WF_SYNC_WORDS))) return rc; // per cohort
 		if ((rc = dalloc(e, &e->d_wf_hbuf[i], (size_t)2 * n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES))) return rc; // deblock, intra
@@ -1204,8 +1215,13 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			if ((rc = dalloc(e, &e->d_db_hbuf[i], n_hb))) return rc;
 			HIP_TRY(e, hipMemset(e->d_db_hbuf[i], 0, n_hb * sizeof(uint64_t)));
 		}
-		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 3 * n_units * PROG_BANDS))) return rc;
-		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 3 * (size_t)n_units * PROG_BANDS)));
+		if (e->ir_rows) { // (tagged like db_hbuf)
+			const size_t n_hb = (size_t)n_units * 2 * e->db_bands * 4 * mb_w;
+			if ((rc = dalloc(e, &e->d_ir_hbuf[i], n_hb))) return rc;
+			HIP_TRY(e, hipMemset(e->d_ir_hbuf[i], 0, n_hb * sizeof(uint64_t)));
+		}
+		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 4 * n_units * PROG_BANDS))) return rc;
+		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 4 * (size_t)n_units * PROG_BANDS)));
 	}
 	{
 		e->prev_slot = e->prev2_slot = -1;
@@ -1317,7 +1333,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		// behind against 4.1 / 15.1 / 29.3 / 42.2 beside). CEDAR_IDR_DEBLOCK_INLINE.
 		const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
 		e->lookahead = false;
-		e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows || cfg->keyframe_interval < 20;
+		e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows || cfg->keyframe_interval < 20 || !plan.idr_beside_ok;
 		// (sessions whose frames run back to back take the IDR picture out of line too: nothing polls
 		// there, the P picture after it waits for its events, and with 4 frames in flight it gets a
 		// three-frame head start)
@@ -1504,6 +1520,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.prefix_len = nullptr;
 	P.pred4_tab = e->d_pred4;
 	P.abort_all = e->d_abort_all;
+	P.dbg_log = e->d_dbg_log;
 	P.wf_sync = e->d_wf_sync[0];
 	P.wf_hbuf = e->d_wf_hbuf[0];
 	P.db_hbuf = e->d_db_hbuf[0];
@@ -1512,6 +1529,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.prog_inter = nullptr;
 	P.prog_db = nullptr;
 	P.prog_intra = nullptr;
+	P.prog_intra_c = nullptr;
 	P.prev_db = nullptr;
 	P.stripe_s0 = 0;
 	P.stripe_s1 = 0;
@@ -1523,6 +1541,10 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.db_lds_kb = getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb; // (see launch_deblock_rows)
 	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;
+	P.ir_rows = e->ir_rows ? 1 : 0;
+	P.ir_bands = e->db_bands;
+	P.ir_lds_kb = getenv("CEDAR_INTRA_LDS_KB") ? std::max(0, atoi(getenv("CEDAR_INTRA_LDS_KB"))) : e->ir_lds_kb; // (see launch_intra_rows)
+	P.ir_hbuf = e->d_ir_hbuf[0];
 	{
 		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO
 		P.fault_inject = env ? atoi(env) : 0;
@@ -1683,6 +1705,8 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	if (Q.db_hbuf)
 		Q.db_hbuf += u0 * e->db_bands * P.mb_w * DBR_HB_GRANULES;
 	Q.wf_hbuf_intra += u0 * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
+	if (Q.ir_hbuf)
+		Q.ir_hbuf += u0 * 2 * e->db_bands * 4 * P.mb_w;
 	return Q;
 }
 
@@ -1874,6 +1898,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.wf_sync = e->d_wf_sync[ds];
 	P.wf_hbuf = e->d_wf_hbuf[ds];
 	P.db_hbuf = e->d_db_hbuf[ds];
+	P.ir_hbuf = e->d_ir_hbuf[ds];
 	P.db_tag = seq;
 	P.wf_hbuf_intra = e->d_wf_hbuf[ds] + (size_t)S * e->ext.slice_num * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
 	P.out = e->d_out[ds];
@@ -1883,6 +1908,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		P.prog_inter = e->d_prog[ds];
 		P.prog_db = e->d_prog[ds] + 16;
 		P.prog_intra = e->d_prog[ds] + 16 + 2 * (size_t)S * e->ext.slice_num * PROG_BANDS;
+		P.prog_intra_c = e->ir_rows ? e->d_prog[ds] + 16 + 3 * (size_t)S * e->ext.slice_num * PROG_BANDS : nullptr;
 		P.prev_db = prev >= 0 ? e->d_prog[prev] + 16 : nullptr;
 		P.prog_tag = seq << 16;
 		P.prev_tag = prev >= 0 ? e->slot_tag[prev] : 0;
@@ -2069,7 +2095,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			if (!pipe)
 				HIP_TRY(e, hipStreamWaitEvent(s_dbc, e->ev_analysis[ei], 0));
 			if (db_late) // same stream: everything is there when the kernel starts, nothing to poll
-				Pc.prog_intra = nullptr;
+				Pc.prog_intra = Pc.prog_intra_c = nullptr;
 			// Pipelined: ONE packet on the deblock stream per frame -- every packet queued behind a
 			// resident kernel costs the hardware pipe ~20 us. The kernel's last workgroup zeroes the
 			// sync words for the slot's next frame and raises the frame's done flag itself.
@@ -2364,6 +2390,52 @@ static int collect_frame(cedar_enc *e)
 		too_big = too_big || sz[n] > (size_t)n * e->stream_out_cap;
 	}
 	const uint32_t wf_err = *f.h_wf_err;
+	if (wf_err && getenv("CEDAR_DEBUG_HANG")) { // development: what the progress and ticket words say when a hand-off timed out
+		hipDeviceSynchronize();
+		const int n_units = S * e->ext.slice_num;
+		std::vector<uint32_t> w((size_t)16 + 4 * n_units * PROG_BANDS), sy((size_t)3 * WF_SYNC_WORDS);
+		fprintf(stderr, "HANG: wf_err %u, frame idr %d, seq/tag %u, ds %d, h_done %u %u, frames in flight behind it %d, frame_count %d\n", wf_err, (int)f.idr, f.done_tag, f.ds,
+			f.h_done[0], f.h_done[1], e->fl_count, e->frame_count);
+		uint32_t ab[8] = {};
+		if (hipMemcpy(ab, e->d_abort_all, sizeof(ab), hipMemcpyDeviceToHost) == hipSuccess)
+			fprintf(stderr, " first wait that ran out: band %u planes %u idr %u unit %u | need %u saw %08x %08x %08x at step %u, tag %08x | %dx%d mb, db_bands %d\n", (ab[1] - 1) & 0xff, (ab[1] >> 8) & 15,
+				(ab[1] >> 12) & 1, ab[1] >> 16, ab[2], ab[3], ab[4], ab[5], ab[6], ab[7], e->P.mb_w, e->P.mb_h, e->db_bands);
+		if (e->d_dbg_log) { // the device's own account: code, frame tag, argument, microseconds since the first entry
+			std::vector<uint32_t> lg((size_t)4 + 4 * DBG_LOG_ENTRIES);
+			if (hipMemcpy(lg.data(), e->d_dbg_log, lg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+				const size_t n = std::min<size_t>(lg[0], DBG_LOG_ENTRIES);
+				std::vector<std::array<uint64_t, 3>> ev;
+				for (size_t i = 0; i < n; i++)
+					ev.push_back({ (uint64_t)lg[4 + 4 * i + 2] | (uint64_t)lg[4 + 4 * i + 3] << 32, lg[4 + 4 * i], lg[4 + 4 * i + 1] });
+				std::sort(ev.begin(), ev.end());
+				static const char *const names[12] = { "?", "input", "intra_decide", "intra_rows start", "intra_rows end", "deblock start", "deblock end", "gate start",
+								       "gate end", "inter", "?", "?" };
+				fprintf(stderr, " device log, %zu entries (us since the first | event | frame tag | argument):\n", n);
+				for (size_t i = 0; i < n; i++) {
+					const uint32_t code = (uint32_t)ev[i][1] & 0xff, tag = (uint32_t)ev[i][1] >> 8, arg = (uint32_t)ev[i][2];
+					if (code == 3 || code == 4 || code == 5 || code == 6) {
+						if ((arg & 0xff) != 0 && (arg & 0xff) != (uint32_t)e->db_bands - 1 && (arg & 0xff) != (uint32_t)e->db_bands / 2)
+							continue; // (first, middle and last band of a picture say enough)
+					}
+					fprintf(stderr, "  %10.1f %-16s tag %3u arg %08x\n", (double)(ev[i][0] - ev[0][0]) / 100.0, names[code < 12 ? code : 0], tag, arg);
+				}
+			}
+		}
+		for (int k = 0; k < e->depth; k++) {
+			if (hipMemcpy(w.data(), e->d_prog[k], w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sy.data(), e->d_wf_sync[k], sy.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+				break;
+			fprintf(stderr, " slot %2d%s tag %08x: inter %08x | db_y", k, k == f.ds ? "*" : " ", e->slot_tag[k], w[0]);
+			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + b]);
+			fprintf(stderr, " | db_c");
+			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + n_units * PROG_BANDS + b]);
+			fprintf(stderr, " | intra_y");
+			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + 2 * n_units * PROG_BANDS + b]);
+			fprintf(stderr, " | intra_c");
+			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + 3 * n_units * PROG_BANDS + b]);
+			fprintf(stderr, " | sync0 %u %u %u %u sync1 %u %u %u sync2 %u %u %u\n", sy[0], sy[1], sy[2], sy[3], sy[WF_SYNC_WORDS], sy[WF_SYNC_WORDS + 1], sy[WF_SYNC_WORDS + 2],
+				sy[2 * WF_SYNC_WORDS], sy[2 * WF_SYNC_WORDS + 1], sy[2 * WF_SYNC_WORDS + 2]);
+		}
+	}
 	// Scene cut (cedar_enc_config_ext.scene_cut): enough macroblocks of this P picture said their own mean predicts them
 	// better than the best vector: the picture is coded again as an IDR picture that starts a new GOP, and the frames
 	// submitted behind it after it -- the machinery of a failed frame, with the frame itself put back first.

@@ -335,6 +335,7 @@ struct AnalysisWait {
 	uint32_t seen;      // diagonals of this frame known to be analysed (0x7fffffff: frames are not pipelined, or a wait ran out)
 	bool idr_pic;       // the picture is all intra: ask the intra wavefront's band words, in x + 2*y
 	int y0b, unit, band, nbands;
+	int planes = 3;     // what the waiting workgroup filters: 1 luma, 2 chroma, 3 both (k_intra_rows publishes the planes apart)
 };
 DEVI void wait_analysis(const Params &p, AnalysisWait &a, int t, uint32_t *xerr)
 {
@@ -345,18 +346,30 @@ DEVI void wait_analysis(const Params &p, AnalysisWait &a, int t, uint32_t *xerr)
 	// P pictures: one word, the analysis runs in whole diagonal stripes. IDR pictures: the intra wavefront publishes per
 	// band; this band, the one above (its rows above) and the one below (its consumers) count.
 	const uint32_t *w0 = p.prog_inter, *w1 = p.prog_inter, *w2 = p.prog_inter;
+	// (k_intra_rows: luma and chroma are wavefronts of their own; a workgroup that filters both planes asks both)
+	const bool two = a.idr_pic && p.prog_intra && p.prog_intra_c && a.planes == 3;
+	const ptrdiff_t cdist = two ? p.prog_intra_c - p.prog_intra : 0;
 	if (a.idr_pic && p.prog_intra) {
-		w0 = p.prog_intra + a.unit * PROG_BANDS + (a.band < PROG_BANDS ? a.band : PROG_BANDS - 1);
+		const uint32_t *base = p.prog_intra_c && a.planes == 2 ? p.prog_intra_c : p.prog_intra;
+		w0 = base + a.unit * PROG_BANDS + (a.band < PROG_BANDS ? a.band : PROG_BANDS - 1);
 		w1 = a.band > 0 ? w0 - 1 : w0;
 		w2 = a.band + 1 < a.nbands && a.band + 1 < PROG_BANDS ? w0 + 1 : w0;
 	}
 	uint32_t spins = 0;
 	uint64_t t0 = 0;
 	while (true) {
-		const uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		uint32_t v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		uint32_t v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		uint32_t v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const uint32_t want = p.prog_tag | need;
+		if (two) { // the lesser of the two planes' words (same tag or an older one: compared as distances from `want`)
+			const uint32_t c0 = __hip_atomic_load(w0 + cdist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t c1 = __hip_atomic_load(w1 + cdist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t c2 = __hip_atomic_load(w2 + cdist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			v0 = (int32_t)(c0 - want) < (int32_t)(v0 - want) ? c0 : v0;
+			v1 = (int32_t)(c1 - want) < (int32_t)(v1 - want) ? c1 : v1;
+			v2 = (int32_t)(c2 - want) < (int32_t)(v2 - want) ? c2 : v2;
+		}
 		if ((int32_t)(v0 - want) >= 0 && (int32_t)(v1 - want) >= 0 && (int32_t)(v2 - want) >= 0) {
 			const uint32_t x = v0 & 0xffffu, y = v1 & 0xffffu, z = v2 & 0xffffu;
 			a.seen = x < y ? (x < z ? x : z) : (y < z ? y : z);
@@ -365,6 +378,15 @@ DEVI void wait_analysis(const Params &p, AnalysisWait &a, int t, uint32_t *xerr)
 		// (a 3 us sleep per look: the clock is read every 256th, i.e. every ~0.8 ms)
 		if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
 			__hip_atomic_store(xerr, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			// (development, CEDAR_DEBUG_HANG: the first wait that runs out says where it stood)
+			if ((threadIdx.x & 63) == 0 && atomicCAS(p.abort_all + 1, 0u, 1u + (uint32_t)a.band + ((uint32_t)a.planes << 8) + ((uint32_t)a.idr_pic << 12) + ((uint32_t)a.unit << 16)) == 0u) {
+				p.abort_all[2] = need;
+				p.abort_all[3] = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				p.abort_all[4] = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				p.abort_all[5] = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				p.abort_all[6] = (uint32_t)t;
+				p.abort_all[7] = p.prog_tag;
+			}
 			__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			a.seen = 0x7fffffffu;
 			break;

@@ -1,0 +1,12 @@
+# runs a bench configuration until a run fails with a timed-out hand-off; the session dumps its progress words (CEDAR_DEBUG_HANG)
+# usage: hang_hunt.sh <runs> <bench args...>
+cd $GRAFT_REPO_ROOT
+n=0; runs=${1:-40}; shift
+for i in $(seq 1 $runs); do
+  t0=$SECONDS
+  CEDAR_DEBUG_HANG=1 timeout -k 10 100 python3 bench.py --cpu-frames 0 --batched-streams 0 --gop-parallel 0 --other-configs 0 "$@" > gpurun_out/hh.json 2> gpurun_out/hh.err
+  rc=$?
+  echo "run $i rc $rc wall $((SECONDS - t0)) s"
+  if [ $rc -ne 0 ]; then n=$((n+1)); grep -A3 HANG gpurun_out/hh.err | cut -c1-900; [ $n -ge 3 ] && break; fi
+done
+echo "runs $i failures $n"
