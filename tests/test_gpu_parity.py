@@ -782,14 +782,28 @@ def test_hip_streams_equal_the_fullsize_golden_vectors(ce):
     import hashlib
     import json
     cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "indep_fullsize.json")))["cases"]
-    assert [c["case"][0] for c in cases] == ["configs[1]", "configs[2]", "configs[3]"]
-    for c in cases:
+    assert [c["case"][0] for c in cases] == ["configs[1]", "configs[2]", "configs[3]"] + ["configs[4] stream %d" % s for s in range(1, 8)]
+    for c in cases[:3]:
         name, w, h, qp, keyint, frames, slices, fps = c["case"]
         with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, slice_count=slices, level=c["level_idc"],
                              fps_num=fps, fps_den=1) as enc:
             got = _encode_pipelined(enc, [ol.gen_frame("B", w, h, f) for f in range(frames)])
         assert [hashlib.sha1(au).hexdigest() for au in got] == c["au_sha1"], name
         assert hashlib.sha1(b"".join(got)).hexdigest() == c["stream_sha1"], name
+    # configs[4]: the 8 concurrent 1080p streams as ONE lock-step session; stream 0 is configs[2]'s, stream s is fed
+    # pattern-B with seed offset s << 8 (what bench.py feeds it), the first 3 access units of each
+    name, w, h, qp, keyint, _, _, fps = cases[1]["case"]
+    with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=keyint, n_streams=8, level=41, fps_num=fps, fps_den=1) as enc:
+        got = [[] for _ in range(8)]
+        for f in range(3):
+            for s in range(8):
+                enc.set_input(*ol.gen_frame("B", w, h, f, s << 8), stream=s)
+            enc.encode()
+            for s in range(8):
+                got[s].append(hashlib.sha1(enc.output(s)).hexdigest())
+    assert got[0] == cases[1]["au_sha1"][:3]
+    for s in range(1, 8):
+        assert cases[2 + s]["case"][8] == s << 8 and got[s] == cases[2 + s]["au_sha1"], s
 
 
 def test_hip_streams_equal_the_independent_decoders_golden_vectors(ce):
