@@ -776,7 +776,12 @@ DEVI void intra_rows_body(const Params &p)
 		uint32_t spins = 0;
 		uint64_t t0 = 0;
 		while (__any(mx < p.mb_w)) {
-			const bool can = mx < p.mb_w && irw_ctr(&S.written[g]) >= mx - IRW_RING + 1;
+			// A slot is free once its macroblock is written back -- AND the chain no longer reads it: an Intra16x16 macroblock
+			// takes its left column from the ring slot of the macroblock before it (written back the moment the chain is
+			// through with it), and the skew restarts from the macroblock's own slot after its row has been handed on. So the
+			// ring is used 7 deep: staging macroblock s overwrites s - 8, the chain on macroblock c reads c - 1 and c, the writer
+			// has at most c behind it, s <= written + 6 <= c + 6.
+			const bool can = mx < p.mb_w && irw_ctr(&S.written[g]) >= mx - IRW_RING + 2;
 			if (!__any(can)) {
 				if (wait_expired(++spins, t0) || ((spins & 15u) == 0 && irw_ctr(&S.abort))) {
 					if (!irw_ctr(&S.abort))
