@@ -35,6 +35,8 @@ Extra objects on the JSON line:
                and the fraction of THAT ceiling; `kernels` lists every stage the same way.
   cpu_baseline the scalar C oracle (oracle/, kind "port") timed on this box's
                host cores on a bounded sample of the same workload (rank 0, N=1)
+  region_runs  the spread of `value`: --regions (5) consecutive timed regions of --steps frames of the measured session,
+               each with its IDR pictures where the first had them and bracketed like it; `value` is the first
   gop_parallel the same ONE stream with G closed GOPs encoded side by side
                (cedar_enc_config_ext.gop_parallel; same bytes, G*keyint frames of latency)
   batched      S lock-step streams per GPU
@@ -85,6 +87,42 @@ INTER_VALU_SLOTS_PER_MB = 1210
 VALU_PEAK_SLOTS = 256 * 4 * 2.4e9 / 4
 
 
+def valu_counters():
+    """profiles/valu.json (tools/collect_r04_valu.sh + tools/pmc_valu_summary.py): SQ counters per kernel of the w1 leg (one
+    1080p stream, frames back to back) and the s32 leg (32 lock-step streams). An issue slot = one SQ_ACTIVE_INST_VALU
+    count = 4 SIMD cycles with a VALU instruction in flight. Static: counters of a committed profile, not of this run."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+    except Exception:  # noqa: BLE001
+        return None
+    tag = sorted(k for k in v if k.endswith("_s32"))
+    tag1 = sorted(k for k in v if k.endswith("_w1"))
+    if not tag or not tag1:
+        return None
+    s32, w1 = v[tag[-1]], v[tag1[-1]]
+    idr_only = ("k_intra", "k_deblock_rows<1>", "k_deblock_rows<5>", "k_deblock2_planes<1", "k_deblock2_planes<5", "k_probe", "k_flag")
+
+    def per_mb(leg):
+        return {k: round(d["active_slots_per_macroblock"], 1) for k, d in leg.items()
+                if d.get("active_slots_per_macroblock", 0) >= 0.05 and not k.startswith("k_probe")}
+
+    def p_picture(leg):
+        return sum(d.get("active_slots_per_macroblock", 0.0) for k, d in leg.items() if not k.startswith(idr_only))
+
+    inter = next((d for k, d in s32.items() if k.startswith("k_inter<0, false, false>")), None)
+    return {"source": "profiles/valu.json: rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_WAVES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE, "
+                      "separate passes, legs %s and %s (static: a committed profile, not this run)" % (tag1[-1], tag[-1]),
+            "slot": "4 SIMD cycles with a VALU instruction in flight (one SQ_ACTIVE_INST_VALU count)",
+            "slots_per_macroblock_one_stream": per_mb(w1), "slots_per_macroblock_32_streams": per_mb(s32),
+            "p_picture_slots_per_macroblock_one_stream": round(p_picture(w1), 1),
+            "p_picture_slots_per_macroblock_32_streams": round(p_picture(s32), 1),
+            "k_inter": None if inter is None else {
+                "instructions_per_macroblock": round(inter["valu_per_macroblock"], 1),
+                "slots_per_macroblock": round(inter["active_slots_per_macroblock"], 1),
+                "static_isa_count": INTER_VALU_SLOTS_PER_MB,
+                "slot_share_while_it_runs_alone": round(inter["active_slot_share"], 4)}}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +142,8 @@ def parse():
     ap.add_argument("--other-configs", type=int, default=1,
                     help="1: also time BASELINE configs[1] (854x480 QP 30) and configs[3] in its one-GPU forms "
                          "(3840x2160 QP 24 as 1 slice and as 4 slices) for 25 steps each (N=1 only); 0 = skip")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps frames of the measured session: `value` is the first, `region_runs` lists all")
     ap.add_argument("--slices-across-gpus", action="store_true",
                     help="configs[3]: rank k encodes slice k of one picture (default 3840x2160), no collective")
     ap.add_argument("--gops-across-gpus", action="store_true",
@@ -210,7 +250,7 @@ def run_rank(args, rank, world, local_rank):
         with session(S) as pe:
             Pump(pe, S, inputs).feed(0, 3 * pe.pipeline_depth + K).drain()
 
-    def measure(S, steps, warmup, inputs, profile, keep_n=0):
+    def measure(S, steps, warmup, inputs, profile, keep_n=0, regions=1):
         prime(S, inputs)
         enc = session(S)
         first_aus = []
@@ -243,6 +283,21 @@ def run_rank(args, rank, world, local_rank):
         barrier()
         dt = time.perf_counter() - t0
         st = enc.stats()
+        # the spread of the number: `regions - 1` more timed regions of the same session, each of `steps` frames with its IDR
+        # pictures where the first region had them (untimed frames in between bring the GOP phase back), each bracketed
+        # like the first. `value` stays the first region's.
+        st["region_seconds"] = [dt]
+        nxt = pad + warmup + steps
+        for _ in range(max(0, regions - 1)):
+            gap = (-steps) % K
+            Pump(enc, S, inputs).feed(nxt, gap).drain()
+            nxt += gap
+            barrier()
+            t1 = time.perf_counter()
+            Pump(enc, S, inputs).feed(nxt, steps).drain()
+            barrier()
+            st["region_seconds"].append(time.perf_counter() - t1)
+            nxt += steps
         st["warmup"] = st_warm
         st["dominant"] = dominant
         st["first_frame"] = pad + warmup
@@ -290,8 +345,9 @@ def run_rank(args, rank, world, local_rank):
     inputs = make_inputs(max(S, min(8, max(sweep + [1]))))
     profile = os.environ.get("BENCH_NO_PROFILE") is None
     keep_n = args.cpu_frames if world == 1 else (3 if args.slices_across_gpus else 0)
-    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, profile, keep_n=keep_n)
+    dt, nbytes, st, first_aus = measure(S, args.steps, args.warmup, inputs, profile, keep_n=keep_n, regions=args.regions)
     dt_max = allmax(dt)
+    region_dts = [allmax(x) for x in st["region_seconds"]]
     nbytes_all = allsum(nbytes)
     slices_equal = None
     if args.slices_across_gpus and world > 1:
@@ -372,27 +428,32 @@ def run_rank(args, rank, world, local_rank):
     def kernel_line(k, ms):
         alg = KERNEL_BYTES_PER_MB[k] * mb_per_launch + (nbytes / max(1, args.steps) if k == "entropy" else 0)
         ach = alg / (ms * 1e-3) / 1e9
-        name = "k_deblock_rows" if k == "deblock" and st.get("deblock_rows") else KERNEL_NAME[k]
+        name = "k_deblock_rows" if k == "deblock" and st.get("deblock_rows") else "k_intra_rows" if k == "intra_recon" and st.get("intra_rows") else KERNEL_NAME[k]
         line = {"kernel": name, "work_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "hbm_GBs": round(ach, 2), "hbm_frac": ach / HBM_PEAK_GBS}
         if k == "inter":
-            slots = INTER_VALU_SLOTS_PER_MB * mb_per_launch / (ms * 1e-3)
+            per_mb = ((valu or {}).get("k_inter") or {}).get("slots_per_macroblock") or INTER_VALU_SLOTS_PER_MB
+            slots = per_mb * mb_per_launch / (ms * 1e-3)
             line["true_bound"] = {"kind": "valu issue (wave instructions; the search prunes by exact successive elimination)",
-                                  "valu_slots_per_macroblock": INTER_VALU_SLOTS_PER_MB,
+                                  "valu_slots_per_macroblock": per_mb,
+                                  "valu_slots_source": "SQ_ACTIVE_INST_VALU (profiles/valu.json)" if valu else "static ISA count",
                                   "achieved_Gslots": round(slots / 1e9, 1), "peak_Gslots": round(VALU_PEAK_SLOTS / 1e9, 1),
                                   "frac": slots / VALU_PEAK_SLOTS,
                                   "exhaustive_equivalent_Tsad": round(SAD_OPS_PER_MB * mb_per_launch / (ms * 1e-3) / 1e12, 1)}
         elif k in ("deblock", "intra_recon"):
             mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
             nsteps = mb_w + (mb_h - 1) * (1 if k == "deblock" else 2)
-            line["true_bound"] = {"kind": "dependency latency: anti-diagonal wavefront", "wavefront_steps": nsteps,
-                                  "us_per_step": round(ms * 1e3 / nsteps, 3)}
+            if k == "intra_recon" and st.get("intra_rows"):   # steps are 4x4 blocks: T = X + 2 Y (enc_k_intra.hip)
+                nsteps = 4 * mb_w + 2 * (4 * mb_h - 1)
+            line["true_bound"] = {"kind": "dependency latency: anti-diagonal wavefront" + (" of 4x4 blocks" if k == "intra_recon" and st.get("intra_rows") else ""),
+                                  "wavefront_steps": nsteps, "us_per_step": round(ms * 1e3 / nsteps, 3)}
             if k == "deblock" and st.get("deblock_rows"):   # a workgroup (CU) per band of 4 rows: rows above cross L2
                 line["true_bound"]["band_boundaries"] = max(0, (mb_h + 3) // 4 - 1)
         else:
             line["true_bound"] = {"kind": "hbm (latency at this size)", "frac": ach / HBM_PEAK_GBS}
         return line
 
+    valu = valu_counters()
     dom = kernel_line(stage, wms)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -416,7 +477,7 @@ def run_rank(args, rank, world, local_rank):
         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
         "true_bound": dom["true_bound"],
         "wf_split": st.get("wf_split"),
-        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams", "deblock_rows")},
+        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams", "deblock_rows", "intra_rows")},
         "pipeline_achieved_GBs": round(pipe_bytes / dt_max / 1e9, 3),
         "pipeline_frac": pipe_bytes / dt_max / 1e9 / HBM_PEAK_GBS,
         # every stage with frames back to back (duration = work), against its own bound
@@ -424,7 +485,18 @@ def run_rank(args, rank, world, local_rank):
         # every stage as launched in the measured (pipelined) session, from its warm-up frames
         "stage_ms_per_launch_pipelined": ({k: round(st["warmup"]["ms"][k] / max(1, st["warmup"]["launches"][k]), 4)
                                            for k in st["warmup"]["ms"]} if st.get("warmup") else None),
+        "valu": valu,
     }
+    if valu:
+        # what the lock-step batch of this run does with the chip's VALU issue: slots per macroblock of a P picture's kernels
+        # (counters) x the macroblock rate measured here, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per slot
+        b32 = next((b for b in batched if b["streams_per_gpu"] == 32), None)
+        if b32:
+            g = valu["p_picture_slots_per_macroblock_32_streams"] * b32["value"]
+            valu["batch_32_streams"] = {"macroblocks_per_s": b32["value"], "achieved_Gslots": round(g / 1e9, 1),
+                                        "peak_Gslots": round(VALU_PEAK_SLOTS / 1e9, 1), "frac": g / VALU_PEAK_SLOTS}
+        g1 = valu["p_picture_slots_per_macroblock_one_stream"] * value
+        valu["headline"] = {"macroblocks_per_s": value, "achieved_Gslots": round(g1 / 1e9, 1), "frac": g1 / VALU_PEAK_SLOTS}
 
     # ---- CPU baseline: the scalar C oracle on a bounded sample (rank 0, N=1 only) ----
     cpu = None
@@ -493,6 +565,8 @@ def run_rank(args, rank, world, local_rank):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3,
+        # the same session's consecutive timed regions (same steps, same IDR placement), the first one is `value`
+        "region_runs": [total_mbs / x for x in region_dts],
         "higher_is_better": True,
         "scaling": "strong" if args.slices_across_gpus else "weak",
         "vs_baseline": None,
@@ -562,10 +636,22 @@ def run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, 
     enc.close()
     ok = ok_oracle = None
     parts = [None] * world
+    # ... and for the check against the CPU oracle's serial bytes (the first check compares the HIP path with itself): the
+    # same sharding -- GOP g on rank g mod N, cedar_enc_set_frame_index -- at 320x240, where the scalar twin codes 2 N GOPs
+    # in seconds. Every rank codes ITS OWN small GOPs on its own GPU; rank 0 only concatenates and compares.
+    sw, sh = 320, 240
+    small = {}
+    with ce.CedarEncoder(width=sw, height=sh, qp=args.qp, keyframe_interval=K, device=local_rank) as sh_enc:
+        for k in range(2):
+            g = k * world + rank
+            sh_enc.set_frame_index(g * K)
+            small[g] = [sh_enc.encode_frame(*ce.gen_pattern("B", sw, sh, g * K + t)) for t in range(K)]
+    small_parts = [None] * world
     if world > 1:
         dist.all_gather_object(parts, mine)
+        dist.all_gather_object(small_parts, small)
     else:
-        parts = [mine]
+        parts, small_parts = [mine], [small]
     if rank == 0:
         with ce.CedarEncoder(width=W, height=H, qp=args.qp, keyframe_interval=K, device=local_rank) as one:
             serial = []
@@ -581,22 +667,12 @@ def run_gop_shards(args, rank, world, local_rank, ce, torch, dist, make_inputs, 
         ok = shards == serial
         if not ok:
             raise SystemExit("GOP shards from %d ranks do not concatenate to the serial stream" % world)
-        # ... and against the CPU oracle's serial bytes (the check above compares the HIP path with itself): the same
-        # sharding -- GOP g on shard g mod N, cedar_enc_set_frame_index -- at 320x240, where the scalar twin codes
-        # 2 N GOPs in seconds
         from tests import oracle_lib as ol
-        sw, sh = 320, 240
-        sframes = [ol.gen_frame("B", sw, sh, f) for f in range(2 * world * K)]
         oe = ol.OracleEncoder(ol.default_config(sw, sh, qp=args.qp, keyint=K))
-        oracle_serial = [oe.encode(y, uv) for y, uv in sframes]
-        got = [None] * len(sframes)
-        for r in range(world):
-            with ce.CedarEncoder(width=sw, height=sh, qp=args.qp, keyframe_interval=K, device=local_rank) as sh_enc:
-                for k in range(2):
-                    g = k * world + r
-                    sh_enc.set_frame_index(g * K)
-                    for t in range(K):
-                        got[g * K + t] = sh_enc.encode_frame(*sframes[g * K + t])
+        oracle_serial = [oe.encode(*ol.gen_frame("B", sw, sh, f)) for f in range(2 * world * K)]
+        got = []
+        for g in range(2 * world):
+            got += small_parts[g % world][g]
         ok_oracle = got == oracle_serial
         if not ok_oracle:
             raise SystemExit("GOP shards do not concatenate to the ORACLE's serial stream")

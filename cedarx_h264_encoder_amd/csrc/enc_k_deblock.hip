@@ -650,17 +650,13 @@ int launch_deblock_rows(const Params &p, void *stream)
 	constexpr size_t lds_alone = 144 * 1024;
 	static_assert(lds_min <= 64 * 1024, "a workgroup's tiles");
 	const size_t want = (size_t)p.db_lds_kb * 1024, lds = want > lds_alone ? lds_alone : want < lds_min ? lds_min : want;
-	static bool attr_set = false;
-	if (!attr_set) {
-		if (hipFuncSetAttribute((const void *)k_deblock_rows<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock_rows<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock_rows<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess)
-			return -1;
-		attr_set = true;
-	}
+	static DeviceOnce attr;
+	auto dyn = [&](const void *k) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) == hipSuccess; };
+	if (!attr.run([&]() {
+		    return dyn((const void *)k_deblock_rows<0>) && dyn((const void *)k_deblock_rows<1>) && dyn((const void *)k_deblock_rows<2>) &&
+			   dyn((const void *)k_deblock_rows<3>) && dyn((const void *)k_deblock_rows<4>) && dyn((const void *)k_deblock_rows<5>);
+	    }))
+		return -1;
 	const dim3 grid((unsigned)(2 * p.n_streams * p.slice_num * p.db_bands)), block(64 * DBR_WAVES);
 	if (p.roi_off) // regions of interest: thresholds per macroblock; an IDR picture is "every macroblock intra" there
 		hipLaunchKernelGGL((k_deblock_rows<3>), grid, block, lds, s, p);

@@ -969,15 +969,9 @@ int launch_intra_rows(const Params &p, void *stream)
 	if (need > lds_beside)
 		return -1;
 	const size_t want = (size_t)p.ir_lds_kb * 1024, lds = want > lds_alone ? lds_alone : want < need ? need : want;
-	static bool attr_set[64] = {};
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+	static DeviceOnce attr;
+	if (!attr.run([&]() { return hipFuncSetAttribute((const void *)k_intra_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) == hipSuccess; }))
 		return -1;
-	if (!attr_set[dev]) {
-		if (hipFuncSetAttribute((const void *)k_intra_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_alone) != hipSuccess)
-			return -1;
-		attr_set[dev] = true;
-	}
 	const dim3 grid((unsigned)(2 * p.n_streams * p.slice_num * p.ir_bands)), block(64 * IRW_WAVES);
 	hipLaunchKernelGGL(k_intra_rows, grid, block, lds, s, p);
 	return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -1448,17 +1448,13 @@ static int launch_deblock(const Params &p, hipStream_t s, int planes)
 	const size_t lds = planes == 3 ? l3 : planes == 1 ? l1 : planes == 2 ? l2 : (l1 > l2 ? l1 : l2);
 	const size_t lds_max = l3 > l1 ? l3 : l1;
 	static_assert(l1 <= 160 * 1024 && l3 <= 160 * 1024 && l2 <= l3, "a CU has 160 KiB of LDS");
-	static bool attr_set = false;
-	if (!attr_set) {
-		if (hipFuncSetAttribute((const void *)k_deblock2_planes<0, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<1, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<2, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<3, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<4, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess ||
-		    hipFuncSetAttribute((const void *)k_deblock2_planes<5, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
-			return -1;
-		attr_set = true;
-	}
+	static DeviceOnce attr; // (one per instantiation of this launcher)
+	auto dyn = [&](const void *k) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) == hipSuccess; };
+	if (!attr.run([&]() {
+		    return dyn((const void *)k_deblock2_planes<0, PAIRS>) && dyn((const void *)k_deblock2_planes<1, PAIRS>) && dyn((const void *)k_deblock2_planes<2, PAIRS>) &&
+			   dyn((const void *)k_deblock2_planes<3, PAIRS>) && dyn((const void *)k_deblock2_planes<4, PAIRS>) && dyn((const void *)k_deblock2_planes<5, PAIRS>);
+	    }))
+		return -1;
 	dim3 grid(planes == 4 ? 2 * nwg : nwg);
 	if (p.roi_off) // regions of interest: thresholds per macroblock; an IDR picture is "every macroblock intra" there
 		hipLaunchKernelGGL((k_deblock2_planes<3, PAIRS>), grid, dim3(128 * PAIRS), lds, s, p, planes);

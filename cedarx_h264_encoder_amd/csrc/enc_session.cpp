@@ -18,6 +18,9 @@
 #include <algorithm>
 
 #include <sched.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include <array>
 #include <atomic>
@@ -40,6 +43,41 @@ namespace {
 // one behind polling kernels of the other on shared hardware queues and wait for each other
 // until the spin bounds. Further sessions run their frames back to back.
 std::atomic<int> g_pipelined_sessions[64];
+// ... and per device across PROCESSES: a pipelined session's deblock workgroups sit on their CUs and poll until their
+// picture's analysis comes (enc_plan.h counts them per XCD against the CUs of the device), and that count knows nothing
+// of another process whose resident workgroups take the same CUs. The session that pipelines holds an exclusive
+// advisory lock on a file named after the device's PCI bus id for as long as it lives; a session that finds it taken
+// runs its frames back to back (nothing resident waits for anything there), exactly as the second session of one
+// process does. Where no lock file can be made the per-process rule is all there is.
+int pipe_lock_acquire(int device)
+{
+	char bus[64] = "unknown";
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess)
+		snprintf(bus, sizeof(bus), "dev%d", device);
+	for (char *c = bus; *c; c++)
+		if (*c == ':' || *c == '/')
+			*c = '_';
+	const char *dir = getenv("CEDAR_LOCK_DIR");
+	char path[256];
+	snprintf(path, sizeof(path), "%s/cedar_h264enc.%s.lock", dir && *dir ? dir : "/tmp", bus);
+	const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+	if (fd < 0)
+		return -2; // no lock file: the per-process rule only
+	if (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+		close(fd);
+		return -1; // another process pipelines on this device
+	}
+	return fd;
+}
+void pipe_token_release(int device, bool &holds, int &lock_fd)
+{
+	if (holds)
+		g_pipelined_sessions[device & 63].fetch_sub(1);
+	holds = false;
+	if (lock_fd >= 0)
+		close(lock_fd); // (drops the lock)
+	lock_fd = -1;
+}
 
 constexpr int MAX_COHORTS = 4; // see submit_frame
 constexpr int DB_STREAMS = 3;
@@ -302,6 +340,7 @@ struct cedar_enc {
 	uint32_t *d_prog[CEDAR_ENC_PIPELINE_DEPTH] = {}; // [0] prog_inter, [16..) prog_db[2][n_units]
 	bool row_pipe = false;      // consecutive frames overlap along the wavefront diagonals (few units)
 	bool holds_pipe_token = false;
+	int pipe_lock_fd = -1;      // the device's lock file while this session is its one pipelined session across processes
 	int db_streams = 1;         // deblock streams that really run beside s_main and each other
 	int inter_bands = 1;
 	int prev_slot = -1, prev2_slot = -1; // slots of the two frames submitted last
@@ -900,8 +939,7 @@ extern "C" int cedar_enc_config_ext(cedar_enc *e, struct cedar_enc_config *cfg, 
 		memcpy(msg, e->err, sizeof(msg));
 		if (e->device_set) // (a parameter refused before that must not touch whatever device the caller has current)
 			hipDeviceSynchronize();
-		if (e->holds_pipe_token)
-			g_pipelined_sessions[e->device & 63].fetch_sub(1);
+		pipe_token_release(e->device, e->holds_pipe_token, e->pipe_lock_fd);
 		free_all(e);
 		*e = cedar_enc();
 		memcpy(e->err, msg, sizeof(msg));
@@ -1267,10 +1305,15 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		const int db_max = plan.db_streams_wanted;
 		bool want = plan.want_row_pipe != 0;
 		if (want && !e->holds_pipe_token) {
-			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0)
-				e->holds_pipe_token = true;
-			else
+			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0) {
+				e->pipe_lock_fd = pipe_lock_acquire(e->device);
+				if (e->pipe_lock_fd == -1) // taken by a session of another process
+					g_pipelined_sessions[e->device & 63].fetch_sub(1);
+				else
+					e->holds_pipe_token = true;
+			} else {
 				g_pipelined_sessions[e->device & 63].fetch_sub(1);
+			}
 		}
 		want = want && e->holds_pipe_token;
 		int usable = 0;
@@ -2441,7 +2484,10 @@ static int collect_frame(cedar_enc *e)
 	// submitted behind it after it -- the machinery of a failed frame, with the frame itself put back first.
 	if (e->ext.scene_cut > 0 && !f.idr && !hip_failed && !wf_err && !(flags & ~4u) && !too_big &&
 	    (uint64_t)e->h_sizes[slot][S + 2] * 100 >= (uint64_t)e->ext.scene_cut * e->P.n_mb) {
-		ReplayIn again{ f.in_used, f.in_own, f.lane_gidx, true, f.qp_bump };
+		// (no QP bump survives the restart -- the twin's `goto restart` picks the picture's base QP again. Not that a bumped
+		// pass can get here: a vote needs SADmean < min over vectors (SAD + lambda (bits - 32)) with bits <= 30, which only
+		// falls as lambda grows, so a picture that did not cut at its first QP does not cut 6 steps coarser.)
+		ReplayIn again{ f.in_used, f.in_own, f.lane_gidx, true, 0 };
 		const InFlight snapshot = f;
 		const int rc = recover(e, snapshot, &again);
 		if (rc)
@@ -2818,8 +2864,7 @@ extern "C" void cedar_enc_close(cedar_enc *e)
 		flusher_stop(e);
 		hipDeviceSynchronize();
 	}
-	if (e->holds_pipe_token)
-		g_pipelined_sessions[e->device & 63].fetch_sub(1);
+	pipe_token_release(e->device, e->holds_pipe_token, e->pipe_lock_fd);
 	free_all(e);
 	delete e;
 }
@@ -2846,6 +2891,7 @@ extern "C" int cedar_enc_get_stats(cedar_enc *e, struct cedar_enc_stats *out)
 	out->wf_split = e->wf_split;
 	out->deblock_planes_split = e->split_planes ? 1 : 0;
 	out->deblock_rows = e->db_rows ? 1 : 0;
+	out->intra_rows = e->ir_rows ? 1 : 0;
 	out->frames_pipelined = e->row_pipe ? 1 : 0;
 	out->idr_lookahead = e->lookahead ? 1 : 0;
 	out->depth = e->depth;

@@ -3,6 +3,8 @@
 // deblocking with one wave per macroblock row): LDS-only wave synchronisation, the write-through hand-off between
 // workgroups, bounded LDS waits, the deblocking filters of clause 8.7 on one line of samples, the per-row LDS tiles.
 #pragma once
+#include <mutex>
+
 #include <hip/hip_runtime.h>
 
 #include "enc_device.h"
@@ -10,6 +12,26 @@
 namespace cedar {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Host side of the launchers: hipFuncSetAttribute applies to the CURRENT device's copy of a kernel, so "done" is kept per
+// device, and sessions may be configured from several threads, so it is kept under a lock.
+struct DeviceOnce {
+	std::mutex m;
+	bool done[64] = {};
+	template <typename F> bool run(F set)
+	{
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+			return false;
+		std::lock_guard<std::mutex> g(m);
+		if (!done[dev]) {
+			if (!set())
+				return false;
+			done[dev] = true;
+		}
+		return true;
+	}
+};
 
 // intra-wave hand-off through LDS only: order LDS accesses, leave global loads
 // and stores in flight (a plain fence would drain them with vmcnt(0))

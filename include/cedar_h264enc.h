@@ -278,6 +278,7 @@ struct cedar_enc_stats {
 	uint64_t requantised_frames;             /* re-encodes because of a macroblock above 3200 bits  */
 	uint64_t scene_cuts;                     /* P pictures coded again as IDR pictures (scene_cut)  */
 	int      deblock_rows;                   /* 1: deblocking with a wave per macroblock row, a workgroup per band of 4 rows */
+	int      intra_rows;                     /* 1: intra reconstruction as a wavefront of 4x4 blocks, a wave per macroblock row */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */

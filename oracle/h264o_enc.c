@@ -2475,8 +2475,9 @@ again: /* strict_mb_bits == 2: a picture with a macroblock above 3200 bits is co
 		bw_trailing(&b);
 		if (b.overflow)
 			return -ENOSPC;
-		/* H.264 A.3.1: no macroblock_layer() above 3200 bits. No I_PCM fallback exists yet: the picture is
-		 * refused when asked to be strict (state untouched, as for any failed frame), else emitted */
+		/* H.264 A.3.1: no macroblock_layer() above 3200 bits. Sessions that code such macroblocks I_PCM (cfg.pcm,
+		 * DESIGN.md 3.6) never get here; the others requantise the picture (2), refuse it (1: state untouched, as for
+		 * any failed frame) or emit it */
 		if (max_mb_bits > 3200 && e->cfg.strict_mb_bits == 2 && e->qp + 6 <= 51) {
 			e->qp += 6; /* nothing of the session's state has been committed yet: just code it again */
 			goto again;

@@ -41,6 +41,7 @@ def test_bench_single_gpu_line():
     assert j["unit"] == "macroblocks/s" and j["dtype"] == "u8" and j["higher_is_better"] is True
     assert j["vs_baseline"] is None and "workload" in j["config"] and "model" not in j["config"]
     assert abs(j["value"] - 8160 * 25 / (j["ms_per_step"] * 25e-3)) < 1e-3 * j["value"]
+    assert len(j["region_runs"]) == 5 and j["region_runs"][0] == j["value"] and min(j["region_runs"]) > 0  # the spread of the number
     rf, cb = j["roofline"], j["cpu_baseline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 * rf["frac"] and rf["achieved"] > 0  # achieved is printed rounded

@@ -70,3 +70,68 @@ def test_two_ranks_shard_streams_without_collectives(tmp_path):
         assert got[gs] == hh.hexdigest()
     assert len(set(got.values())) == 4            # different seeds -> different streams
     assert res["max_dt"] > 0
+
+
+# ---- two encoder PROCESSES on one GPU: only one of them may pipeline its frames on the device ----
+TWO_PROC_WORKER = textwrap.dedent("""
+    import hashlib, json, os, sys, time
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    sys.path.insert(0, %r)
+    import torch  # noqa: F401  (first: one HIP runtime per process)
+    import cedarx_h264_encoder_amd as ce
+    me, other, want = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))
+    w, h, n = 1920, 1080, 25
+    frames = [ce.gen_pattern("B", w, h, f) for f in range(n)]
+    enc = ce.CedarEncoder(width=w, height=h, qp=24, keyframe_interval=25, fps_num=30, fps_den=1)
+    open(me, "w").write("configured")
+    t0 = time.time()
+    while not os.path.exists(other) and time.time() - t0 < 120:   # both sessions exist before either encodes
+        time.sleep(0.01)
+    ok = os.path.exists(other)
+    pipelined = enc.stats()["frames_pipelined"]
+    for rep in range(3):
+        got, q = [], 0
+        for y, uv in frames:
+            if q == enc.pipeline_depth:
+                enc.collect(); got.append(enc.output(0)); q -= 1
+            enc.set_input(y, uv)
+            enc.submit(); q += 1
+        while q:
+            enc.collect(); got.append(enc.output(0)); q -= 1
+        # keyint 25 and 25 frames per repetition: every repetition is the same GOP (idr_pic_id alternates)
+        if rep == 0:
+            ok = ok and [hashlib.sha1(a).hexdigest() for a in got] == want
+        else:
+            ok = ok and [len(a) for a in got[1:]] == [len(a) for a in first[1:]] and got[1:] == first[1:]
+        first = got if rep == 0 else first
+    enc.close()
+    print("RESULT " + json.dumps({"ok": bool(ok), "pipelined": bool(pipelined)}))
+""")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_only_one_pipelines(tmp_path):
+    """A pipelined session's deblock workgroups are resident and poll; enc_plan.h budgets them against the CUs of the
+    device, which only holds if no OTHER process does the same on that device. The session that pipelines holds the
+    device's lock file (enc_session.cpp, pipe_lock_acquire); the second process finds it taken and runs its frames back
+    to back. Both emit the golden bytes of configs[2] (tests/golden/indep_fullsize.json), side by side on one GPU."""
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "indep_fullsize.json")))["cases"][1]
+    assert want["case"][:6] == ["configs[2]", 1920, 1080, 24, 25, 25]
+    (tmp_path / "want.json").write_text(json.dumps(want["au_sha1"]))
+    script = tmp_path / "worker.py"
+    script.write_text(TWO_PROC_WORKER % ROOT)
+    env = dict(os.environ, CEDAR_LOCK_DIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, str(script), str(tmp_path / ("flag%d" % i)), str(tmp_path / ("flag%d" % (1 - i))),
+                               str(tmp_path / "want.json")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+             for i in range(2)]
+    res = []
+    for pr in procs:
+        out, err = pr.communicate(timeout=280)
+        assert pr.returncode == 0, err[-2000:]
+        res.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:]))
+    assert all(r["ok"] for r in res), res
+    assert sorted(r["pipelined"] for r in res) == [False, True], res

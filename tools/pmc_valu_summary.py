@@ -42,8 +42,12 @@ def main():
         slots = gui / 8.0 * 256 * 4 / 4.0 if gui else 0.0   # VALU issue slots of the chip while the launch ran
         rows.append((k, n, valu, waves, valu / waves if waves else 0, valu / mbs, salu, lds, act * 4, busy, wcyc, gui / 8.0,
                      valu / slots if slots else 0))
+        # an issue slot = 4 SIMD cycles with a VALU instruction in flight = one SQ_ACTIVE_INST_VALU count (a quarter-rate
+        # v_qsad_pk_u16_u8 holds its SIMD for 4 of them: SQ_INSTS_VALU counts it once)
         out[k.replace("cedar::", "")] = {"valu_per_launch": valu, "valu_per_macroblock": valu / mbs, "waves": waves,
-                                         "issue_slot_share": valu / slots if slots else None}
+                                         "issue_slot_share": valu / slots if slots else None,
+                                         "active_slots_per_macroblock": act / mbs,
+                                         "active_slot_share": act / slots if slots else None}
     path = os.path.join(ROOT, "profiles", "%s_pmc_valu.csv" % tag)
     with open(path, "w") as fh:
         fh.write("kernel,launches,SQ_INSTS_VALU,SQ_WAVES,valu_per_wave,valu_per_macroblock(%d per launch),SQ_INSTS_SALU,SQ_INSTS_LDS,"
