@@ -234,6 +234,20 @@ DEVI int idct_lanes(int d, const LaneK &ci, const LaneK &cj)
 // polling on one device starve each other's producers for a while; that is slow, not lost). Looked
 // at every 256th iteration; the first look starts the clock.
 constexpr uint64_t WAIT_LIMIT_TICKS = 300000000ull; // 3 s
+// The source planes of stream st (see Params::src_direct): base pointers; a reader takes row min(y, src_last_*) at stride cw.
+DEVI const uint8_t *in_plane(const Params &p, int st, bool luma)
+{
+	if (p.in_luma)
+		return luma ? p.in_luma[st] : p.in_chroma[st];
+	const uint8_t *base = nullptr; // wave-uniform pick from the kernel arguments without indexing them dynamically
+#pragma unroll
+	for (int k = 0; k < IN_K_STREAMS; k++)
+		base = st == k ? (luma ? p.in_k[k] : p.in_k[IN_K_STREAMS + k]) : base;
+	return base;
+}
+DEVI const uint8_t *src_luma(const Params &p, int st) { return p.src_direct ? in_plane(p, st, true) : p.src_y + (size_t)st * p.plane_y_stride; }
+DEVI const uint8_t *src_chroma(const Params &p, int st) { return p.src_direct ? in_plane(p, st, false) : p.src_uv + (size_t)st * p.plane_uv_stride; }
+
 DEVI bool wait_expired(uint32_t spins, uint64_t &t0)
 {
 	if ((spins & 255u) != 255u)

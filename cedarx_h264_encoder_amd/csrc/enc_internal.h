@@ -40,6 +40,8 @@ constexpr uint32_t PCM_MB_BITS_FLAG = 0x80000000u; // Params::mb_bits of an I_PC
 constexpr int SLOT_BYTES = 2048;  // private CAVLC bit buffer of one macroblock
 constexpr int SLOT_WORDS = SLOT_BYTES / 4;
 constexpr int ESC_CHUNK = 32;     // bytes of RBSP per emulation-prevention thread
+constexpr int PK_CHUNK = 2048;    // k_pack_out: bytes of RBSP a workgroup builds, escapes and writes out
+constexpr int PK_BITS = PK_CHUNK * 8;
 constexpr int MAX_UNITS = 1024;   // streams x slices per session
 constexpr int WF_WAVES = 16;      // waves of one wavefront workgroup
 constexpr int IR_TRIPLES = 2;     // intra reconstruction: (luma, chroma, mover) wave triples per workgroup, one per band of 4 rows
@@ -104,6 +106,10 @@ struct Params {
 	const uint8_t *const *in_chroma; // [n_streams]
 	const uint8_t *in_k[2 * IN_K_STREAMS]; // few streams: the frame pointers travel in the kernel arguments (luma, then chroma)
 	uint8_t *src_y, *src_uv;         // padded source planes
+	// src_direct: no padded planes and no k_input -- the width is a multiple of 16, so the caller's packed frame IS the
+	// source plane of every column, and the rows below the picture are its last row: readers clamp the row to src_last_y /
+	// src_last_c (the coded size's last row when the planes are padded: a no-op)
+	int32_t src_direct, src_last_y, src_last_c;
 	uint8_t *rec_y, *rec_uv;         // reconstruction being written
 	const uint8_t *ref_y, *ref_uv;   // previous reconstruction (deblocked)
 	MbInfo *mbi;
@@ -130,7 +136,15 @@ struct Params {
 	uint32_t *esc_cnt;               // [n_units][esc_chunks_cap]
 	uint32_t *nal_off;               // [n_units] byte offset of the NAL in out
 	uint32_t *nal_size;              // [n_units]
-	uint32_t *stream_size;           // [n_streams + 3] bytes per stream; [n] total; [n+1] error flags; [n+2] units scanned (k_esc_scan)
+	uint32_t *stream_size;           // [n_streams + 3] bytes per stream; [n] total; [n+1] error flags; [n+2] units scanned (k_esc_scan) / chunks through (k_pack_out)
+	// the fused back end (k_pack_out; nullptr: k_zero .. k_esc_write + k_copy_out through the RBSP buffer)
+	uint64_t *ent_rec;               // [n_units][unit_mb_cap + 2] per entry: bit position | (skip run, bits of the macroblock (0: skipped), I_PCM) << 32
+	uint32_t *pk_first;              // [n_units][pk_chunks_cap] the entry that covers the first bit of every chunk of PK_CHUNK RBSP bytes
+	uint64_t *pk_agg;                // [n_units][pk_chunks_cap] a chunk's escaping table | the frame's tag (db_tag) << 32
+	uint64_t *pk_unit;               // [n_units] a unit's escape bytes | the frame's tag << 32
+	int32_t pk_chunks_cap;           // chunks per unit the arrays hold
+	int32_t pk_store_mode;           // (development, CEDAR_PK_STORE) how the bytes reach the host: 0 plain stores (coherent host memory), 1 write-through stores, 2 plain stores and a release fence per workgroup
+	int32_t pk_launch_chunks;        // workgroups per unit of this launch (a unit's last one takes the chunks beyond)
 	uint8_t *out;                    // compact output: all streams back to back
 	const SliceHdr *hdr;             // [n_units] (streams differ where they are GOP lanes: idr_pic_id)
 	const uint32_t *prefix_len;      // [n_streams] bytes reserved in front (SPS+PPS)
@@ -241,6 +255,8 @@ struct Launch {
 	static int probe_pipe(void *blocked, void *chain, uint32_t *d_words, int n_chain, double *us_per_kernel);
 	static int deblock(const Params &p, void *stream, int planes); // 1 luma, 2 chroma, 3 both
 	static int entropy(const Params &p, void *stream); // cavlc, scan, pack, escape
+	// ... and the bytes on the host: the fused back end (cavlc, scan, k_pack_out), or entropy() + copy_out()
+	static int entropy_out(const Params &p, void *stream, uint8_t *host_out, uint32_t *host_sizes);
 };
 
 int launch_deblock_rows(const Params &p, void *stream); // enc_k_deblock.hip (Launch::deblock when Params::db_rows)

@@ -17,10 +17,9 @@
 
 #include "enc_device.h"
 #include "enc_tables.h"
+#include "enc_wf_common.h" // (u32x4, the write-through loads and stores of the tagged hand-off words)
 
 namespace cedar {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------- per-thread MSB-first bit writer into a slot ----------------
 struct BitW {
@@ -842,6 +841,11 @@ DEVI PosMap block_scan_posmap(PosMap v, PosMap *s_pm)
 // room to do 20 us of work (profiles/r02_s32: k_scan 675 us average). Four waves slip in anywhere.
 #define SCAN_THREADS ((int)blockDim.x)
 
+// (round 4: a thread takes SC_PER_T consecutive entries -- a serial scan of eight in registers around ONE block scan per
+// tile of 8 x threads entries: a 1080p unit is a single tile for 1024 threads where it was 8 trips of 4 barriers each,
+// 25 -> ~8 us alone; a batch's 256-thread workgroups make 4 trips instead of 32)
+constexpr int SC_PER_T = 8;
+
 __global__ __launch_bounds__(1024) void k_scan(Params p)
 {
 	__shared__ int s_tmp[32];
@@ -856,73 +860,120 @@ __global__ __launch_bounds__(1024) void k_scan(Params p)
 	uint32_t *off = p.bit_off + (size_t)unit * (p.unit_mb_cap + 2);
 	uint32_t *run = p.run_before + (size_t)unit * (p.unit_mb_cap + 2);
 	const bool is_p = !p.is_idr;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (int)(blockDim.x >> 6);
 	if (threadIdx.x == 0) {
 		s_carry_max = -1;
 		s_carry_sum = p.hdr[unit].nbits;
 	}
 	__syncthreads();
-	for (int base = 0; base <= n; base += SCAN_THREADS) {
-		const int e = base + threadIdx.x;
-		const bool mb = e < n, trailer = e == n;
-		const int sk = mb ? p.skip[mb0 + e] : 0;
-		// last non-skipped macroblock index at or before e (inclusive max-scan)
-		int m = (mb && !sk) ? e : -1;
-		m = block_scan_incl<true>(m, s_tmp);
-		const int cmax = s_carry_max;
-		m = m > cmax ? m : cmax;
-		// exclusive value = inclusive of e-1
-		int prev = __shfl_up(m, 1, 64);
-		__syncthreads();
-		if ((threadIdx.x & 63) == 63)
-			s_tmp[threadIdx.x >> 6] = m;
-		__syncthreads();
-		if ((threadIdx.x & 63) == 0)
-			prev = threadIdx.x == 0 ? cmax : s_tmp[(threadIdx.x >> 6) - 1];
-		const int r = (mb && !sk) || trailer ? e - 1 - prev : 0;
-		int bits = 0;
-		bool pcm_e = false;
-		if (mb && !sk) {
-			const uint32_t mbb = p.mb_bits[mb0 + e];
-			pcm_e = (mbb & PCM_MB_BITS_FLAG) != 0;
-			bits = (is_p ? ue_len((uint32_t)r) : 0) + (int)(mbb & ~PCM_MB_BITS_FLAG);
-		} else if (trailer) {
-			bits = ((is_p && r > 0) ? ue_len((uint32_t)r) : 0) + 1; // + rbsp stop bit
+	for (int base = 0; base <= n; base += SCAN_THREADS * SC_PER_T) {
+		const int e0 = base + (int)threadIdx.x * SC_PER_T;
+		// ---- this thread's entries: skip flags and bits ----
+		uint32_t mbb[SC_PER_T];
+		bool coded[SC_PER_T];
+#pragma unroll
+		for (int i = 0; i < SC_PER_T; i++) {
+			const int e = e0 + i;
+			const bool mb = e < n;
+			coded[i] = mb && !p.skip[mb0 + (mb ? e : 0)];
+			mbb[i] = coded[i] ? p.mb_bits[mb0 + e] : 0u;
 		}
-		int end_pos; // bit position behind entry e
+		// ---- last coded macroblock at or before every entry: the thread's own, then the threads before it ----
+		int lm = -1;
+#pragma unroll
+		for (int i = 0; i < SC_PER_T; i++)
+			lm = coded[i] ? e0 + i : lm;
+		const int incl_m = block_scan_incl<true>(lm, s_tmp);
+		int prev = __shfl_up(incl_m, 1, 64);
+		if (lane == 0)
+			prev = wave ? s_tmp[16 + wave - 1] : -0x7fffffff;
+		const int cmax = s_carry_max;
+		prev = prev > cmax ? prev : cmax; // the last coded macroblock in front of e0
+		const int tot_m = max(s_tmp[16 + nwaves - 1], cmax);
+		// ---- skip runs and bits of the entries ----
+		int r[SC_PER_T], bits[SC_PER_T];
+		int lsum = 0;
+		bool any_pcm = false;
+#pragma unroll
+		for (int i = 0; i < SC_PER_T; i++) {
+			const int e = e0 + i;
+			const bool trailer = e == n;
+			r[i] = coded[i] || trailer ? e - 1 - prev : 0;
+			bits[i] = coded[i] ? (is_p ? ue_len((uint32_t)r[i]) : 0) + (int)(mbb[i] & ~PCM_MB_BITS_FLAG)
+				  : trailer ? ((is_p && r[i] > 0) ? ue_len((uint32_t)r[i]) : 0) + 1 // + rbsp stop bit
+					    : 0;
+			lsum += bits[i];
+			any_pcm = any_pcm || (mbb[i] & PCM_MB_BITS_FLAG) != 0;
+			prev = coded[i] ? e : prev;
+		}
+		// ---- positions ----
+		int start[SC_PER_T], end[SC_PER_T];
+		int tile_end;
+		const int pos0 = s_carry_sum;
 		if (!p.pcm) {
-			const int incl = block_scan_incl<false>(bits, s_tmp);
-			const int csum = s_carry_sum;
-			if (mb || trailer)
-				off[e] = (uint32_t)(csum + incl - bits);
-			end_pos = csum + incl;
+			const int incl = block_scan_incl<false>(lsum, s_tmp);
+			int pos = pos0 + incl - lsum;
+#pragma unroll
+			for (int i = 0; i < SC_PER_T; i++) {
+				start[i] = pos;
+				pos += bits[i];
+				end[i] = pos;
+			}
+			tile_end = pos0 + s_tmp[16 + nwaves - 1];
 		} else {
 			// I_PCM macroblocks: the samples start at the next byte boundary behind the header, so an entry is
 			// no longer a length but a map of positions, pos -> pos + a, or pos -> align8(pos + a) + b behind
 			// which everything is byte aligned again. Maps of that form compose to maps of that form (PosMap), and
 			// composition is associative: an inclusive scan gives every entry the map of all entries up to it.
-			PosMap f{ bits, pcm_e ? 3072 : 0, pcm_e ? 1 : 0 };
-			const PosMap incl = block_scan_posmap(f, s_pm);
-			const int start = s_carry_sum;
-			// (exclusive value = the map of the entries before e: from the lane to the left, the wave before)
+			PosMap loc[SC_PER_T + 1]; // loc[i]: the thread's entries before its i-th
+			loc[0] = PosMap{ 0, 0, 0 };
+#pragma unroll
+			for (int i = 0; i < SC_PER_T; i++) {
+				const bool pcm_e = (mbb[i] & PCM_MB_BITS_FLAG) != 0;
+				loc[i + 1] = posmap_then(loc[i], PosMap{ bits[i], pcm_e ? 3072 : 0, pcm_e ? 1 : 0 });
+			}
+			const PosMap incl = block_scan_posmap(loc[SC_PER_T], s_pm);
 			PosMap ex{ __shfl_up(incl.a, 1, 64), __shfl_up(incl.b, 1, 64), __shfl_up(incl.pcm, 1, 64) };
-			__syncthreads();
-			if ((threadIdx.x & 63) == 63)
-				s_pm[threadIdx.x >> 6] = incl;
-			__syncthreads();
-			if ((threadIdx.x & 63) == 0)
-				ex = threadIdx.x == 0 ? PosMap{ 0, 0, 0 } : s_pm[(threadIdx.x >> 6) - 1];
-			if (mb || trailer)
-				off[e] = (uint32_t)posmap_apply(ex, start);
-			end_pos = posmap_apply(incl, start);
+			if (lane == 0)
+				ex = wave ? s_pm[16 + wave - 1] : PosMap{ 0, 0, 0 };
+#pragma unroll
+			for (int i = 0; i < SC_PER_T; i++) {
+				start[i] = posmap_apply(posmap_then(ex, loc[i]), pos0);
+				end[i] = posmap_apply(posmap_then(ex, loc[i + 1]), pos0);
+			}
+			tile_end = posmap_apply(s_pm[16 + nwaves - 1], pos0);
 		}
-		if (mb || trailer)
-			run[e] = (uint32_t)r;
-		if (trailer)
-			p.unit_bits[unit] = (uint32_t)end_pos;
+		(void)any_pcm;
+		// ---- out ----
+#pragma unroll
+		for (int i = 0; i < SC_PER_T; i++) {
+			const int e = e0 + i;
+			if (e > n)
+				continue;
+			const bool trailer = e == n;
+			if (!p.ent_rec) { // (k_pack's and k_esc_*'s inputs)
+				off[e] = (uint32_t)start[i];
+				run[e] = (uint32_t)r[i];
+			} else {
+				// k_pack_out: everything it needs to know of an entry in one word, and for every chunk of PK_CHUNK output
+				// bytes the entry that covers its first bit (an entry is at most 3088 bits: at most one chunk boundary)
+				const uint32_t len = trailer ? 1u : (mbb[i] & ~PCM_MB_BITS_FLAG);
+				// (run: 16 bits, a unit has at most 36864 macroblocks; len: 15 bits, 0 = a skipped macroblock -- a coded one has its mb_type)
+				const uint32_t hi = (uint32_t)r[i] | (len & 0x7fffu) << 16 | ((mbb[i] & PCM_MB_BITS_FLAG) ? 1u : 0u) << 31;
+				p.ent_rec[(size_t)unit * (p.unit_mb_cap + 2) + e] = (uint64_t)(uint32_t)start[i] | (uint64_t)hi << 32;
+				if (end[i] > start[i]) {
+					const int c = (start[i] + PK_BITS - 1) / PK_BITS;
+					if (c * PK_BITS < end[i] && c < p.pk_chunks_cap)
+						p.pk_first[(size_t)unit * p.pk_chunks_cap + c] = (uint32_t)e;
+				}
+			}
+			if (trailer)
+				p.unit_bits[unit] = (uint32_t)end[i];
+		}
 		__syncthreads();
-		if (threadIdx.x == SCAN_THREADS - 1) {
-			s_carry_max = m;
-			s_carry_sum = end_pos;
+		if (threadIdx.x == 0) {
+			s_carry_max = tot_m;
+			s_carry_sum = tile_end;
 		}
 		__syncthreads();
 	}
@@ -1019,14 +1070,14 @@ __global__ __launch_bounds__(256) void k_pack(Params p)
 		// I_PCM: pcm_alignment_zero_bits (the buffer is zero), then 256 luma, 64 Cb, 64 Cr samples from the source
 		uint32_t bp = (pos + nbits + 7) & ~7u;
 		const int my = r0 + e / p.mb_w, mx = e % p.mb_w;
-		const uint8_t *sy = p.src_y + (size_t)st * p.plane_y_stride + (size_t)(16 * my) * p.cw + 16 * mx;
-		const uint8_t *sc = p.src_uv + (size_t)st * p.plane_uv_stride + (size_t)(8 * my) * p.cw + 16 * mx;
+		const uint8_t *sy = src_luma(p, st) + 16 * mx;
+		const uint8_t *sc = src_chroma(p, st) + 16 * mx;
 		for (int y = 0; y < 16; y++)
 			for (int k = 0; k < 4; k++, bp += 32)
-				or_bits(w, capw, bp, __builtin_bswap32(*(const uint32_t *)(sy + (size_t)y * p.cw + 4 * k)), 32);
+				or_bits(w, capw, bp, __builtin_bswap32(*(const uint32_t *)(sy + (size_t)min(16 * my + y, p.src_last_y) * p.cw + 4 * k)), 32);
 		for (int c = 0; c < 2; c++)
 			for (int y = 0; y < 8; y++) {
-				const uint8_t *r = sc + (size_t)y * p.cw + c;
+				const uint8_t *r = sc + (size_t)min(8 * my + y, p.src_last_c) * p.cw + c;
 				for (int k = 0; k < 2; k++, bp += 32)
 					or_bits(w, capw, bp, (uint32_t)r[8 * k] << 24 | (uint32_t)r[8 * k + 2] << 16 | (uint32_t)r[8 * k + 4] << 8 | r[8 * k + 6], 32);
 			}
@@ -1171,6 +1222,422 @@ __global__ __launch_bounds__(256) void k_esc_write(Params p)
 	esc_chunk<true>(rb, start, start + ESC_CHUNK < nbytes ? start + ESC_CHUNK : nbytes, o);
 }
 
+
+// ------------------------------------------------------------------------
+// k_pack_out (round 4): everything behind k_scan in ONE launch -- bit-granular concatenation, emulation prevention, start
+// code + NAL header, compaction of all NAL units into the caller's pinned buffer, sizes and the completion flag. It takes
+// the place of k_zero, k_pack, k_esc_count, k_esc_scan, k_esc_write and k_copy_out, and of the RBSP buffer they met in
+// (4.4 MB of atomic ORs into a zeroed buffer to place 0.2 MB of bits; CEDAR_ENTROPY_FUSED=0 keeps that path).
+//
+// A workgroup owns PK_CHUNK bytes of one unit's RBSP. It builds them in LDS: k_scan left, per chunk, the entry that covers
+// its first bit (pk_first) and per entry one word with its bit position, skip run and length (ent_rec); the threads take the
+// chunk's entries 256 at a time and OR their slot words -- clipped to the chunk -- into LDS. Escaping is the automaton
+// "two zero bytes, then a byte <= 3 gets a 03 in front", whose state before a byte only depends on the zero run in front of
+// it: every thread runs its 8 bytes from each of the three states, a (count, state-after) table per thread, and tables
+// compose associatively -- a scan inside the workgroup, and the workgroup's total goes out as ONE tagged 64-bit word
+// (pk_agg). A chunk learns the escapes in front of it and its state by composing the words of the chunks before it in its
+// unit, a unit's last chunk publishes the unit's total (pk_unit), and a NAL's place in the output is the sum of what is in
+// front of it: a workgroup only ever waits for workgroups with a lower index, which the hardware started no later (each XCD
+// takes its share of a launch in order), and the words carry the frame's tag, so nothing needs clearing. The escaped bytes
+// are laid out in LDS congruent to their address modulo 16 and leave as 16-byte stores (byte stores at a chunk's ragged
+// ends). The workgroup that counts out last writes the sizes and raises the frame's flag.
+// ------------------------------------------------------------------------
+constexpr int PK_THREADS = 256;
+constexpr int PK_PER_T = PK_CHUNK / PK_THREADS; // 8 bytes of RBSP per thread
+static_assert(PK_PER_T == 8, "a thread's bytes are two LDS words");
+
+// table of the escaping automaton over a run of bytes: counts c[s] (16 bits each) and states after o[s] (2 bits each) for
+// the three states s before it
+constexpr uint64_t PK_TAB_ID = (uint64_t)0 << 48 | (uint64_t)1 << 50 | (uint64_t)2 << 52;
+DEVI uint32_t tab_c(uint64_t t, int s) { return (uint32_t)(t >> (16 * s)) & 0xffffu; }
+DEVI int tab_o(uint64_t t, int s) { return (int)(t >> (48 + 2 * s)) & 3; }
+DEVI uint64_t tab_then(uint64_t a, uint64_t b) // a, then b
+{
+	uint64_t r = 0;
+#pragma unroll
+	for (int s = 0; s < 3; s++) {
+		const int oa = tab_o(a, s);
+		r |= (uint64_t)((tab_c(a, s) + tab_c(b, oa)) & 0xffffu) << (16 * s) | (uint64_t)tab_o(b, oa) << (48 + 2 * s);
+	}
+	return r;
+}
+DEVI uint64_t shfl_up64(uint64_t v, int off)
+{
+	const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, off, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), off, 64);
+	return (uint64_t)hi << 32 | lo;
+}
+DEVI uint64_t shfl64(uint64_t v, int lane)
+{
+	const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, lane, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), lane, 64);
+	return (uint64_t)hi << 32 | lo;
+}
+// inclusive scan of tables over the lanes of a wave, lane order = byte order
+DEVI uint64_t tab_wave_scan(uint64_t v, int lane)
+{
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint64_t o = shfl_up64(v, off);
+		if (lane >= off)
+			v = tab_then(o, v);
+	}
+	return v;
+}
+// a chunk's table as it travels: count from state 0 in 12 bits, the other two as differences (-2..5), the states after
+DEVI uint32_t tab_to_word(uint64_t t)
+{
+	const int c0 = (int)tab_c(t, 0), d1 = (int)tab_c(t, 1) - c0 + 2, d2 = (int)tab_c(t, 2) - c0 + 2;
+	return (uint32_t)c0 | (uint32_t)(d1 & 7) << 12 | (uint32_t)(d2 & 7) << 15 | (uint32_t)tab_o(t, 0) << 18 | (uint32_t)tab_o(t, 1) << 20 | (uint32_t)tab_o(t, 2) << 22;
+}
+DEVI uint64_t tab_from_word(uint32_t w)
+{
+	const uint32_t c0 = w & 0xfffu, c1 = c0 + ((w >> 12) & 7u) - 2u, c2 = c0 + ((w >> 15) & 7u) - 2u;
+	return (uint64_t)c0 | (uint64_t)(c1 & 0xffffu) << 16 | (uint64_t)(c2 & 0xffffu) << 32 | (uint64_t)((w >> 18) & 3u) << 48 | (uint64_t)((w >> 20) & 3u) << 50 |
+	       (uint64_t)((w >> 22) & 3u) << 52;
+}
+
+// wait for a tagged word (upper half = this frame's tag); bounded like every hand-off of the path
+DEVI uint32_t pk_wait_word(const uint64_t *w, uint32_t tag, const Params &p, bool &dead)
+{
+	uint64_t v = xload64(w);
+	uint32_t spins = 0;
+	uint64_t t0 = 0;
+	while ((uint32_t)(v >> 32) != tag && !dead) {
+		if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+			__hip_atomic_store(p.wf_err, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			dead = true;
+			break;
+		}
+		__builtin_amdgcn_s_sleep(2);
+		v = xload64(w);
+	}
+	return (uint32_t)v;
+}
+
+// OR the low n bits of v (n <= 32) into the chunk image at bit position rel (relative to the chunk; may lie outside)
+DEVI void pk_or(uint32_t *img, int rel, uint32_t v, int n)
+{
+	if (n <= 0 || rel >= PK_BITS || rel + n <= 0)
+		return;
+	if (n < 32)
+		v &= (1u << n) - 1u;
+	if (rel < 0) { // the front is another chunk's
+		n += rel;
+		v &= (1u << n) - 1u; // (n < 32 here)
+		rel = 0;
+	}
+	if (rel + n > PK_BITS) { // so is the tail
+		const int cut = rel + n - PK_BITS;
+		v >>= cut;
+		n -= cut;
+	}
+	const int wi = rel >> 5, sft = rel & 31;
+	if (sft + n <= 32) {
+		atomicOr(&img[wi], __builtin_bswap32(v << (32 - sft - n)));
+	} else {
+		const int lo = sft + n - 32;
+		atomicOr(&img[wi], __builtin_bswap32(v >> lo));
+		atomicOr(&img[wi + 1], __builtin_bswap32(v << (32 - lo))); // (img has a word of slack)
+	}
+}
+
+__global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host_out, uint32_t *host_sizes)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t s_img[PK_CHUNK / 4 + 4];
+	__shared__ __attribute__((aligned(16))) uint8_t s_o[16 + 5 + PK_CHUNK + PK_CHUNK / 2 + 32];
+	__shared__ uint64_t s_wt[PK_THREADS / 64];
+	__shared__ uint32_t s_pre[6]; // escapes in front of the chunk, state before it, NAL offset, chunks of the launch, dead, last
+	const int unit = blockIdx.y;
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int n_units = p.n_streams * p.slice_num;
+	const uint32_t nbytes = (p.unit_bits[unit] + 7) >> 3;
+	const int n_chunks = (int)min((nbytes + PK_CHUNK - 1) / PK_CHUNK, (uint32_t)p.pk_chunks_cap);
+	if ((int)blockIdx.x >= n_chunks)
+		return;
+	// The launch has as many workgroups per unit as the session's pictures have needed so far, and some (pk_launch_chunks):
+	// a unit's last workgroup takes whatever chunks lie beyond, one after the other (it still only waits for lower indices)
+	const bool takes_tail = blockIdx.x == gridDim.x - 1;
+	const int st = unit / p.slice_num, ls = unit % p.slice_num;
+	int r0, r1;
+	slice_rows(p.mb_h, p.slice_count, p.slice_first + ls, &r0, &r1);
+	const int n = (r1 - r0) * p.mb_w;
+	const uint32_t tag = p.db_tag;
+	const bool is_p = !p.is_idr;
+	bool dead = false;
+	for (int c = (int)blockIdx.x; c < n_chunks; c = takes_tail ? c + 1 : n_chunks) {
+	const int bit0 = c * PK_BITS;                       // first bit of the chunk
+	const int len_c = (int)min((uint32_t)PK_CHUNK, nbytes - (uint32_t)c * PK_CHUNK); // its bytes
+
+	// ---- the chunk's RBSP bytes, in LDS ----
+	for (int i = t; i < PK_CHUNK / 4 + 4; i += PK_THREADS)
+		s_img[i] = 0;
+	__syncthreads();
+	if (c == 0 && t == 0) { // the slice header
+		const uint64_t hb = p.hdr[unit].bits;
+		const int hn = p.hdr[unit].nbits;
+		if (hn > 32) {
+			pk_or(s_img, 0, (uint32_t)(hb >> 32), hn - 32);
+			pk_or(s_img, hn - 32, (uint32_t)hb, 32);
+		} else {
+			pk_or(s_img, 0, (uint32_t)hb, hn);
+		}
+	}
+	{
+		const uint64_t *rec = p.ent_rec + (size_t)unit * (p.unit_mb_cap + 2);
+		const int e_lo = c == 0 ? 0 : (int)p.pk_first[(size_t)unit * p.pk_chunks_cap + c];
+		const size_t mb_base = (size_t)st * p.n_mb + (size_t)r0 * p.mb_w;
+		constexpr int PK_AHEAD = 4; // entries a thread has in flight: their records, then the first two words of their slots
+		bool done = false;
+		for (int eb = e_lo + t; eb <= n && !done; eb += PK_AHEAD * PK_THREADS) {
+			uint64_t rcs[PK_AHEAD];
+			uint32_t s0[PK_AHEAD], s1[PK_AHEAD];
+#pragma unroll
+			for (int j = 0; j < PK_AHEAD; j++) {
+				const int e = eb + j * PK_THREADS;
+				rcs[j] = e <= n ? rec[e] : ~0ull; // (a position behind every chunk)
+			}
+#pragma unroll
+			for (int j = 0; j < PK_AHEAD; j++) {
+				const int e = eb + j * PK_THREADS;
+				const uint32_t hi = (uint32_t)(rcs[j] >> 32), len = (hi >> 16) & 0x7fffu;
+				const bool want = e < n && len != 0 && (int)(uint32_t)rcs[j] - bit0 < PK_BITS;
+				const uint32_t *slot = p.slot + (mb_base + (want ? e : 0)) * SLOT_WORDS;
+				s0[j] = want ? slot[0] : 0u;
+				s1[j] = want && len > 32 ? slot[1] : 0u;
+			}
+#pragma unroll
+			for (int j = 0; j < PK_AHEAD; j++) {
+				const int e = eb + j * PK_THREADS;
+				const uint64_t rc = rcs[j];
+				int pos = (int)(uint32_t)rc - bit0;
+				if (e > n || pos >= PK_BITS) { // (positions ascend: nothing further on is this chunk's)
+					done = true;
+					break;
+				}
+				const uint32_t hi = (uint32_t)(rc >> 32), run = hi & 0xffffu, len = (hi >> 16) & 0x7fffu;
+				if (len == 0)
+					continue; // a skipped macroblock
+				if (is_p && (e < n || run > 0)) { // mb_skip_run in front of a coded macroblock, or pending at the end of the slice
+					const uint32_t v = run + 1;
+					const int l = 2 * (32 - __clz(v)) - 1;
+					pk_or(s_img, pos, v, l);
+					pos += l;
+				}
+				if (e == n) { // rbsp_trailing_bits: the stop bit (the image is zero behind it)
+					pk_or(s_img, pos, 1, 1);
+					continue;
+				}
+				const uint32_t *slot = p.slot + (mb_base + e) * SLOT_WORDS;
+				const int full = (int)(len >> 5), rem = (int)(len & 31);
+				if (pos + (int)len > 0) { // (an entry that ends in front of the chunk has nothing for it; pk_first never points at one)
+					int k = pos < 0 ? (-pos) >> 5 : 0; // words wholly in front of the chunk
+					for (; k < full && k < SLOT_WORDS && pos + 32 * k < PK_BITS; k++)
+						pk_or(s_img, pos + 32 * k, k == 0 ? s0[j] : k == 1 ? s1[j] : slot[k], 32);
+					if (rem && full < SLOT_WORDS)
+						pk_or(s_img, pos + 32 * full, (full == 0 ? s0[j] : full == 1 ? s1[j] : slot[full]) >> (32 - rem), rem);
+				}
+				if (hi >> 31) {
+					// I_PCM: pcm_alignment_zero_bits (the image is zero), then 256 luma, 64 Cb, 64 Cr samples from the source
+					int bp = (pos + (int)len + 7) & ~7; // (bit0 is a multiple of 8)
+					const int my = r0 + e / p.mb_w, mx = e % p.mb_w;
+					const uint8_t *sy = src_luma(p, st) + 16 * mx;
+					const uint8_t *sc = src_chroma(p, st) + 16 * mx;
+					for (int y = 0; y < 16; y++)
+						for (int k = 0; k < 4; k++, bp += 32)
+							pk_or(s_img, bp, __builtin_bswap32(*(const uint32_t *)(sy + (size_t)min(16 * my + y, p.src_last_y) * p.cw + 4 * k)), 32);
+					for (int cc = 0; cc < 2; cc++)
+						for (int y = 0; y < 8; y++) {
+							const uint8_t *r = sc + (size_t)min(8 * my + y, p.src_last_c) * p.cw + cc;
+							for (int k = 0; k < 2; k++, bp += 32)
+								pk_or(s_img, bp, (uint32_t)r[8 * k] << 24 | (uint32_t)r[8 * k + 2] << 16 | (uint32_t)r[8 * k + 4] << 8 | r[8 * k + 6], 32);
+						}
+				}
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- the escaping automaton over this thread's 8 bytes, from each of the three states ----
+	const uint32_t w0 = s_img[2 * t], w1 = s_img[2 * t + 1];
+	const int nb = min(max(len_c - PK_PER_T * t, 0), PK_PER_T);
+	uint64_t tab = 0;
+#pragma unroll
+	for (int s = 0; s < 3; s++) {
+		int z = s;
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int i = 0; i < PK_PER_T; i++)
+			if (i < nb) {
+				const uint32_t v = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+				if (z == 2 && v <= 3) {
+					cnt++;
+					z = 0;
+				}
+				z = v == 0 ? z + 1 : 0;
+			}
+		tab |= (uint64_t)cnt << (16 * s) | (uint64_t)z << (48 + 2 * s);
+	}
+	const uint64_t incl = tab_wave_scan(tab, lane);
+	if (lane == 63)
+		s_wt[wave] = incl;
+	__syncthreads();
+	uint64_t wpre = PK_TAB_ID, total = PK_TAB_ID;
+#pragma unroll
+	for (int w = 0; w < PK_THREADS / 64; w++) {
+		if (w < wave)
+			wpre = tab_then(wpre, s_wt[w]);
+		total = tab_then(total, s_wt[w]);
+	}
+	uint64_t excl = shfl_up64(incl, 1);
+	if (lane == 0)
+		excl = PK_TAB_ID;
+	excl = tab_then(wpre, excl); // the bytes of the chunk in front of this thread's
+	uint64_t *agg = p.pk_agg + (size_t)unit * p.pk_chunks_cap;
+	if (t == 0)
+		xstore64(&agg[c], (uint64_t)tag << 32 | tab_to_word(total));
+
+	// ---- what lies in front: the chunks before this one in its unit, the units before this one ----
+	if (wave == 0) {
+		uint64_t pre = PK_TAB_ID;
+		for (int base = 0; base < c; base += 64) {
+			const int i = base + lane;
+			uint64_t v = PK_TAB_ID;
+			if (i < c)
+				v = tab_from_word(pk_wait_word(&agg[i], tag, p, dead));
+			v = tab_wave_scan(v, lane);
+			pre = tab_then(pre, shfl64(v, 63));
+		}
+		const uint32_t esc_before = tab_c(pre, 0); // (a NAL's payload starts in state 0: its header byte is not zero)
+		const int s_in = tab_o(pre, 0);
+		const uint32_t esc_unit = esc_before + tab_c(total, s_in);
+		if (c == n_chunks - 1 && lane == 0)
+			xstore64(&p.pk_unit[unit], (uint64_t)tag << 32 | esc_unit);
+		uint32_t front = 0, chunks = 0;
+		for (int base = 0; base < n_units; base += 64) {
+			const int u2 = base + lane;
+			if (u2 < n_units) {
+				const uint32_t nb2 = (p.unit_bits[u2] + 7) >> 3;
+				chunks += min((nb2 + PK_CHUNK - 1) / PK_CHUNK, (uint32_t)p.pk_chunks_cap);
+				if (u2 < unit)
+					front += 5u + nb2 + pk_wait_word(&p.pk_unit[u2], tag, p, dead) + (u2 % p.slice_num == 0 ? p.prefix_len[u2 / p.slice_num] : 0u);
+			}
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+			front += (uint32_t)__shfl_xor((int)front, off, 64);
+			chunks += (uint32_t)__shfl_xor((int)chunks, off, 64);
+		}
+		const bool any_dead = __any(dead);
+		if (lane == 0) {
+			s_pre[0] = esc_before;
+			s_pre[1] = (uint32_t)s_in;
+			s_pre[2] = front + (ls == 0 ? p.prefix_len[st] : 0u);
+			s_pre[3] = chunks;
+			s_pre[4] = any_dead ? 1u : 0u;
+		}
+	}
+	__syncthreads();
+	const uint32_t esc_before = s_pre[0];
+	const int s_in = (int)s_pre[1];
+	const uint32_t nal_off = s_pre[2], all_chunks = s_pre[3];
+	const bool failed = s_pre[4] != 0;
+
+	// ---- escaped bytes into LDS, congruent to their address modulo 16; then out ----
+	const uint32_t out0 = nal_off + (c == 0 ? 0u : 5u + (uint32_t)c * PK_CHUNK + esc_before); // first byte this chunk writes
+	const uint32_t head = c == 0 ? 5u : 0u;
+	const uint32_t out_len = head + (uint32_t)len_c + tab_c(total, s_in);
+	const uint32_t a = (uint32_t)((uintptr_t)(host_out + out0) & 15u);
+	if (c == 0 && t < 5) // 4-byte start code on every NAL (cedar.c:875-878) + header byte
+		s_o[a + t] = t == 3 ? 1 : t == 4 ? (uint8_t)((p.nal_ref_idc << 5) | p.nal_type) : 0;
+	{
+		int z = tab_o(excl, s_in);
+		uint8_t *o = s_o + a + head + PK_PER_T * t + tab_c(excl, s_in);
+#pragma unroll
+		for (int i = 0; i < PK_PER_T; i++)
+			if (i < nb) {
+				const uint32_t v = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+				if (z == 2 && v <= 3) {
+					*o++ = 3;
+					z = 0;
+				}
+				*o++ = (uint8_t)v;
+				z = v == 0 ? z + 1 : 0;
+			}
+	}
+	__syncthreads();
+	const bool fits = out0 + out_len <= (uint32_t)p.out_cap && !failed;
+	if (fits) {
+		uint8_t *g = host_out + out0 - a; // 16-byte aligned
+		for (uint32_t j = t; 16 * j < a + out_len; j += PK_THREADS) {
+			const uint32_t lo = 16 * j, hi16 = lo + 16;
+			// (write-through stores: the GPU caches pinned host memory like any other, and nothing here writes an L2 back)
+			if (lo >= a && hi16 <= a + out_len) {
+				if (p.pk_store_mode == 1) {
+					const uint64_t *v = (const uint64_t *)(s_o + lo);
+					__hip_atomic_store((uint64_t *)(g + lo), v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store((uint64_t *)(g + lo + 8), v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				} else {
+					*(u32x4 *)(g + lo) = *(const u32x4 *)(s_o + lo);
+				}
+			} else {
+				for (uint32_t b = max(lo, a); b < min(hi16, a + out_len); b++) {
+					if (p.pk_store_mode == 1)
+						__hip_atomic_store(g + b, s_o[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					else
+						g[b] = s_o[b];
+				}
+			}
+		}
+	} else if (t == 0) {
+		atomicOr(&p.stream_size[p.n_streams + 1], 2u);
+	}
+
+	// ---- count out; the last workgroup of the launch lays the sizes down and raises the frame's flag ----
+	// (No release fence: at agent or system scope it writes the XCD's whole L2 back -- beside a batch's k_inter and
+	// deblocking that is megabytes of their dirty lines per workgroup; the first version, with one, took 0.4-0.9 ms per
+	// launch of 16 pictures. The bytes went to the host by write-through stores: a thread whose stores have been
+	// acknowledged -- s_waitcnt vmcnt(0) -- has delivered them. (Plain stores stay in the L2 until something writes it
+	// back: the second version's sizes arrived a frame late.) What the last workgroup reads was written with write-through
+	// atomics or by the kernels before this one.)
+	if (p.pk_store_mode == 2)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	uint32_t *cnt = p.stream_size + p.n_streams + 2;
+	if (t == 0 && __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == all_chunks - 1) {
+	uint32_t pos = 0, stream_start = 0, flags = __hip_atomic_load(&p.stream_size[p.n_streams + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for (int u = 0; u < n_units; u++) { // stream-major: every stream's NAL units back to back behind its SPS / PPS / AUD prefix
+		const int st2 = u / p.slice_num, ls2 = u % p.slice_num;
+		const uint32_t nb2 = (p.unit_bits[u] + 7) >> 3;
+		if (ls2 == 0) {
+			stream_start = pos;
+			pos += p.prefix_len[st2];
+		}
+		const uint64_t uw = xload64(&p.pk_unit[u]);
+		const uint32_t size = 5u + nb2 + ((uint32_t)(uw >> 32) == tag ? (uint32_t)uw : 0u);
+		p.nal_off[u] = pos;
+		p.nal_size[u] = size;
+		pos += size;
+		if (ls2 == p.slice_num - 1)
+			__hip_atomic_store(&host_sizes[st2], pos - stream_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (pos > (uint32_t)p.out_cap || (nb2 + PK_CHUNK - 1) / PK_CHUNK > (uint32_t)p.pk_chunks_cap || (uint32_t)(uw >> 32) != tag)
+			flags |= 2u;
+	}
+	__hip_atomic_store(&host_sizes[p.n_streams], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	__hip_atomic_store(&host_sizes[p.n_streams + 1], flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	if (p.cut_votes) { // scene cuts (one stream, one cohort): the picture's votes (the analysis is over: the entropy stream waited for it)
+		__hip_atomic_store(&host_sizes[p.n_streams + 2], p.cut_votes[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		p.cut_votes[0] = 0; // ... and the slot's next P picture starts from zero
+	}
+	for (int i = 0; i < p.n_streams + 4; i++) // the size words are left zeroed for the lane's next frame
+		__hip_atomic_store(&p.stream_size[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the sizes are on the host before the flag is)
+	if (p.done_flag)
+		__hip_atomic_store(p.done_flag, p.done_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	__syncthreads(); // (the tail: the LDS images are the next chunk's now)
+	}
+}
+
 int Launch::entropy(const Params &p, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
@@ -1189,11 +1656,24 @@ int Launch::entropy(const Params &p, void *stream)
 	else
 		hipLaunchKernelGGL(k_cavlc, dim3((mbs + 63) / 64, p.n_streams), dim3(64), 0, s, p);
 	hipLaunchKernelGGL(k_scan, dim3(n_units), dim3(n_units > 8 ? 256 : 1024), 0, s, p);
+	if (p.ent_rec) // the fused back end: Launch::entropy_out adds k_pack_out
+		return (int)hipGetLastError();
 	hipLaunchKernelGGL(k_zero, dim3((p.rbsp_cap / 16 + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_pack, dim3((p.unit_mb_cap + 2 + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_esc_count, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
 	hipLaunchKernelGGL(k_esc_scan, dim3(n_units), dim3(n_units > 8 ? 256 : 1024), 0, s, p);
 	hipLaunchKernelGGL(k_esc_write, dim3((p.esc_chunks_cap + 255) / 256, n_units), dim3(256), 0, s, p);
+	return (int)hipGetLastError();
+}
+
+// cavlc, scan and -- the fused back end -- k_pack_out; or the round-3 chain with k_copy_out behind it
+int Launch::entropy_out(const Params &p, void *stream, uint8_t *host_out, uint32_t *host_sizes)
+{
+	if (entropy(p, stream))
+		return -1;
+	if (!p.ent_rec)
+		return copy_out(p, stream, host_out, host_sizes);
+	hipLaunchKernelGGL(k_pack_out, dim3((unsigned)min(max(p.pk_launch_chunks, 1), p.pk_chunks_cap), (unsigned)(p.n_streams * p.slice_num)), dim3(PK_THREADS), 0, (hipStream_t)stream, p, host_out, host_sizes);
 	return (int)hipGetLastError();
 }
 

@@ -750,8 +750,8 @@ DEVI void intra_rows_body(const Params &p)
 
 	if (wave == 4) {
 		// ======================================== stager ========================================
-		const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
-		const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+		const uint8_t *src_y = src_luma(p, st);
+		const uint8_t *src_uv = src_chroma(p, st);
 		int mx = row_ok ? 0 : p.mb_w; // next macroblock of this lane group's row to stage
 		struct StageRegs {
 			u32x4 s;
@@ -763,10 +763,10 @@ DEVI void intra_rows_body(const Params &p)
 				return;
 			const size_t a = row_mb + m;
 			if (LUMA) {
-				Rg.s = *(const u32x4 *)(src_y + (size_t)(my * 16 + l) * p.cw + m * 16);
+				Rg.s = *(const u32x4 *)(src_y + (size_t)min(my * 16 + l, p.src_last_y) * p.cw + m * 16);
 				Rg.mode = (uint32_t)(uint8_t)p.i4modes[a * 16 + irw_blk_idx(l & 3, l >> 2)];
 			} else if (l < 8) {
-				Rg.s = *(const u32x4 *)(src_uv + (size_t)(my * 8 + l) * p.cw + m * 16);
+				Rg.s = *(const u32x4 *)(src_uv + (size_t)min(my * 8 + l, p.src_last_c) * p.cw + m * 16);
 			}
 			Rg.info = ((const uint32_t *)&p.mbi[a])[0];
 		};

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	const int qp_base = MBQP ? roi_qp(p, st, mx, my) : p.qp;
 	QpSet qs = qp_set<MBQP>(p, qp_base);
 
-	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
-	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+	const uint8_t *src_y = src_luma(p, st);
+	const uint8_t *src_uv = src_chroma(p, st);
 	const uint8_t *ref_y = p.ref_y + (size_t)st * p.plane_y_stride;
 	const uint8_t *ref_uv = p.ref_uv + (size_t)st * p.plane_uv_stride;
 	uint8_t *rec_y = valid ? p.rec_y + (size_t)st * p.plane_y_stride + (size_t)y0 * p.cw + x0 : p.dummy_rec;
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// ---- stage tiles through LDS with 16-byte loads (offsets inside a plane fit 32 bits) ----
 	const uint32_t cw = (uint32_t)p.cw;
 	if (lane < 16)
-		*(u32x4 *)(s_cur + lane * 16) = *(const u32x4 *)(src_y + (uint32_t)(y0 + lane) * cw + (uint32_t)x0);
+		*(u32x4 *)(s_cur + lane * 16) = *(const u32x4 *)(src_y + (uint32_t)min(y0 + lane, p.src_last_y) * cw + (uint32_t)x0);
 	else if (lane < 24)
-		*(u32x4 *)(s_curc + (lane - 16) * 16) = *(const u32x4 *)(src_uv + (uint32_t)(my * 8 + lane - 16) * cw + (uint32_t)x0);
+		*(u32x4 *)(s_curc + (lane - 16) * 16) = *(const u32x4 *)(src_uv + (uint32_t)min(my * 8 + lane - 16, p.src_last_c) * cw + (uint32_t)x0);
 	// Reference window. Samples outside the picture are never used (a candidate that touches them
 	// is not valid), so the loads are unconditional from clamped coordinates: no branches.
 	// chroma: 25 rows x 4 segments; lane -> (row = lane / 4 + 16 * pass, seg = lane % 4). It waits in
@@ -1072,8 +1072,10 @@ __global__ __launch_bounds__(256) void k_copy_out(Params p, uint8_t *host_out, u
 		((u32x4 *)host_out)[i] = ((const u32x4 *)p.out)[i];
 	if (blockIdx.x == 0 && (int)threadIdx.x < p.n_streams + 2)
 		host_sizes[threadIdx.x] = p.stream_size[threadIdx.x];
-	if (p.cut_votes && blockIdx.x == 0 && (int)threadIdx.x == p.n_streams + 2) // scene cuts (one stream, one cohort): the picture's votes
+	if (p.cut_votes && blockIdx.x == 0 && (int)threadIdx.x == p.n_streams + 2) { // scene cuts (one stream, one cohort): the picture's votes
 		host_sizes[threadIdx.x] = p.cut_votes[0];                              // (the analysis is over: the entropy stream waited for it)
+		p.cut_votes[0] = 0;                                                    // ... and the slot's next P picture starts from zero
+	}
 	if (!p.done_flag)
 		return;
 	// Pipelined frames: the last workgroup raises the frame's "bitstream delivered" flag (after
@@ -1211,14 +1213,20 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 	const int lane = threadIdx.x;
 	if (blockIdx.x == 0 && lane == 0)
 		dbg_event(p, 2, p.db_tag, 0);
+	if (p.src_direct && blockIdx.x == 0 && (p.wf_split_intra > 1 || p.ir_rows)) {
+		// (what k_input does where it runs: the ticket / abort / progress words of the intra wavefront start at zero)
+		const int used = 16 + p.n_streams * p.slice_num * WF_MAX_SPLIT;
+		for (int i = lane; i < used; i += 64)
+			p.wf_sync[i] = 0;
+	}
 	int mx, my, st;
 	xcd_mb(p, mx, my, st);
 	const int x0 = mx * 16, y0 = my * 16;
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, slice_of_row(p.mb_h, p.slice_count, my), &r0, &r1);
 	const bool top_mb = my > r0, left_mb = mx > 0, tr_mb = top_mb && mx < p.mb_w - 1;
-	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
-	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+	const uint8_t *src_y = src_luma(p, st);
+	const uint8_t *src_uv = src_chroma(p, st);
 	const size_t mbaddr = (size_t)st * p.n_mb + (size_t)my * p.mb_w + mx;
 
 	// load tiles (byte loads; out-of-picture entries are never used)
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 		int gx = x0 - 1 + tx, gy = y0 - 1 + ty;
 		uint8_t v = 128;
 		if (gx >= 0 && gy >= 0 && gx < p.cw && gy < p.ch)
-			v = src_y[(size_t)gy * p.cw + gx];
+			v = src_y[(size_t)min(gy, p.src_last_y) * p.cw + gx];
 		s_t[ty * TS + tx] = v;
 	}
 	for (int i = lane; i < 2 * 81; i += 64) {
@@ -1235,7 +1243,7 @@ __global__ __launch_bounds__(64) void k_intra_decide(Params p)
 		int gx = mx * 8 - 1 + tx, gy = my * 8 - 1 + ty;
 		uint8_t v = 128;
 		if (gx >= 0 && gy >= 0 && gx < (p.cw >> 1) && gy < (p.ch >> 1))
-			v = src_uv[(size_t)gy * p.cw + 2 * gx + c];
+			v = src_uv[(size_t)min(gy, p.src_last_c) * p.cw + 2 * gx + c];
 		s_c[c][ty * 12 + tx] = v;
 	}
 	__syncthreads();

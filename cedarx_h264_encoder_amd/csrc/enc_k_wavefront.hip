@@ -810,8 +810,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 
 	Ir2GroupLds &L = s_g[trip * 4 + g];
 	const Ir2GroupLds &LU = s_g[trip * 4 + (g > 0 ? g - 1 : 0)];
-	const uint8_t *src_y = p.src_y + (size_t)st * p.plane_y_stride;
-	const uint8_t *src_uv = p.src_uv + (size_t)st * p.plane_uv_stride;
+	const uint8_t *src_y = src_luma(p, st);
+	const uint8_t *src_uv = src_chroma(p, st);
 	uint8_t *rec_y = p.rec_y + (size_t)st * p.plane_y_stride;
 	uint8_t *rec_uv = p.rec_uv + (size_t)st * p.plane_uv_stride;
 	int f_intra = (1 << p.qbits) / 3, f_intra_c = (1 << p.qbits_c) / 3;
@@ -1262,8 +1262,8 @@ __global__ __launch_bounds__(64 * 3 * IR_TRIPLES) void k_intra_recon2(Params p)
 					xseen = xwait(&xprog[wj - 1], xabort, xerr, (uint32_t)need);
 				R.top_ok = xseen >= (uint32_t)need;
 			}
-			R.sy = *(const u32x4 *)(src_y + (size_t)(y0 + l) * p.cw + x0);
-			R.sc = *(const u32x4 *)(src_uv + (size_t)((y0 >> 1) + (l & 7)) * p.cw + x0);
+			R.sy = *(const u32x4 *)(src_y + (size_t)min(y0 + l, p.src_last_y) * p.cw + x0);
+			R.sc = *(const u32x4 *)(src_uv + (size_t)min((y0 >> 1) + (l & 7), p.src_last_c) * p.cw + x0);
 			R.mi = *(const uint64_t *)&p.mbi[a];
 			R.modes = *(const u32x4 *)(p.i4modes + a * 16);
 			if (ROI)

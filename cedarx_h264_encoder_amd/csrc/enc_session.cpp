@@ -321,6 +321,13 @@ struct cedar_enc {
 	uint32_t *d_slot[ENT_LANES] = {}, *d_mb_bits[ENT_LANES] = {};
 	uint8_t *d_skip[ENT_LANES] = {};
 	uint32_t *d_bit_off[ENT_LANES] = {}, *d_run[ENT_LANES] = {}, *d_unit_bits[ENT_LANES] = {};
+	bool src_direct_ok = false;  // the width is a multiple of 16: frames may be read where the caller put them (CEDAR_SRC_DIRECT=0: always through k_input)
+	// k_pack_out's workgroups per unit: twice what the session's pictures of the kind (IDR, P) have needed so far -- a guess by
+	// size before the first one is back; whatever a picture needs beyond that its last workgroup does alone (same bytes)
+	int pk_seen[2] = { 0, 0 };
+	bool ent_fused = true;       // k_pack_out behind k_scan (CEDAR_ENTROPY_FUSED=0: k_zero .. k_esc_write + k_copy_out through the RBSP buffer)
+	uint64_t *d_ent_rec[ENT_LANES] = {}, *d_pk_agg[ENT_LANES] = {}, *d_pk_unit[ENT_LANES] = {};
+	uint32_t *d_pk_first[ENT_LANES] = {};
 	uint8_t *d_rbsp[ENT_LANES] = {};
 	uint32_t *d_esc[ENT_LANES] = {}, *d_nal_off[ENT_LANES] = {}, *d_nal_size[ENT_LANES] = {}, *d_stream_size[ENT_LANES] = {};
 	int ent_lanes = 1;
@@ -471,6 +478,7 @@ void free_all(cedar_enc *e)
 	}
 	for (int l = 0; l < ENT_LANES; l++) {
 		F(e->d_slot[l]); F(e->d_mb_bits[l]); F(e->d_skip[l]); F(e->d_bit_off[l]); F(e->d_run[l]); F(e->d_unit_bits[l]);
+		F(e->d_ent_rec[l]); F(e->d_pk_agg[l]); F(e->d_pk_unit[l]); F(e->d_pk_first[l]);
 		F(e->d_rbsp[l]); F(e->d_esc[l]); F(e->d_nal_off[l]); F(e->d_nal_size[l]); F(e->d_stream_size[l]);
 	}
 	F(e->d_pred4); F(e->d_dummy_rec); F(e->d_stripe_tab); F(e->d_abort_all); F(e->d_dbg_log);
@@ -1109,9 +1117,12 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S_user, hipHostMallocDefault));
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S_user, hipHostMallocDefault));
 	for (int i = 0; i < e->depth; i++) {
-		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, hipHostMallocMapped));
+		// (CEDAR_HOST_COHERENT, development: the bytestream and size buffers as coherent -- fine-grained -- host memory, which
+		// the GPU does not cache)
+		const unsigned out_flags = hipHostMallocMapped | (getenv("CEDAR_HOST_COHERENT") && atoi(getenv("CEDAR_HOST_COHERENT")) ? hipHostMallocCoherent : 0u);
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, out_flags));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
-		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (size_t)MAX_COHORTS * (S + 2) * sizeof(uint32_t), hipHostMallocMapped));
+		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (size_t)MAX_COHORTS * (S + 2) * sizeof(uint32_t), out_flags));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_sizes[i], e->h_sizes[i], 0));
 	}
 	for (int i = 0; i < e->depth; i++) {
@@ -1219,17 +1230,27 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.rbsp_cap = align_up(P.unit_mb_cap * 1024 + 4096, 256);
 	P.esc_chunks_cap = P.rbsp_cap / ESC_CHUNK;
 	P.out_cap = (int32_t)e->out_cap;
+	e->ent_fused = !(getenv("CEDAR_ENTROPY_FUSED") && atoi(getenv("CEDAR_ENTROPY_FUSED")) == 0);
+	e->src_direct_ok = (P.width & 15) == 0 && !(getenv("CEDAR_SRC_DIRECT") && atoi(getenv("CEDAR_SRC_DIRECT")) == 0);
+	P.pk_chunks_cap = P.rbsp_cap / PK_CHUNK + 1;
 	for (int l = 0; l < e->ent_lanes; l++) {
 		if ((rc = dalloc(e, &e->d_bit_off[l], (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
 		if ((rc = dalloc(e, &e->d_run[l], (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
 		if ((rc = dalloc(e, &e->d_unit_bits[l], (size_t)n_units))) return rc;
-		if ((rc = dalloc(e, &e->d_rbsp[l], (size_t)n_units * P.rbsp_cap + 64))) return rc; // + one escape chunk of read slack
-		if ((rc = dalloc(e, &e->d_esc[l], (size_t)n_units * P.esc_chunks_cap))) return rc;
+		if (e->ent_fused) { // k_pack_out: no RBSP buffer; its tagged words start zeroed (dalloc) and never hold another frame's tag
+			if ((rc = dalloc(e, &e->d_ent_rec[l], (size_t)n_units * (P.unit_mb_cap + 2)))) return rc;
+			if ((rc = dalloc(e, &e->d_pk_first[l], (size_t)n_units * P.pk_chunks_cap))) return rc;
+			if ((rc = dalloc(e, &e->d_pk_agg[l], (size_t)n_units * P.pk_chunks_cap))) return rc;
+			if ((rc = dalloc(e, &e->d_pk_unit[l], (size_t)n_units))) return rc;
+		} else {
+			if ((rc = dalloc(e, &e->d_rbsp[l], (size_t)n_units * P.rbsp_cap + 64))) return rc; // + one escape chunk of read slack
+			if ((rc = dalloc(e, &e->d_esc[l], (size_t)n_units * P.esc_chunks_cap))) return rc;
+		}
 		if ((rc = dalloc(e, &e->d_nal_off[l], (size_t)n_units))) return rc;
 		if ((rc = dalloc(e, &e->d_nal_size[l], (size_t)n_units))) return rc;
 		if ((rc = dalloc(e, &e->d_stream_size[l], (size_t)MAX_COHORTS * (S + 4)))) return rc; // + k_copy_out's workgroup counter; per cohort
 	}
-	for (int i = 0; i < e->depth; i++)
+	for (int i = 0; i < e->depth && !e->ent_fused; i++)
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
 	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
 	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
@@ -1552,6 +1573,13 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.mvd = nullptr;
 	P.bit_off = e->d_bit_off[0];
 	P.run_before = e->d_run[0];
+	P.src_direct = 0;
+	P.src_last_y = P.ch - 1;
+	P.src_last_c = P.ch / 2 - 1;
+	P.ent_rec = e->d_ent_rec[0];
+	P.pk_first = e->d_pk_first[0];
+	P.pk_agg = e->d_pk_agg[0];
+	P.pk_unit = e->d_pk_unit[0];
 	P.unit_bits = e->d_unit_bits[0];
 	P.rbsp = e->d_rbsp[0];
 	P.esc_cnt = e->d_esc[0];
@@ -1734,14 +1762,23 @@ static Params cohort_params(const cedar_enc *e, const Params &P, int c)
 	Q.bit_off += u0 * (P.unit_mb_cap + 2);
 	Q.run_before += u0 * (P.unit_mb_cap + 2);
 	Q.unit_bits += u0;
-	Q.rbsp += u0 * P.rbsp_cap;
-	Q.esc_cnt += u0 * P.esc_chunks_cap;
+	if (Q.rbsp) {
+		Q.rbsp += u0 * P.rbsp_cap;
+		Q.esc_cnt += u0 * P.esc_chunks_cap;
+	}
+	if (Q.ent_rec) {
+		Q.ent_rec += u0 * (P.unit_mb_cap + 2);
+		Q.pk_first += u0 * P.pk_chunks_cap;
+		Q.pk_agg += u0 * P.pk_chunks_cap;
+		Q.pk_unit += u0;
+	}
 	Q.nal_off += u0;
 	Q.nal_size += u0;
 	Q.hdr += u0;
 	Q.prefix_len += s0;
 	Q.stream_size += (size_t)c * (S + 4);
-	Q.out += (size_t)s0 * e->stream_out_cap;
+	if (Q.out)
+		Q.out += (size_t)s0 * e->stream_out_cap;
 	Q.out_cap = (int32_t)((size_t)n * e->stream_out_cap);
 	Q.wf_sync += (size_t)c * 3 * WF_SYNC_WORDS;
 	Q.wf_hbuf += u0 * e->hb_slots * P.mb_w * WF_HBUF_GRANULES;
@@ -1793,13 +1830,11 @@ static int emit_tail(cedar_enc *e, Params &Pc, hipStream_t s_ana, hipStream_t s_
 	tm_begin(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
 	if (Pc.roi_off && Launch::qp_eff(Pc, s_ent))
 		return fail(e, -EIO, "k_qp_eff launch failed");
-	if (Launch::entropy(Pc, s_ent))
-		return fail(e, -EIO, "entropy launch failed");
-	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
 	Pc.done_flag = f.d_done;
 	Pc.done_tag = f.done_tag;
-	if (Launch::copy_out(Pc, s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
-		return fail(e, -EIO, "k_copy_out launch failed");
+	if (Launch::entropy_out(Pc, s_ent, e->dv_out[f.host_out], e->dv_sizes[slot]))
+		return fail(e, -EIO, "entropy launch failed");
+	tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_ent);
 	return 0;
 }
 
@@ -1972,7 +2007,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 
 	// ---- input: H2D of the pinned buffers unless the caller supplied device frames ----
 	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
-	bool any_host = false;
+	bool any_host = false, in_work = false; // (in_work: something of this frame was enqueued on s_in)
 	const size_t in_y_slot = (size_t)ds * e->cfg.input_luma_size * S, in_uv_slot = (size_t)ds * e->cfg.input_chroma_size * S;
 	f.in_own.assign((size_t)S, 0);
 	for (int s = 0; s < S; s++) {
@@ -1987,12 +2022,13 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			// the frame's data sits in the device copy of the slot it was first submitted to: move it to
 			// this slot's, so that "a frame in flight owns the copy of its slot" holds again
 			if (replay->in[s] != dy) {
+				in_work = true;
 				HIP_TRY(e, hipMemcpyAsync(dy, replay->in[s], (size_t)P.width * P.height, hipMemcpyDeviceToDevice, s_in));
 				HIP_TRY(e, hipMemcpyAsync(duv, replay->in[S + s], (size_t)P.width * P.height / 2, hipMemcpyDeviceToDevice, s_in));
 			}
 			continue;
 		}
-		any_host = true;
+		any_host = in_work = true;
 		HIP_TRY(e, hipMemcpyAsync(dy, e->h_luma + (size_t)s * e->cfg.input_luma_size,
 					  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_in));
 		HIP_TRY(e, hipMemcpyAsync(duv, e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
@@ -2034,6 +2070,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 			t[s] = in_ptr(s, false);
 			t[S + s] = in_ptr(s, true);
 		}
+		in_work = true;
 		HIP_TRY(e, hipMemcpyAsync((void *)(e->d_in_ptrs + (size_t)ds * 2 * S), t.data(), sizeof(void *) * 2 * S,
 					  hipMemcpyHostToDevice, s_in));
 		e->in_tab_valid[ds] = !replay;
@@ -2044,7 +2081,18 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	}
 	if (any_host)
 		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_in));
-	// (k_input also zeroes the ticket / abort / progress words of the wavefront kernels)
+	// No padded copy of the frame (no k_input: -6.3 MB of traffic and a launch per 1080p frame) where the caller's packed
+	// frame can serve as the source planes: a width that is a multiple of 16 (no column to replicate; the rows below the
+	// picture are the last row, which the readers take by clamping) and 16-byte aligned frames (they load 16 bytes a lane).
+	{
+		bool direct = e->src_direct_ok;
+		for (int s = 0; s < 2 * S && direct; s++)
+			direct = ((uintptr_t)f.in_used[s] & 15u) == 0;
+		P.src_direct = direct ? 1 : 0;
+		P.src_last_y = direct ? P.height - 1 : P.ch - 1;
+		P.src_last_c = direct ? P.height / 2 - 1 : P.ch / 2 - 1;
+	}
+	// (k_input -- k_intra_decide without it -- also zeroes the ticket / abort / progress words of the intra wavefront)
 	*f.h_wf_err = 0;
 	P.wf_err = f.d_wf_err;
 	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
@@ -2077,6 +2125,16 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.skip = e->d_skip[lane];
 	P.bit_off = e->d_bit_off[lane];
 	P.run_before = e->d_run[lane];
+	P.ent_rec = e->d_ent_rec[lane];
+	{
+		P.pk_store_mode = getenv("CEDAR_PK_STORE") ? atoi(getenv("CEDAR_PK_STORE")) : 2;
+		const char *g = getenv("CEDAR_PK_GRID"); // (development: workgroups per unit, fixed)
+		const int seen = e->pk_seen[idr ? 1 : 0], unit_mbs = P.unit_mb_cap;
+		P.pk_launch_chunks = g ? atoi(g) : seen ? 2 * seen + 2 : idr ? unit_mbs / 12 + 8 : unit_mbs / 96 + 4; // (80 / 10 bytes a macroblock)
+	}
+	P.pk_first = e->d_pk_first[lane];
+	P.pk_agg = e->d_pk_agg[lane];
+	P.pk_unit = e->d_pk_unit[lane];
 	P.unit_bits = e->d_unit_bits[lane];
 	P.rbsp = e->d_rbsp[lane];
 	P.esc_cnt = e->d_esc[lane];
@@ -2120,13 +2178,16 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		// the streams of this cohort's deblocking and entropy chain (cedar_enc::s_db_c)
 		hipStream_t s_dbc = !pipe && !ahead && e->s_db_c[c] ? e->s_db_c[c] : s_db;
 		hipStream_t s_entc = !pipe && e->s_ent_c[c] ? e->s_ent_c[c] : s_ent;
-		if (Launch::input(Pc, s_in))
+		if (!Pc.src_direct && Launch::input(Pc, s_in))
 			return fail(e, -EIO, "k_input launch failed");
 		if (c == C - 1)
 			tm_end(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
-		HIP_TRY(e, hipEventRecord(e->ev_input[ei], s_in));
-		if (s_in != s_ana)
-			HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[ei], 0));
+		// (frames read where the caller put them and nothing copied: the input stream has nothing of this frame to wait for)
+		if (!Pc.src_direct || in_work) {
+			HIP_TRY(e, hipEventRecord(e->ev_input[ei], s_in));
+			if (s_in != s_ana)
+				HIP_TRY(e, hipStreamWaitEvent(s_ana, e->ev_input[ei], 0));
+		}
 
 		auto launch_deblock = [&]() -> int {
 		// ---- in-loop deblocking: produces the next frame's reference ----
@@ -2272,16 +2333,14 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		// macroblocks differ in QP: QP_Y as the decoder will hold it, for the mb_qp_delta of the next one
 		if (Pc.roi_off && Launch::qp_eff(Pc, s_entc))
 			return fail(e, -EIO, "k_qp_eff launch failed");
-		if (Launch::entropy(Pc, s_entc))
+		// (frames back to back: every cohort's last kernel leaves its size words zeroed, the last one raises the flag)
+		Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done : self_zero ? e->d_abort_all + 8 : nullptr;
+		Pc.done_tag = f.done_tag;
+		if (Launch::entropy_out(Pc, s_entc, e->dv_out[f.host_out] + (size_t)(S * c / C) * (C > 1 ? e->stream_out_cap : 0),
+					e->dv_sizes[slot] + (size_t)c * (S + 2)))
 			return fail(e, -EIO, "entropy launch failed");
 		if (c == C - 1)
 			tm_end(e, f, CEDAR_ENC_STAGE_ENTROPY, s_entc);
-		// (frames back to back: every cohort's k_copy_out leaves its size words zeroed, the last one raises the flag)
-		Pc.done_flag = pipe || (self_reset && c == C - 1) ? f.d_done : self_zero ? e->d_abort_all + 8 : nullptr;
-		Pc.done_tag = f.done_tag;
-		if (Launch::copy_out(Pc, s_entc, e->dv_out[f.host_out] + (size_t)(S * c / C) * (C > 1 ? e->stream_out_cap : 0),
-				     e->dv_sizes[slot] + (size_t)c * (S + 2)))
-			return fail(e, -EIO, "k_copy_out launch failed");
 		if (!pipe && e->ev_entropy[ei])
 			HIP_TRY(e, hipEventRecord(e->ev_entropy[ei], s_entc));
 		if (!pipe && c == C - 1) {
@@ -2373,6 +2432,9 @@ static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again =
 	}
 	for (int l = 0; l < e->ent_lanes; l++)
 		HIP_TRY(e, hipMemset(e->d_stream_size[l], 0, sizeof(uint32_t) * MAX_COHORTS * (e->ext.n_streams + 4)));
+	for (uint32_t *v : e->d_cut_votes) // (the frame that failed never reported, and so never cleared, its votes)
+		if (v)
+			HIP_TRY(e, hipMemset(v, 0, sizeof(uint32_t)));
 	HIP_TRY(e, hipMemset(e->d_abort_all, 0, sizeof(uint32_t)));
 	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (hipMemset runs on the null stream, which the session's streams do not wait for)
 	for (const ReplayIn &r : later) {
@@ -2532,6 +2594,7 @@ static int collect_frame(cedar_enc *e)
 		for (int s = s0; s < s1; s++) {
 			e->res_off[s] = off;
 			e->res_size[s] = sz[s - s0];
+			e->pk_seen[f.idr ? 1 : 0] = std::max(e->pk_seen[f.idr ? 1 : 0], (int)(sz[s - s0] / PK_CHUNK) + 1);
 			uint8_t *front = e->h_out[f.host_out] + off;
 			if (f.aud) {
 				const std::vector<uint8_t> &a = e->aud_nal[f.aud - 1];

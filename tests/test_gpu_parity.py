@@ -717,11 +717,12 @@ def test_two_sessions_interleaved_pipelined(ce):
     {"CEDAR_WF_SPLIT": "1", "CEDAR_WF_SPLIT_INTRA": "1"},            # 17 bands on one workgroup: bands wrap around its wave teams
     {"CEDAR_WF_SPLIT": "3", "CEDAR_WF_SPLIT_INTRA": "2", "CEDAR_DEBLOCK_PLANES": "0"},  # both planes in every wave pair
     {"CEDAR_WF_SPLIT": "8", "CEDAR_WF_SPLIT_INTRA": "8", "CEDAR_ROW_PIPE": "0"},
+    {"CEDAR_ENTROPY_FUSED": "0", "CEDAR_INTRA_ROWS": "0"},   # round 3's back end (k_zero .. k_esc_write, k_copy_out) and intra wavefront
 ])
 def test_1080p_wavefront_shapes_match_oracle(ce, monkeypatch, env):
     """The wavefront kernels' work split (workgroups per unit, bands per workgroup, planes per wave
     pair) is a launch-shape choice: every shape must give the oracle's bytes."""
-    for k in ("CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DEBLOCK_PLANES", "CEDAR_ROW_PIPE"):
+    for k in ("CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DEBLOCK_PLANES", "CEDAR_ROW_PIPE", "CEDAR_ENTROPY_FUSED", "CEDAR_INTRA_ROWS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -732,6 +733,38 @@ def test_1080p_wavefront_shapes_match_oracle(ce, monkeypatch, env):
     with ce.CedarEncoder(width=w, height=h, qp=26, keyframe_interval=25) as enc:
         got = _encode_pipelined(enc, frames)
     assert got == want
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_both_entropy_back_ends_give_the_oracles_bytes(ce, monkeypatch, fused):
+    """k_pack_out (one launch behind k_scan: bits, emulation prevention, NAL layout, bytes on the host) and the chain it
+    replaces (CEDAR_ENTROPY_FUSED=0) on what stresses a back end: slices and lock-step streams (many NAL units to lay out),
+    I_PCM pictures (byte-aligned raw samples, long zero runs to escape: a black picture), pictures of a few bytes."""
+    monkeypatch.setenv("CEDAR_ENTROPY_FUSED", fused)
+    rng = np.random.RandomState(7)
+    cases = [(320, 240, 24, 3, 3, "B"), (640, 368, 1, 1, 1, "noise"), (96, 64, 4, 2, 2, "black"), (1920, 1080, 40, 1, 1, "static")]
+    for w, h, qp, slices, streams, kind in cases:
+        def frame(f, s):
+            if kind == "noise":
+                r = np.random.RandomState(100 * f + s)
+                return r.randint(0, 256, w * h).astype(np.uint8), r.randint(0, 256, w * h // 2).astype(np.uint8)
+            if kind == "black":   # I_PCM cannot happen here; zero samples with a tiny texture: long zero runs in a short stream
+                y = np.zeros(w * h, np.uint8)
+                y[(f * 7 + s) % 50::97] = 3
+                return y, np.zeros(w * h // 2, np.uint8)
+            if kind == "static":
+                return ol.gen_frame("A", w, h, 0)
+            return ol.gen_frame(kind, w, h, f, s << 8)
+        n = 4
+        oes = [ol.OracleEncoder(ol.default_config(w, h, qp=qp, keyint=3, slice_count=slices)) for _ in range(streams)]
+        with ce.CedarEncoder(width=w, height=h, qp=qp, keyframe_interval=3, slice_count=slices, n_streams=streams) as enc:
+            for f in range(n):
+                for s in range(streams):
+                    enc.set_input(*frame(f, s), stream=s)
+                enc.encode()
+                for s in range(streams):
+                    assert enc.output(s) == oes[s].encode(*frame(f, s)), (w, h, kind, f, s)
+    del rng
 
 
 def test_long_pipelined_run_many_gops(ce):
