@@ -136,14 +136,14 @@ struct Params {
 	uint32_t *esc_cnt;               // [n_units][esc_chunks_cap]
 	uint32_t *nal_off;               // [n_units] byte offset of the NAL in out
 	uint32_t *nal_size;              // [n_units]
-	uint32_t *stream_size;           // [n_streams + 3] bytes per stream; [n] total; [n+1] error flags; [n+2] units scanned (k_esc_scan) / chunks through (k_pack_out)
+	uint32_t *stream_size;           // [n_streams + 3] bytes per stream; [n] total; [n+1] error flags; [n+2] units scanned (k_esc_scan) / chunks through (k_pack_out); [n+3] k_copy_out's workgroups / k_pack_out's tickets
 	// the fused back end (k_pack_out; nullptr: k_zero .. k_esc_write + k_copy_out through the RBSP buffer)
 	uint64_t *ent_rec;               // [n_units][unit_mb_cap + 2] per entry: bit position | (skip run, bits of the macroblock (0: skipped), I_PCM) << 32
 	uint32_t *pk_first;              // [n_units][pk_chunks_cap] the entry that covers the first bit of every chunk of PK_CHUNK RBSP bytes
 	uint64_t *pk_agg;                // [n_units][pk_chunks_cap] a chunk's escaping table | the frame's tag (db_tag) << 32
 	uint64_t *pk_unit;               // [n_units] a unit's escape bytes | the frame's tag << 32
 	int32_t pk_chunks_cap;           // chunks per unit the arrays hold
-	int32_t pk_store_mode;           // (development, CEDAR_PK_STORE) how the bytes reach the host: 0 plain stores (coherent host memory), 1 write-through stores, 2 plain stores and a release fence per workgroup
+	int32_t pk_fence;                // 1: the host buffers are cached by the GPU (CEDAR_HOST_COHERENT=0): every workgroup writes its L2 back before it counts out
 	int32_t pk_launch_chunks;        // workgroups per unit of this launch (a unit's last one takes the chunks beyond)
 	uint8_t *out;                    // compact output: all streams back to back
 	const SliceHdr *hdr;             // [n_units] (streams differ where they are GOP lanes: idr_pic_id)

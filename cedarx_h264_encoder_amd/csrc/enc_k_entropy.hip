@@ -864,6 +864,10 @@ __global__ __launch_bounds__(1024) void k_scan(Params p)
 	if (threadIdx.x == 0) {
 		s_carry_max = -1;
 		s_carry_sum = p.hdr[unit].nbits;
+		// k_pack_out's ticket counter starts at zero (it cannot clear the word itself: a workgroup that starts after the
+		// launch's last chunk is done must still find a ticket that says so)
+		if (p.ent_rec && unit == 0)
+			__hip_atomic_store(&p.stream_size[p.n_streams + 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	__syncthreads();
 	for (int base = 0; base <= n; base += SCAN_THREADS * SC_PER_T) {
@@ -1302,8 +1306,13 @@ DEVI uint32_t pk_wait_word(const uint64_t *w, uint32_t tag, const Params &p, boo
 	uint32_t spins = 0;
 	uint64_t t0 = 0;
 	while ((uint32_t)(v >> 32) != tag && !dead) {
-		if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+		if (wait_expired(++spins, t0)) { // (its own code: the word it waited for never came)
 			__hip_atomic_store(p.wf_err, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			dead = true;
+			break;
+		}
+		if ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // another wait of the session ran out
 			dead = true;
 			break;
 		}
@@ -1346,24 +1355,63 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 	__shared__ __attribute__((aligned(16))) uint8_t s_o[16 + 5 + PK_CHUNK + PK_CHUNK / 2 + 32];
 	__shared__ uint64_t s_wt[PK_THREADS / 64];
 	__shared__ uint32_t s_pre[6]; // escapes in front of the chunk, state before it, NAL offset, chunks of the launch, dead, last
-	const int unit = blockIdx.y;
+	__shared__ int s_job[4]; // the chunk this workgroup does next: unit, chunk, chunks of the launch; -1: none left
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const int n_units = p.n_streams * p.slice_num;
+	const uint32_t tag = p.db_tag;
+	const bool is_p = !p.is_idr;
+	bool dead = false;
+	// Chunks are taken by TICKET, in the order the workgroups get to run: ticket k is chunk k of the launch in unit-major
+	// order, and a chunk only waits for chunks with lower tickets -- which were taken by workgroups that are RUNNING, so the
+	// wait ends whatever else fills the chip. (The first version gave workgroup (unit, chunk) its chunk by index and relied
+	// on every XCD starting its share of a launch in order: true, but two such launches side by side -- two encoder processes
+	// on one GPU, 2 x 32 streams -- can each fill an XCD with workgroups that wait for one the OTHER launch leaves no room
+	// for: -EIO after 3 s in tests/test_bench_contract.py's two-rank rehearsal.) A workgroup that has done its chunk takes the
+	// next ticket: the launch needs no workgroup per possible chunk, only enough of them to keep the chip busy.
+	for (;;) {
+	if (wave == 0) {
+		int ticket = 0;
+		if (lane == 0)
+			ticket = (int)__hip_atomic_fetch_add(&p.stream_size[p.n_streams + 3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		ticket = __builtin_amdgcn_readfirstlane(ticket);
+		int before = 0, found_u = -1, found_c = 0; // chunks of the units in front; the ticket's unit and chunk
+		for (int base = 0; base < n_units; base += 64) {
+			const int u2 = base + lane;
+			const uint32_t nb2 = u2 < n_units ? (p.unit_bits[u2] + 7) >> 3 : 0u;
+			const int nc2 = (int)min((nb2 + PK_CHUNK - 1) / PK_CHUNK, (uint32_t)p.pk_chunks_cap);
+			int incl = nc2;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const int o = __shfl_up(incl, off, 64);
+				if (lane >= off)
+					incl += o;
+			}
+			const int lo = before + incl - nc2; // first ticket of unit u2
+			const uint64_t hit = __ballot(ticket >= lo && ticket < lo + nc2);
+			if (hit && found_u < 0) {
+				const int l = __builtin_ctzll(hit);
+				found_u = base + l;
+				found_c = ticket - __shfl(lo, l, 64);
+			}
+			before += __shfl(incl, 63, 64);
+		}
+		if (lane == 0) {
+			s_job[0] = found_u;
+			s_job[1] = found_c;
+			s_job[2] = before; // chunks of the launch
+		}
+	}
+	__syncthreads();
+	const int unit = s_job[0], c = s_job[1];
+	const uint32_t all_chunks = (uint32_t)s_job[2];
+	if (unit < 0)
+		return; // (no chunk left: uniform)
 	const uint32_t nbytes = (p.unit_bits[unit] + 7) >> 3;
 	const int n_chunks = (int)min((nbytes + PK_CHUNK - 1) / PK_CHUNK, (uint32_t)p.pk_chunks_cap);
-	if ((int)blockIdx.x >= n_chunks)
-		return;
-	// The launch has as many workgroups per unit as the session's pictures have needed so far, and some (pk_launch_chunks):
-	// a unit's last workgroup takes whatever chunks lie beyond, one after the other (it still only waits for lower indices)
-	const bool takes_tail = blockIdx.x == gridDim.x - 1;
 	const int st = unit / p.slice_num, ls = unit % p.slice_num;
 	int r0, r1;
 	slice_rows(p.mb_h, p.slice_count, p.slice_first + ls, &r0, &r1);
 	const int n = (r1 - r0) * p.mb_w;
-	const uint32_t tag = p.db_tag;
-	const bool is_p = !p.is_idr;
-	bool dead = false;
-	for (int c = (int)blockIdx.x; c < n_chunks; c = takes_tail ? c + 1 : n_chunks) {
 	const int bit0 = c * PK_BITS;                       // first bit of the chunk
 	const int len_c = (int)min((uint32_t)PK_CHUNK, nbytes - (uint32_t)c * PK_CHUNK); // its bytes
 
@@ -1538,7 +1586,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 	__syncthreads();
 	const uint32_t esc_before = s_pre[0];
 	const int s_in = (int)s_pre[1];
-	const uint32_t nal_off = s_pre[2], all_chunks = s_pre[3];
+	const uint32_t nal_off = s_pre[2];
 	const bool failed = s_pre[4] != 0;
 
 	// ---- escaped bytes into LDS, congruent to their address modulo 16; then out ----
@@ -1569,22 +1617,12 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 		uint8_t *g = host_out + out0 - a; // 16-byte aligned
 		for (uint32_t j = t; 16 * j < a + out_len; j += PK_THREADS) {
 			const uint32_t lo = 16 * j, hi16 = lo + 16;
-			// (write-through stores: the GPU caches pinned host memory like any other, and nothing here writes an L2 back)
+			// (the host buffer is coherent memory, which the GPU does not cache: see the count-out below)
 			if (lo >= a && hi16 <= a + out_len) {
-				if (p.pk_store_mode == 1) {
-					const uint64_t *v = (const uint64_t *)(s_o + lo);
-					__hip_atomic_store((uint64_t *)(g + lo), v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-					__hip_atomic_store((uint64_t *)(g + lo + 8), v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				} else {
-					*(u32x4 *)(g + lo) = *(const u32x4 *)(s_o + lo);
-				}
+				*(u32x4 *)(g + lo) = *(const u32x4 *)(s_o + lo);
 			} else {
-				for (uint32_t b = max(lo, a); b < min(hi16, a + out_len); b++) {
-					if (p.pk_store_mode == 1)
-						__hip_atomic_store(g + b, s_o[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-					else
-						g[b] = s_o[b];
-				}
+				for (uint32_t b = max(lo, a); b < min(hi16, a + out_len); b++)
+					g[b] = s_o[b];
 			}
 		}
 	} else if (t == 0) {
@@ -1594,11 +1632,12 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 	// ---- count out; the last workgroup of the launch lays the sizes down and raises the frame's flag ----
 	// (No release fence: at agent or system scope it writes the XCD's whole L2 back -- beside a batch's k_inter and
 	// deblocking that is megabytes of their dirty lines per workgroup; the first version, with one, took 0.4-0.9 ms per
-	// launch of 16 pictures. The bytes went to the host by write-through stores: a thread whose stores have been
-	// acknowledged -- s_waitcnt vmcnt(0) -- has delivered them. (Plain stores stay in the L2 until something writes it
-	// back: the second version's sizes arrived a frame late.) What the last workgroup reads was written with write-through
-	// atomics or by the kernels before this one.)
-	if (p.pk_store_mode == 2)
+	// launch of 16 pictures. The host buffers are coherent memory, which the GPU does not cache: a thread whose stores
+	// have been acknowledged -- s_waitcnt vmcnt(0) -- has delivered them. (In plain pinned memory they stay in the L2 until
+	// something writes it back: the second version's sizes arrived a frame late; write-through stores of 8 bytes each got
+	// them there at 27 MB/s. pk_fence keeps the fence for such buffers.) What the last workgroup reads was written with
+	// write-through atomics or by the kernels before this one.)
+	if (p.pk_fence)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
@@ -1628,13 +1667,13 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 		__hip_atomic_store(&host_sizes[p.n_streams + 2], p.cut_votes[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		p.cut_votes[0] = 0; // ... and the slot's next P picture starts from zero
 	}
-	for (int i = 0; i < p.n_streams + 4; i++) // the size words are left zeroed for the lane's next frame
+	for (int i = 0; i < p.n_streams + 3; i++) // the size words are left zeroed for the lane's next frame (the ticket word: k_scan)
 		__hip_atomic_store(&p.stream_size[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the sizes are on the host before the flag is)
 	if (p.done_flag)
 		__hip_atomic_store(p.done_flag, p.done_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
-	__syncthreads(); // (the tail: the LDS images are the next chunk's now)
+	__syncthreads(); // (the LDS images and the job words are the next chunk's now)
 	}
 }
 
@@ -1673,7 +1712,12 @@ int Launch::entropy_out(const Params &p, void *stream, uint8_t *host_out, uint32
 		return -1;
 	if (!p.ent_rec)
 		return copy_out(p, stream, host_out, host_sizes);
-	hipLaunchKernelGGL(k_pack_out, dim3((unsigned)min(max(p.pk_launch_chunks, 1), p.pk_chunks_cap), (unsigned)(p.n_streams * p.slice_num)), dim3(PK_THREADS), 0, (hipStream_t)stream, p, host_out, host_sizes);
+	// as many workgroups as the launch is expected to have chunks (pk_launch_chunks per unit), at most four to a CU: they take
+	// chunks by ticket until none is left, so neither too few nor too many is wrong
+	const int n_units = p.n_streams * p.slice_num;
+	const long want = (long)n_units * (p.pk_launch_chunks > 0 ? p.pk_launch_chunks : 1);
+	const unsigned grid = (unsigned)(want < 1 ? 1 : want > 1024 ? 1024 : want);
+	hipLaunchKernelGGL(k_pack_out, dim3(grid), dim3(PK_THREADS), 0, (hipStream_t)stream, p, host_out, host_sizes);
 	return (int)hipGetLastError();
 }
 

@@ -325,6 +325,7 @@ struct cedar_enc {
 	// k_pack_out's workgroups per unit: twice what the session's pictures of the kind (IDR, P) have needed so far -- a guess by
 	// size before the first one is back; whatever a picture needs beyond that its last workgroup does alone (same bytes)
 	int pk_seen[2] = { 0, 0 };
+	bool host_coherent = true;   // the pinned output buffers are fine-grained host memory (see CONFIG)
 	bool ent_fused = true;       // k_pack_out behind k_scan (CEDAR_ENTROPY_FUSED=0: k_zero .. k_esc_write + k_copy_out through the RBSP buffer)
 	uint64_t *d_ent_rec[ENT_LANES] = {}, *d_pk_agg[ENT_LANES] = {}, *d_pk_unit[ENT_LANES] = {};
 	uint32_t *d_pk_first[ENT_LANES] = {};
@@ -978,7 +979,8 @@ extern "C" int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar
 	const Plan p = plan_static(in);
 	const PlanRun run = plan_run(in, p, PlanProbe{ q->db_streams_usable, q->holds_pipe_token });
 	*r = cedar_enc_plan_result{ p.error, p.depth, p.wf_split, p.wf_split_intra, p.db_pairs, p.split_planes, p.want_row_pipe,
-				    p.db_streams_wanted, run.row_pipe, run.db_streams, run.inter_bands, run.defer_default, run.cohorts, p.db_rows };
+				    p.db_streams_wanted, run.row_pipe, run.db_streams, run.inter_bands, run.defer_default, run.cohorts, p.db_rows,
+				    p.ir_rows, (2 * p.n_units * p.db_bands + 7) / 8, p.db_lds_kb, p.idr_beside_ok };
 	return 0;
 }
 
@@ -1117,9 +1119,13 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S_user, hipHostMallocDefault));
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S_user, hipHostMallocDefault));
 	for (int i = 0; i < e->depth; i++) {
-		// (CEDAR_HOST_COHERENT, development: the bytestream and size buffers as coherent -- fine-grained -- host memory, which
-		// the GPU does not cache)
-		const unsigned out_flags = hipHostMallocMapped | (getenv("CEDAR_HOST_COHERENT") && atoi(getenv("CEDAR_HOST_COHERENT")) ? hipHostMallocCoherent : 0u);
+		// The bytestream and size buffers are COHERENT (fine-grained) host memory: the GPU does not cache it, so what k_pack_out
+		// stores there is delivered when the stores have been acknowledged. (Plain hipHostMallocMapped memory is cached in the
+		// L2 of whichever XCD wrote it until a release fence writes that L2 back -- beside a batch's k_inter that is megabytes
+		// of other kernels' dirty lines per workgroup: 32 x 1080p 144 M MB/s with such a fence in every workgroup of
+		// k_pack_out, 182 M without. CEDAR_HOST_COHERENT=0 keeps the old kind, and the fences.)
+		e->host_coherent = !(getenv("CEDAR_HOST_COHERENT") && atoi(getenv("CEDAR_HOST_COHERENT")) == 0);
+		const unsigned out_flags = hipHostMallocMapped | (e->host_coherent ? hipHostMallocCoherent : 0u);
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, out_flags));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (size_t)MAX_COHORTS * (S + 2) * sizeof(uint32_t), out_flags));
@@ -2127,7 +2133,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.run_before = e->d_run[lane];
 	P.ent_rec = e->d_ent_rec[lane];
 	{
-		P.pk_store_mode = getenv("CEDAR_PK_STORE") ? atoi(getenv("CEDAR_PK_STORE")) : 2;
+		P.pk_fence = e->host_coherent ? 0 : 1;
 		const char *g = getenv("CEDAR_PK_GRID"); // (development: workgroups per unit, fixed)
 		const int seen = e->pk_seen[idr ? 1 : 0], unit_mbs = P.unit_mb_cap;
 		P.pk_launch_chunks = g ? atoi(g) : seen ? 2 * seen + 2 : idr ? unit_mbs / 12 + 8 : unit_mbs / 96 + 4; // (80 / 10 bytes a macroblock)

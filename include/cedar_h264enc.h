@@ -328,6 +328,11 @@ struct cedar_enc_plan_result {
 	int want_row_pipe, db_streams_wanted;   /* before the probes */
 	int row_pipe, db_streams, inter_bands, defer_default, cohorts; /* after them */
 	int deblock_rows;                       /* 1: deblocking with a wave per macroblock row (few units), 0: wave pairs per band */
+	int intra_rows;                         /* 1: intra reconstruction as a wavefront of 4x4 blocks, a wave per macroblock row */
+	/* who may be resident and waiting (sessions that pipeline on k_deblock_rows): the workgroups a picture's deblocking
+	 * puts on ONE of the 8 XCDs (each XCD places its share of a launch in order on its own CUs), the KiB of LDS each
+	 * claims, and whether a third picture's -- an IDR picture's deblocking beside its intra wavefront -- may join the two */
+	int db_wgs_per_xcd, db_lds_kb, idr_beside_ok;
 };
 int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar_enc_plan_result *r);
 

@@ -18,11 +18,12 @@ class Query(ctypes.Structure):
 class Result(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("error", "depth", "wf_split", "wf_split_intra", "db_pairs", "split_planes",
                                             "want_row_pipe", "db_streams_wanted", "row_pipe", "db_streams", "inter_bands",
-                                            "defer_default", "cohorts", "deblock_rows")]
+                                            "defer_default", "cohorts", "deblock_rows", "intra_rows", "db_wgs_per_xcd", "db_lds_kb",
+                                            "idr_beside_ok")]
 
 
 ENV = ("CEDAR_ROW_PIPE", "CEDAR_PIPE_DEPTH", "CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DB_PAIRS", "CEDAR_DEBLOCK_STREAMS",
-       "CEDAR_DEBLOCK_PLANES", "CEDAR_INTER_BANDS", "CEDAR_DEFER", "CEDAR_COHORTS", "CEDAR_DEBLOCK_ROWS")
+       "CEDAR_DEBLOCK_PLANES", "CEDAR_INTER_BANDS", "CEDAR_DEFER", "CEDAR_COHORTS", "CEDAR_DEBLOCK_ROWS", "CEDAR_INTRA_ROWS")
 
 
 @pytest.fixture
@@ -143,3 +144,39 @@ def test_slices_and_slice_shards(plan, monkeypatch):
     L = ce.load_library()
     bad = Query(120, 68, 4, 3, 2, 1, 256, 2, 1)
     assert L.cedar_enc_plan(ctypes.byref(bad), ctypes.byref(Result())) < 0
+
+
+def test_resident_deblock_workgroups_always_leave_every_xcd_room(plan):
+    """Round 3's hang of 4 to 8 pipelined 1080p streams on k_deblock_rows, and round 4's one 3840x2160 session in ten that
+    ended in -EIO: a pipelined deblock kernel's workgroups are RESIDENT and poll for their picture's analysis, every band
+    claims enough LDS to have its CU to itself (81 KB), the hardware deals a launch's workgroups round-robin over the 8
+    XCDs and each XCD places its share in order on its own 32 CUs -- so the analysis (and an IDR picture's intra
+    wavefront) stalls as soon as ONE XCD has no CU left, however empty the rest of the chip is: three pictures of 72
+    workgroups and 72 intra workgroups were 288 on 256. The guard is counted per XCD: the pictures that can be resident
+    at a time -- one per deblock stream, a third only where idr_beside_ok says so -- leave two CUs of every XCD alone."""
+    seen_pipelined = seen_refused = 0
+    for w, h in ((320, 240), (854, 480), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (4096, 2304), (1920, 4320)):
+        for streams in (1, 2, 3, 4, 5, 6, 8):
+            for slices in (1, 2, 4):
+                for cus in (256, 128, 64):
+                    r = plan(w=w, h=h, streams=streams, slices=slices, cus=cus)
+                    if not (r.deblock_rows and r.row_pipe):
+                        seen_refused += 1
+                        continue
+                    seen_pipelined += 1
+                    xcd = cus // 8
+                    assert r.db_lds_kb == 81                      # a CU per band, room for one intra workgroup (<= 79 KB) beside it
+                    assert r.db_streams <= 2
+                    assert r.db_streams * r.db_wgs_per_xcd <= xcd - 2, (w, h, streams, slices, cus)
+                    if r.idr_beside_ok:
+                        assert 3 * r.db_wgs_per_xcd <= xcd - 2, (w, h, streams, slices, cus)
+    assert seen_pipelined > 20 and seen_refused > 20
+    # the sessions of the bench line: one 1080p stream and the 4K picture may have an IDR picture's deblocking beside its intra
+    # wavefront only where three pictures fit
+    assert plan().idr_beside_ok == 1 and plan().db_wgs_per_xcd == 5               # 34 workgroups a picture
+    assert plan(w=3840, h=2160).idr_beside_ok == 1 and plan(w=3840, h=2160).db_wgs_per_xcd == 9   # 68 a picture: 3 x 9 <= 30
+    r = plan(w=2560, h=1440, streams=2)                                            # 92 a picture: 2 x 12 <= 30 < 3 x 12
+    assert (r.deblock_rows, r.row_pipe, r.db_wgs_per_xcd, r.idr_beside_ok) == (1, 1, 12, 0)
+    assert plan(streams=4).row_pipe == 1 and plan(streams=4).deblock_rows == 0     # 4 x 1080p: 136 a picture, 2 x 17 > 30 -> the wave pairs
+    # back to back nothing waits: no claim
+    assert plan(streams=8).deblock_rows == 1 and plan(streams=8).row_pipe == 0 and plan(streams=8).db_lds_kb == 16
