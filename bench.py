@@ -71,6 +71,7 @@ KERNEL_BYTES_PER_MB = {
 }
 KERNEL_NAME = {"input": "k_input", "intra_decide": "k_intra_decide", "intra_recon": "k_intra_recon2", "inter": "k_inter",
                "deblock": "k_deblock2_planes", "entropy": "k_cavlc2..k_copy_out"}
+KERNEL_NAME_FUSED_ENTROPY = "k_cavlc2, k_scan, k_pack_out"
 PIPELINE_BYTES_PER_MB = {"I": 768.0, "P": 1152.0}
 # What really bounds each kernel. k_inter: the exhaustive +-16 search is 33*33
 # candidates x 256 absolute differences per macroblock; every byte-SAD instruction of gfx950 retires
@@ -428,7 +429,8 @@ def run_rank(args, rank, world, local_rank):
     def kernel_line(k, ms):
         alg = KERNEL_BYTES_PER_MB[k] * mb_per_launch + (nbytes / max(1, args.steps) if k == "entropy" else 0)
         ach = alg / (ms * 1e-3) / 1e9
-        name = "k_deblock_rows" if k == "deblock" and st.get("deblock_rows") else "k_intra_rows" if k == "intra_recon" and st.get("intra_rows") else KERNEL_NAME[k]
+        name = ("k_deblock_rows" if k == "deblock" and st.get("deblock_rows") else "k_intra_rows" if k == "intra_recon" and st.get("intra_rows")
+                else KERNEL_NAME_FUSED_ENTROPY if k == "entropy" and st.get("entropy_fused") else KERNEL_NAME[k])
         line = {"kernel": name, "work_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "hbm_GBs": round(ach, 2), "hbm_frac": ach / HBM_PEAK_GBS}
         if k == "inter":
@@ -477,11 +479,11 @@ def run_rank(args, rank, world, local_rank):
         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
         "true_bound": dom["true_bound"],
         "wf_split": st.get("wf_split"),
-        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams", "deblock_rows", "intra_rows")},
+        "schedule": {k: st.get(k) for k in ("frames_pipelined", "idr_lookahead", "depth", "deblock_streams", "deblock_rows", "intra_rows", "src_direct", "entropy_fused")},
         "pipeline_achieved_GBs": round(pipe_bytes / dt_max / 1e9, 3),
         "pipeline_frac": pipe_bytes / dt_max / 1e9 / HBM_PEAK_GBS,
         # every stage with frames back to back (duration = work), against its own bound
-        "kernels": [kernel_line(k, v) for k, v in (work_ms or {}).items() if v > 0],
+        "kernels": [kernel_line(k, v) for k, v in (work_ms or {}).items() if v > 0 and not (k == "input" and st.get("src_direct"))],
         # every stage as launched in the measured (pipelined) session, from its warm-up frames
         "stage_ms_per_launch_pipelined": ({k: round(st["warmup"]["ms"][k] / max(1, st["warmup"]["launches"][k]), 4)
                                            for k in st["warmup"]["ms"]} if st.get("warmup") else None),

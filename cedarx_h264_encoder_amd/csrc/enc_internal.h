@@ -143,7 +143,7 @@ struct Params {
 	uint64_t *pk_agg;                // [n_units][pk_chunks_cap] a chunk's escaping table | the frame's tag (db_tag) << 32
 	uint64_t *pk_unit;               // [n_units] a unit's escape bytes | the frame's tag << 32
 	int32_t pk_chunks_cap;           // chunks per unit the arrays hold
-	int32_t pk_fence;                // 1: the host buffers are cached by the GPU (CEDAR_HOST_COHERENT=0): every workgroup writes its L2 back before it counts out
+	int32_t pk_deliver;              // how k_pack_out's bytes reach the host: 0 plain stores, the flag from the next kernel of the stream; 1 write-through stores, waited for, the flag from its last workgroup
 	int32_t pk_launch_chunks;        // workgroups per unit of this launch (a unit's last one takes the chunks beyond)
 	uint8_t *out;                    // compact output: all streams back to back
 	const SliceHdr *hdr;             // [n_units] (streams differ where they are GOP lanes: idr_pic_id)

@@ -1617,12 +1617,20 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 		uint8_t *g = host_out + out0 - a; // 16-byte aligned
 		for (uint32_t j = t; 16 * j < a + out_len; j += PK_THREADS) {
 			const uint32_t lo = 16 * j, hi16 = lo + 16;
-			// (the host buffer is coherent memory, which the GPU does not cache: see the count-out below)
+			// (how the bytes get there: see the count-out below)
 			if (lo >= a && hi16 <= a + out_len) {
-				*(u32x4 *)(g + lo) = *(const u32x4 *)(s_o + lo);
+				const u32x4 v = *(const u32x4 *)(s_o + lo);
+				if (p.pk_deliver == 0)
+					*(u32x4 *)(g + lo) = v;
+				else // 16 bytes written through to the host (system scope): the line does not stay in this XCD's L2
+					asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g + lo), "v"(v) : "memory");
 			} else {
-				for (uint32_t b = max(lo, a); b < min(hi16, a + out_len); b++)
-					g[b] = s_o[b];
+				for (uint32_t b = max(lo, a); b < min(hi16, a + out_len); b++) {
+					if (p.pk_deliver == 0)
+						g[b] = s_o[b];
+					else
+						__hip_atomic_store(g + b, s_o[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
 			}
 		}
 	} else if (t == 0) {
@@ -1630,16 +1638,20 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 	}
 
 	// ---- count out; the last workgroup of the launch lays the sizes down and raises the frame's flag ----
-	// (No release fence: at agent or system scope it writes the XCD's whole L2 back -- beside a batch's k_inter and
-	// deblocking that is megabytes of their dirty lines per workgroup; the first version, with one, took 0.4-0.9 ms per
-	// launch of 16 pictures. The host buffers are coherent memory, which the GPU does not cache: a thread whose stores
-	// have been acknowledged -- s_waitcnt vmcnt(0) -- has delivered them. (In plain pinned memory they stay in the L2 until
-	// something writes it back: the second version's sizes arrived a frame late; write-through stores of 8 bytes each got
-	// them there at 27 MB/s. pk_fence keeps the fence for such buffers.) What the last workgroup reads was written with
-	// write-through atomics or by the kernels before this one.)
-	if (p.pk_fence)
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	// WHEN ARE THE BYTES ON THE HOST? The GPU caches pinned host memory like any other: a plain store sits in the L2 of the
+	// XCD that made it until that L2 is written back. Three ways, all measured (32 x 1080p / 8 x 1080p / one stream, M MB/s):
+	//  * a release fence in every workgroup before it counts out (what k_copy_out does): it writes the XCD's WHOLE L2 back
+	//    -- beside a batch's k_inter and deblocking that is megabytes of other kernels' dirty lines per workgroup: 144 / 129 /
+	//    51. Without it, or with "coherent" host memory and s_waitcnt vmcnt(0) alone, or with a read-back of the chunk's last
+	//    byte, the flag overtook the bytes: a pipelined session delivered whole chunks of the frame 16 before
+	//    (tools/dev/pk_diff.py), at 194 / 140 / 57 -- the price list's "plain payload + vmcnt(0), no release: stale";
+	//  * pk_deliver 1: WRITE-THROUGH stores (global_store_dwordx4 sc0 sc1: 16 bytes a lane, a wave writes whole lines; 8-byte
+	//    ones crawl at 27 MB/s over the link) and s_waitcnt vmcnt(0): delivered when acknowledged, the last workgroup raises
+	//    the flag itself. 168 / 124 / 55: every workgroup sits out a round trip to the host on the entropy stream;
+	//  * pk_deliver 0: plain stores, nobody waits, and the FLAG comes from the next kernel of the stream (k_flag): a kernel's
+	//    end is a release for everything it stored. 19x / 140 / 5x. What sessions whose frames run back to back always did.
+	if (p.pk_deliver == 1)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	uint32_t *cnt = p.stream_size + p.n_streams + 2;
 	if (t == 0 && __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == all_chunks - 1) {
@@ -1670,7 +1682,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 	for (int i = 0; i < p.n_streams + 3; i++) // the size words are left zeroed for the lane's next frame (the ticket word: k_scan)
 		__hip_atomic_store(&p.stream_size[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the sizes are on the host before the flag is)
-	if (p.done_flag)
+	if (p.done_flag && p.pk_deliver == 1)
 		__hip_atomic_store(p.done_flag, p.done_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	__syncthreads(); // (the LDS images and the job words are the next chunk's now)
@@ -1718,6 +1730,8 @@ int Launch::entropy_out(const Params &p, void *stream, uint8_t *host_out, uint32
 	const long want = (long)n_units * (p.pk_launch_chunks > 0 ? p.pk_launch_chunks : 1);
 	const unsigned grid = (unsigned)(want < 1 ? 1 : want > 1024 ? 1024 : want);
 	hipLaunchKernelGGL(k_pack_out, dim3(grid), dim3(PK_THREADS), 0, (hipStream_t)stream, p, host_out, host_sizes);
+	if (p.done_flag && p.pk_deliver == 0) // the kernel's end delivers its bytes: the flag is the next kernel's to raise
+		return flag(stream, p.done_flag, p.done_tag);
 	return (int)hipGetLastError();
 }
 

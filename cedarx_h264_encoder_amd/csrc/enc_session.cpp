@@ -321,11 +321,11 @@ struct cedar_enc {
 	uint32_t *d_slot[ENT_LANES] = {}, *d_mb_bits[ENT_LANES] = {};
 	uint8_t *d_skip[ENT_LANES] = {};
 	uint32_t *d_bit_off[ENT_LANES] = {}, *d_run[ENT_LANES] = {}, *d_unit_bits[ENT_LANES] = {};
+	bool last_src_direct = false; // ... and the last frame was
 	bool src_direct_ok = false;  // the width is a multiple of 16: frames may be read where the caller put them (CEDAR_SRC_DIRECT=0: always through k_input)
 	// k_pack_out's workgroups per unit: twice what the session's pictures of the kind (IDR, P) have needed so far -- a guess by
 	// size before the first one is back; whatever a picture needs beyond that its last workgroup does alone (same bytes)
 	int pk_seen[2] = { 0, 0 };
-	bool host_coherent = true;   // the pinned output buffers are fine-grained host memory (see CONFIG)
 	bool ent_fused = true;       // k_pack_out behind k_scan (CEDAR_ENTROPY_FUSED=0: k_zero .. k_esc_write + k_copy_out through the RBSP buffer)
 	uint64_t *d_ent_rec[ENT_LANES] = {}, *d_pk_agg[ENT_LANES] = {}, *d_pk_unit[ENT_LANES] = {};
 	uint32_t *d_pk_first[ENT_LANES] = {};
@@ -1119,13 +1119,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S_user, hipHostMallocDefault));
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S_user, hipHostMallocDefault));
 	for (int i = 0; i < e->depth; i++) {
-		// The bytestream and size buffers are COHERENT (fine-grained) host memory: the GPU does not cache it, so what k_pack_out
-		// stores there is delivered when the stores have been acknowledged. (Plain hipHostMallocMapped memory is cached in the
-		// L2 of whichever XCD wrote it until a release fence writes that L2 back -- beside a batch's k_inter that is megabytes
-		// of other kernels' dirty lines per workgroup: 32 x 1080p 144 M MB/s with such a fence in every workgroup of
-		// k_pack_out, 182 M without. CEDAR_HOST_COHERENT=0 keeps the old kind, and the fences.)
-		e->host_coherent = !(getenv("CEDAR_HOST_COHERENT") && atoi(getenv("CEDAR_HOST_COHERENT")) == 0);
-		const unsigned out_flags = hipHostMallocMapped | (e->host_coherent ? hipHostMallocCoherent : 0u);
+		const unsigned out_flags = hipHostMallocMapped;
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_out[i], e->out_cap + 16, out_flags));
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->dv_out[i], e->h_out[i], 0));
 		HIP_TRY(e, hipHostMalloc((void **)&e->h_sizes[i], (size_t)MAX_COHORTS * (S + 2) * sizeof(uint32_t), out_flags));
@@ -2095,6 +2089,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		for (int s = 0; s < 2 * S && direct; s++)
 			direct = ((uintptr_t)f.in_used[s] & 15u) == 0;
 		P.src_direct = direct ? 1 : 0;
+		e->last_src_direct = direct;
 		P.src_last_y = direct ? P.height - 1 : P.ch - 1;
 		P.src_last_c = direct ? P.height / 2 - 1 : P.ch / 2 - 1;
 	}
@@ -2133,7 +2128,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.run_before = e->d_run[lane];
 	P.ent_rec = e->d_ent_rec[lane];
 	{
-		P.pk_fence = e->host_coherent ? 0 : 1;
+		P.pk_deliver = getenv("CEDAR_PK_DELIVER") ? atoi(getenv("CEDAR_PK_DELIVER")) : 0;
 		const char *g = getenv("CEDAR_PK_GRID"); // (development: workgroups per unit, fixed)
 		const int seen = e->pk_seen[idr ? 1 : 0], unit_mbs = P.unit_mb_cap;
 		P.pk_launch_chunks = g ? atoi(g) : seen ? 2 * seen + 2 : idr ? unit_mbs / 12 + 8 : unit_mbs / 96 + 4; // (80 / 10 bytes a macroblock)
@@ -2961,6 +2956,8 @@ extern "C" int cedar_enc_get_stats(cedar_enc *e, struct cedar_enc_stats *out)
 	out->deblock_planes_split = e->split_planes ? 1 : 0;
 	out->deblock_rows = e->db_rows ? 1 : 0;
 	out->intra_rows = e->ir_rows ? 1 : 0;
+	out->src_direct = e->last_src_direct ? 1 : 0;
+	out->entropy_fused = e->ent_fused ? 1 : 0;
 	out->frames_pipelined = e->row_pipe ? 1 : 0;
 	out->idr_lookahead = e->lookahead ? 1 : 0;
 	out->depth = e->depth;

@@ -52,7 +52,8 @@ class _Stats(ctypes.Structure):
                 ("wf_split", ctypes.c_int), ("deblock_planes_split", ctypes.c_int),
                 ("frames_pipelined", ctypes.c_int), ("idr_lookahead", ctypes.c_int), ("depth", ctypes.c_int),
                 ("deblock_streams", ctypes.c_int), ("oversize_frames", ctypes.c_uint64), ("frame_qp", ctypes.c_int),
-                ("requantised_frames", ctypes.c_uint64), ("scene_cuts", ctypes.c_uint64), ("deblock_rows", ctypes.c_int), ("intra_rows", ctypes.c_int)]
+                ("requantised_frames", ctypes.c_uint64), ("scene_cuts", ctypes.c_uint64), ("deblock_rows", ctypes.c_int), ("intra_rows", ctypes.c_int), ("src_direct", ctypes.c_int),
+                ("entropy_fused", ctypes.c_int)]
 
 
 _lib = None
@@ -301,7 +302,7 @@ class CedarEncoder:
         s = _Stats()
         self._L.cedar_enc_get_stats(self._h, ctypes.byref(s))
         return {"frames": s.frames, "encode_wall_ms": s.encode_wall_ms, "wf_split": s.wf_split,
-                "deblock_planes_split": bool(s.deblock_planes_split), "deblock_rows": bool(s.deblock_rows), "intra_rows": bool(s.intra_rows),
+                "deblock_planes_split": bool(s.deblock_planes_split), "deblock_rows": bool(s.deblock_rows), "intra_rows": bool(s.intra_rows), "src_direct": bool(s.src_direct), "entropy_fused": bool(s.entropy_fused),
                 "frames_pipelined": bool(s.frames_pipelined), "idr_lookahead": bool(s.idr_lookahead),
                 "depth": s.depth, "deblock_streams": s.deblock_streams, "oversize_frames": s.oversize_frames, "frame_qp": s.frame_qp, "requantised_frames": s.requantised_frames, "scene_cuts": s.scene_cuts,
                 "ms": {n: s.ms[i] for i, n in enumerate(STAGES)},

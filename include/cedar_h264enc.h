@@ -279,6 +279,8 @@ struct cedar_enc_stats {
 	uint64_t scene_cuts;                     /* P pictures coded again as IDR pictures (scene_cut)  */
 	int      deblock_rows;                   /* 1: deblocking with a wave per macroblock row, a workgroup per band of 4 rows */
 	int      intra_rows;                     /* 1: intra reconstruction as a wavefront of 4x4 blocks, a wave per macroblock row */
+	int      src_direct;                     /* 1: the last frame was read where the caller put it (no padded copy, no k_input) */
+	int      entropy_fused;                  /* 1: k_pack_out behind k_scan (3 launches), 0: the round-3 chain of 8 */
 };
 /* event timing: 0 off (default), 1 every stage, else a mask with bit (1 + stage) per stage to time;
  * bits 8..15 = n: time every n-th frame only (0/1: every frame) */
