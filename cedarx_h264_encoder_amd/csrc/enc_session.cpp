@@ -322,6 +322,7 @@ struct cedar_enc {
 	uint8_t *d_skip[ENT_LANES] = {};
 	uint32_t *d_bit_off[ENT_LANES] = {}, *d_run[ENT_LANES] = {}, *d_unit_bits[ENT_LANES] = {};
 	bool last_src_direct = false; // ... and the last frame was
+	bool db_first = false;        // frames back to back: the deblock kernel is enqueued before the entropy chain (CEDAR_DB_FIRST)
 	bool src_direct_ok = false;  // the width is a multiple of 16: frames may be read where the caller put them (CEDAR_SRC_DIRECT=0: always through k_input)
 	// k_pack_out's workgroups per unit: twice what the session's pictures of the kind (IDR, P) have needed so far -- a guess by
 	// size before the first one is back; whatever a picture needs beyond that its last workgroup does alone (same bytes)
@@ -1231,6 +1232,7 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	P.esc_chunks_cap = P.rbsp_cap / ESC_CHUNK;
 	P.out_cap = (int32_t)e->out_cap;
 	e->ent_fused = !(getenv("CEDAR_ENTROPY_FUSED") && atoi(getenv("CEDAR_ENTROPY_FUSED")) == 0);
+	e->db_first = getenv("CEDAR_DB_FIRST") && atoi(getenv("CEDAR_DB_FIRST")) != 0;
 	e->src_direct_ok = (P.width & 15) == 0 && !(getenv("CEDAR_SRC_DIRECT") && atoi(getenv("CEDAR_SRC_DIRECT")) == 0);
 	P.pk_chunks_cap = P.rbsp_cap / PK_CHUNK + 1;
 	for (int l = 0; l < e->ent_lanes; l++) {
@@ -2323,6 +2325,13 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		HIP_TRY(e, hipEventRecord(e->ev_analysis[ei], s_ana));
 		t_main = now_ms();
 
+		// (frames back to back: the deblocking is enqueued BEFORE the entropy chain -- see below)
+		const bool db_first = (!pipe || db_late) && e->db_first;
+		if (db_first) {
+			const int rc_db = launch_deblock();
+			if (rc_db)
+				return rc_db;
+		}
 		// ---- entropy coding on its own stream, concurrent with deblocking ----
 		HIP_TRY(e, hipStreamWaitEvent(s_entc, e->ev_analysis[ei], 0));
 		if (c == 0)
@@ -2354,7 +2363,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 		}
 		t_ent = now_ms();
 
-		if (!pipe || db_late) {
+		if ((!pipe || db_late) && !db_first) {
 			const int rc_db = launch_deblock();
 			if (rc_db)
 				return rc_db;
