@@ -31,6 +31,10 @@ constexpr int COEF_DC16 = 256;
 constexpr int COEF_CDC = 272;
 constexpr int COEF_CAC = 280;
 constexpr int COEF_PER_MB = 408;  // 816 bytes = 51 x 16 B
+// Round 4: a P macroblock all of whose levels fit a byte (any picture that is not noise at a very low QP) stores them as
+// int8 at the same INDICES -- the first 408 bytes of its 816, 26 chunks of 16 -- and says so in MbInfo::chroma_mode (which
+// means nothing for an inter macroblock): half the bytes k_inter writes and the CAVLC kernels read.
+constexpr int MB_LEVELS_INT8 = 0x40;
 
 constexpr int NNZ_PER_MB = 24;    // 16 luma (raster bx+4*by), 4 Cb, 4 Cr
 constexpr int MB_BITS_LIMIT = 3200; // H.264 A.3.1: bits of one macroblock_layer()

@@ -79,6 +79,16 @@ DEVI void load_block(const int16_t *src, int lv[16])
 	}
 }
 
+// ... of a macroblock whose levels are stored as bytes (MB_LEVELS_INT8): level index i at byte i
+DEVI void load_block8(const int8_t *src, int lv[16])
+{
+	const u32x4 a = *(const u32x4 *)src;
+	const uint32_t w[4] = { a.x, a.y, a.z, a.w };
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		lv[i] = (int)(int8_t)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+
 // residual_block_cavlc (7.3.5.3.2 / 9.2): lv[first .. first+maxc) in scan order
 DEVI void cavlc_block(BitW &b, const int lv[16], int first, int maxc, int nC)
 {
@@ -193,6 +203,8 @@ DEVI int calc_nc(const Nb &nb, int plane, int bx, int by)
 DEVI void write_residual(BitW &b, const MbInfo &mi, const int16_t *cf, const Nb &nb)
 {
 	int lv[16];
+	const bool c8 = mi.type == MB_P16x16 && (mi.chroma_mode & MB_LEVELS_INT8); // (k_inter: every level of the macroblock fits a byte)
+	const int8_t *cf8 = (const int8_t *)cf;
 	if (mi.type == MB_I16x16) {
 		load_block(cf + COEF_DC16, lv);
 		cavlc_block(b, lv, 0, 16, calc_nc(nb, 0, 0, 0));
@@ -203,7 +215,10 @@ DEVI void write_residual(BitW &b, const MbInfo &mi, const int16_t *cf, const Nb 
 		for (int i4 = 0; i4 < 4; i4++) {
 			const int idx = 4 * i8 + i4;
 			const int nC = calc_nc(nb, 0, blk_x(idx), blk_y(idx));
-			load_block(cf + COEF_LUMA + idx * 16, lv);
+			if (c8)
+				load_block8(cf8 + COEF_LUMA + idx * 16, lv);
+			else
+				load_block(cf + COEF_LUMA + idx * 16, lv);
 			if (mi.type == MB_I16x16)
 				cavlc_block(b, lv, 1, 15, nC);
 			else
@@ -211,8 +226,18 @@ DEVI void write_residual(BitW &b, const MbInfo &mi, const int16_t *cf, const Nb 
 		}
 	}
 	if (mi.cbp & 0x30) {
-		const u32x4 d = *(const u32x4 *)(cf + COEF_CDC);
-		const uint32_t w[4] = { d.x, d.y, d.z, d.w };
+		uint32_t w[4];
+		if (c8) { // 8 bytes at index COEF_CDC
+			const uint64_t d = *(const uint64_t *)(cf8 + COEF_CDC);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t lo = (uint32_t)(d >> (16 * k)) & 0xffu, hi = (uint32_t)(d >> (16 * k + 8)) & 0xffu;
+				w[k] = ((uint32_t)(int)(int8_t)lo & 0xffffu) | ((uint32_t)(int)(int8_t)hi << 16);
+			}
+		} else {
+			const u32x4 d = *(const u32x4 *)(cf + COEF_CDC);
+			w[0] = d.x; w[1] = d.y; w[2] = d.z; w[3] = d.w;
+		}
 		for (int c = 0; c < 2; c++) {
 #pragma unroll
 			for (int i = 0; i < 16; i++)
@@ -226,7 +251,17 @@ DEVI void write_residual(BitW &b, const MbInfo &mi, const int16_t *cf, const Nb 
 		if (mi.cbp & 0x20)
 			for (int c = 0; c < 2; c++)
 				for (int blk = 0; blk < 4; blk++) {
-					load_block(cf + COEF_CAC + (4 * c + blk) * 16, lv);
+					if (c8) { // (16-byte loads want 16-byte addresses: index 280 + 16 k is 8 modulo 16)
+						const int8_t *q = cf8 + COEF_CAC + (4 * c + blk) * 16;
+						const uint64_t d0 = *(const uint64_t *)q, d1 = *(const uint64_t *)(q + 8);
+#pragma unroll
+						for (int i = 0; i < 8; i++) {
+							lv[i] = (int)(int8_t)((d0 >> (8 * i)) & 0xffu);
+							lv[8 + i] = (int)(int8_t)((d1 >> (8 * i)) & 0xffu);
+						}
+					} else {
+						load_block(cf + COEF_CAC + (4 * c + blk) * 16, lv);
+					}
 					cavlc_block(b, lv, 1, 15, calc_nc(nb, 1 + c, blk & 1, blk >> 1));
 				}
 	}
@@ -538,16 +573,31 @@ __global__ __launch_bounds__(64) void k_cavlc2(Params p)
 	// ---- stage everything the half needs (coalesced) ----
 	{
 		// levels: only the block groups the macroblock's coded block pattern names (k_inter stores no others;
-		// 16-byte chunk hl = half a luma block, hl + 32 = Intra16x16 DCs, chroma DCs, chroma AC halves)
+		// 16-byte chunk hl = half a luma block, hl + 32 = Intra16x16 DCs, chroma DCs, chroma AC halves) -- or, where k_inter
+		// stored them as bytes (MB_LEVELS_INT8), chunk hl = the 16 levels from index 16 hl on, widened on the way into LDS
 		const MbInfo m0 = p.mbi[mbaddr];
 		const bool i16 = m0.type == MB_I16x16;
 		const u32x4 *src = (const u32x4 *)(p.coef + mbaddr * COEF_PER_MB);
 		u32x4 *dst = (u32x4 *)s_cf[half];
-		if ((m0.cbp >> (hl >> 3)) & 1)
-			dst[hl] = src[hl];
-		const int c2 = hl + 32;
-		if (c2 < COEF_PER_MB / 8 && (c2 < 34 ? i16 : c2 == 34 ? (m0.cbp & 0x30) != 0 : (m0.cbp & 0x20) != 0))
-			dst[c2] = src[c2];
+		if (m0.type == MB_P16x16 && (m0.chroma_mode & MB_LEVELS_INT8)) {
+			const bool need = hl < 16 ? ((m0.cbp >> (hl >> 2)) & 1) != 0 : hl == 17 ? (m0.cbp & 0x30) != 0 : hl >= 18 && hl < 26 && (m0.cbp & 0x20) != 0;
+			if (need) {
+				const u32x4 v = src[hl];
+				auto wide = [](uint32_t w, int k) { // bytes 2k, 2k + 1 of w as two int16
+					const uint32_t lo = (w >> (16 * k)) & 0xffu, hi = (w >> (16 * k + 8)) & 0xffu;
+					return ((uint32_t)(int)(int8_t)lo & 0xffffu) | ((uint32_t)(int)(int8_t)hi << 16);
+				};
+				dst[2 * hl] = u32x4{ wide(v.x, 0), wide(v.x, 1), wide(v.y, 0), wide(v.y, 1) };
+				if (hl < 25) // (levels 400 .. 407 are the last)
+					dst[2 * hl + 1] = u32x4{ wide(v.z, 0), wide(v.z, 1), wide(v.w, 0), wide(v.w, 1) };
+			}
+		} else {
+			if ((m0.cbp >> (hl >> 3)) & 1)
+				dst[hl] = src[hl];
+			const int c2 = hl + 32;
+			if (c2 < COEF_PER_MB * 2 / 16 && (c2 < 34 ? i16 : c2 == 34 ? (m0.cbp & 0x30) != 0 : (m0.cbp & 0x20) != 0))
+				dst[c2] = src[c2];
+		}
 		if (hl < 24) {
 			s_nnz[half][0][hl] = p.nnz[mbaddr * NNZ_PER_MB + hl];
 			s_nnz[half][1][hl] = has_left ? p.nnz[(mbaddr - 1) * NNZ_PER_MB + hl] : 0;

@@ -690,6 +690,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	// leave as three 8-byte stores at the end)
 	uint32_t nz_luma = 0; // bit = coding-order block index
 	int n_levels = 0;     // levels of the macroblock that are not zero (wave-uniform)
+	uint64_t big_levels = 0; // lanes that have seen a level that does not fit a byte (wave-uniform)
 	const uint8_t *predp = s_ref + (16 + bdy) * REF_STRIDE + 16 + bdx;
 	// fractional vector: the prediction is the rounded mean of two plane samples (kSubTab)
 	const bool frac = SUBPEL && ((qx | qy) & 3) != 0;
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		const int rr = idct_lanes24(__mul24(level, dv_y) << qs.qshift, ci, cj);
 		s_recy[y * 16 + x] = (uint8_t)clip255(pv + rr);
 		const uint64_t bal = __ballot(level != 0);
+		big_levels |= __ballot(level > 127 || level < -127);
 		n_levels += __popcll(bal); // (scalar: a count for the I_PCM gate below)
 		s_nnz[bx + 4 * by] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 #pragma unroll
@@ -805,6 +807,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		s_coef[COEF_CAC + (4 * c + gq) * 16 + zz] = (int16_t)level; // (entry 0 of a block is unused: lane 0 writes its 0 there)
 		cdq[c] = __mul24(level, dv_c) << qs.qshift_c;
 		const uint64_t bal = __ballot(level != 0);
+		big_levels |= __ballot(level > 127 || level < -127);
 		n_levels += __popcll(bal);
 		s_nnz[16 + 4 * c + gq] = (uint8_t)__popc((uint32_t)(bal >> (16 * gq)) & 0xffffu);
 		nz_cac |= bal ? 1u : 0u;
@@ -823,6 +826,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	if (lane < 8)
 		s_coef[COEF_CDC + lane] = (int16_t)lqv;
 	const uint64_t dcmask = __ballot(lqv != 0) & 0xffull;
+	big_levels |= __ballot(lqv > 127 || lqv < -127) & 0xffull;
 	n_levels += __popcll(dcmask);
 	int lqs[8];
 #pragma unroll
@@ -885,11 +889,36 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		}
 	}
 
-	// ---- write back: levels (51 x 16 B), reconstruction rows, records ----
-	{
-		// levels: only the block groups the coded block pattern names (16-byte chunk = half a luma block, the
-		// chroma DCs, half a chroma AC block; the Intra16x16 DCs only for a refresh macroblock) -- nobody reads the
-		// others, and at the rates of real pictures most are empty: 6.7 MB per 1080p picture were written, then read
+	// ---- write back: levels (51 x 16 B, or 26 x 16 B as bytes), reconstruction rows, records ----
+	// levels: only the block groups the coded block pattern names (nobody reads the others, and at the rates of real
+	// pictures most are empty: 6.7 MB per 1080p picture were written, then read) -- and as BYTES when every level of the
+	// macroblock fits one (MB_LEVELS_INT8: the same indices, half the bytes: -1.6 MB written, -3.4 MB read per 1080p P picture
+	// at QP 24). A refresh macroblock keeps int16 (its Intra16x16 DC levels are the large ones).
+	const bool levels8 = !(REFRESH && refresh) && !is_pcm && cbp != 0 && big_levels == 0;
+	if (levels8) {
+		u32x4 a = u32x4{ 0, 0, 0, 0 }, b = a;
+		if (lane < 26) { // level indices 16 lane .. 16 lane + 15 (the last chunk reads 8 int16 of slack behind the 408: the arena is larger)
+			a = *(const u32x4 *)((const uint8_t *)s_coef + lane * 32);
+			b = *(const u32x4 *)((const uint8_t *)s_coef + lane * 32 + 16);
+		}
+		WAVE_LDS_SYNC();
+		if (lane < 26) {
+			auto pk = [](uint32_t w0, uint32_t w1) { // four int16 -> four int8
+				return (w0 & 0xffu) | ((w0 >> 8) & 0xff00u) | ((w1 & 0xffu) << 16) | ((w1 << 8) & 0xff000000u);
+			};
+			*(u32x4 *)((uint8_t *)s_coef + lane * 16) = u32x4{ pk(a.x, a.y), pk(a.z, a.w), pk(b.x, b.y), pk(b.z, b.w) };
+		}
+		WAVE_LDS_SYNC();
+		bool need;
+		if (lane < 16)
+			need = (cbp >> (lane >> 2)) & 1;   // luma block `lane`
+		else if (lane == 17)
+			need = (cbp & 0x30) != 0;           // chroma DC (and the first 8 levels of the first chroma AC block)
+		else
+			need = lane >= 18 && lane < 26 && (cbp & 0x20) != 0;
+		if (need)
+			*(u32x4 *)((uint8_t *)(p.coef + mbaddr * COEF_PER_MB) + lane * 16) = *(const u32x4 *)((const uint8_t *)s_coef + lane * 16);
+	} else {
 		bool need;
 		if (lane < 32)
 			need = (cbp >> (lane >> 3)) & 1;
@@ -914,7 +943,7 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		MbInfo m;
 		m.type = (REFRESH && refresh) ? MB_I16x16 : is_pcm ? MB_IPCM : MB_P16x16;
 		m.i16_mode = (REFRESH && refresh) ? 2 : 0; // DC
-		m.chroma_mode = 0;                         // DC
+		m.chroma_mode = levels8 ? (int8_t)MB_LEVELS_INT8 : 0; // DC; an inter macroblock: how its levels are stored
 		m.cbp = (int8_t)cbp;
 		m.mvx = (int16_t)qx; // quarter samples
 		m.mvy = (int16_t)qy;

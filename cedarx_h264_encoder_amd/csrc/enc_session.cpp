@@ -3012,6 +3012,12 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 		return fail(e, -ENOSPC, "debug buffer needs %zu bytes", n);
 	HIP_TRY(e, hipSetDevice(e->device));
 	HIP_TRY(e, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+	if (what == CEDAR_ENC_DBG_MBINFO) { // (an inter macroblock's chroma_mode says how its levels are stored: not part of the record)
+		MbInfo *m = (MbInfo *)dst;
+		for (int i = 0; i < P.n_mb; i++)
+			if (m[i].type >= MB_P16x16)
+				m[i].chroma_mode = 0;
+	}
 	if (what == CEDAR_ENC_DBG_COEF) {
 		// k_inter only stores the levels of the block groups its coded block pattern names (the entropy kernels
 		// read no others): what the buffer holds elsewhere is an earlier picture's. Shown as what it means: zero.
@@ -3025,6 +3031,11 @@ extern "C" int cedar_enc_debug_read(cedar_enc *e, int what, int stream, void *ds
 			}
 			if (mi[i].type < MB_P16x16)
 				continue;
+			if (mi[i].type == MB_P16x16 && (mi[i].chroma_mode & MB_LEVELS_INT8)) { // stored as bytes at the same indices: widen
+				const int8_t *b8 = (const int8_t *)cf;
+				for (int k = COEF_PER_MB - 1; k >= 0; k--)
+					cf[k] = b8[k];
+			}
 			for (int g8 = 0; g8 < 4; g8++)
 				if (!(mi[i].cbp & (1 << g8)))
 					memset(cf + COEF_LUMA + 64 * g8, 0, 128);
