@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_out(Params p, uint8_t *host
 	//    ones crawl at 27 MB/s over the link) and s_waitcnt vmcnt(0): delivered when acknowledged, the last workgroup raises
 	//    the flag itself. 168 / 124 / 55: every workgroup sits out a round trip to the host on the entropy stream;
 	//  * pk_deliver 0: plain stores, nobody waits, and the FLAG comes from the next kernel of the stream (k_flag): a kernel's
-	//    end is a release for everything it stored. 19x / 140 / 5x. What sessions whose frames run back to back always did.
+	//    end is a release for everything it stored. 195 / 139 / 57. What sessions whose frames run back to back always did.
 	if (p.pk_deliver == 1)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
