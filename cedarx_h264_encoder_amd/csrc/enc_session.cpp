@@ -985,25 +985,10 @@ extern "C" int cedar_enc_plan(const struct cedar_enc_plan_query *q, struct cedar
 	return 0;
 }
 
-static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
+// CEDAR_IOCTL_CONFIG's parameter checks (cedar.c:749-789) and those of the extension block: pure -- no device, no state but
+// the error text. ext has its defaults filled in; S_user / G = the caller's streams and GOP lanes.
+static int validate_config(cedar_enc *e, const struct cedar_enc_config *cfg, const struct cedar_enc_config_ext &ext, int S_user, int G)
 {
-	struct cedar_enc_config_ext ext{};
-	if (ext_in) {
-		if (ext_in->size != (int)sizeof(struct cedar_enc_config_ext))
-			return fail(e, -EINVAL, "config_ext.size mismatch");
-		ext = *ext_in;
-	}
-	if (ext.n_streams == 0) ext.n_streams = 1;
-	if (ext.gop_parallel < 0 || ext.gop_parallel > MAX_UNITS || ext.n_streams < 1 || ext.n_streams > MAX_UNITS)
-		return fail(e, -EINVAL, "bad stream/slice layout");
-	// the caller's streams x GOP lanes = the lock-step "streams" everything below batches
-	const int S_user = ext.n_streams, G = ext.gop_parallel > 1 ? ext.gop_parallel : 1;
-	ext.n_streams = S_user * G;
-	if (ext.slice_count == 0) ext.slice_count = 1;
-	if (ext.slice_num == 0) { ext.slice_first = 0; ext.slice_num = ext.slice_count; }
-	ext.search_range = ext.search_range == 0 ? 16 : ext.search_range < 0 ? 0 : ext.search_range;
-	e->chroma_qp_offset = 4 + ext.chroma_qp_offset_minus4; // cedar.c:971-972
-	// cedar.c:749-789
 	if ((cfg->src_width & 1) || (cfg->src_height & 1) || cfg->src_width <= 0 || cfg->src_height <= 0)
 		return fail(e, -EINVAL, "src width %d, height %d not aligned", cfg->src_width, cfg->src_height);
 	if ((cfg->dst_width & 15) || (cfg->dst_height & 15))
@@ -1067,56 +1052,14 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	if (ext.first_frame_index < 0 || ext.first_frame_index % cfg->keyframe_interval)
 		return fail(e, -EINVAL, "first_frame_index %d is not the start of a GOP (keyframe interval %d)", ext.first_frame_index,
 			    cfg->keyframe_interval);
-	int ndev = 0;
-	if (hipGetDeviceCount(&ndev) != hipSuccess || ext.device < 0 || ext.device >= ndev)
-		return fail(e, -ENODEV, "HIP device %d not available", ext.device);
-	HIP_TRY(e, hipSetDevice(ext.device));
-	e->device = ext.device;
-	e->device_set = true;
-	e->cfg = *cfg;
-	e->ext = ext;
-	e->mb_qp = ext.roi_count > 0;
-	for (int k = 0; k < 5; k++)
-		e->mb_qp = e->mb_qp || ext.mad_dqp[k] != 0;
-	const bool row_rule = e->mb_qp;
-	// rate control over several streams: every stream its own QP per picture, i.e. the kernels that look the
-	// QP up per macroblock (but no QP differs inside a picture: no row rule)
-	e->rc_multi = ext.bitrate > 0 && ext.n_streams > 1 && G == 1;
-	e->rc_lanes = ext.bitrate > 0 && G > 1; // one QP per group of G GOPs (rc_pick_qp_group)
-	e->mb_qp = e->mb_qp || e->rc_multi;
-	e->pcm_session = ext.pcm >= 0 && !e->mb_qp && ext.intra_refresh == 0;
-	if (e->rc_multi) {
-		e->rc_bits_s.assign((size_t)ext.n_streams * 64, 0);
-		e->rc_qp_s.assign((size_t)ext.n_streams * 64, 0);
-	}
-	fill_static_params(e);
-	Params &P = e->P;
-	const int S = ext.n_streams;
-	const int n_units = S * ext.slice_num;
+	(void)mb_w;
+	return 0;
+}
 
-	// The schedule policy is a pure function of geometry, CU count and the CEDAR_* switches (enc_plan.h; held
-	// by tests/test_plan.py without a GPU): frames in flight, wavefront splits, deblock form, what to probe for.
-	static_assert(CEDAR_PLAN_MAX_DEPTH == CEDAR_ENC_PIPELINE_DEPTH, "enc_plan.h");
-	int cus = 0;
-	HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-	PlanIn pin = plan_input(P.mb_w, P.mb_h, P.slice_count, ext.slice_first, ext.slice_num, S, cus);
-	pin.mb_qp = e->mb_qp ? 1 : 0;
-	const Plan plan = plan_static(pin);
-	if (plan.error)
-		return fail(e, -EINVAL, "picture too tall for the deblock wavefront");
-	e->depth = plan.depth;
-	e->nrec = e->depth + 1;
-	// ---- buffer manager (cedar.c:605-704) ----
-	const int luma_sz = align_up(cfg->src_width * cfg->src_height, 4096);      // cedar.c:612
-	const int chroma_sz = align_up(cfg->src_width * cfg->src_height / 2, 4096); // cedar.c:621
-	// reference: fixed 1 MiB (cedar.c:663), which a 1080p IDR can overflow; size by macroblocks
-	int bs_sz = P.n_mb * 1024 + 4096;
-	if (bs_sz < (1 << 20)) bs_sz = 1 << 20;
-	e->out_cap = (size_t)bs_sz * S;
-	e->stream_out_cap = (size_t)bs_sz;
-	if (e->out_cap > 0x7fffffffULL)
-		return fail(e, -EINVAL, "too many streams for one session");
-	int rc = 0;
+// The pinned host side of the buffer manager (cedar.c:605-704): the caller's input buffers, per ring slot the bytestream and
+// size buffers k_pack_out writes, and the few words per frame that kernels read from or write to host memory.
+static int alloc_host_buffers(cedar_enc *e, int luma_sz, int chroma_sz, int S_user, int S, int n_units)
+{
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_luma, (size_t)luma_sz * S_user, hipHostMallocDefault));
 	HIP_TRY(e, hipHostMalloc((void **)&e->h_chroma, (size_t)chroma_sz * S_user, hipHostMallocDefault));
 	for (int i = 0; i < e->depth; i++) {
@@ -1142,6 +1085,19 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		e->fl[i].h_done[0] = e->fl[i].h_done[1] = 0;
 		HIP_TRY(e, hipHostGetDevicePointer((void **)&e->fl[i].d_done, (void *)e->fl[i].h_done, 0));
 	}
+	return 0;
+}
+
+// The device side of the buffer manager: per ring slot the frame's planes, records, levels and hand-off words; per entropy
+// lane the bit slots and what k_scan / k_pack_out meet in; the tables. Sizes follow the plan (frames in flight, which wavefront
+// kernels, how many bands); everything is cleared (dalloc), tagged words on purpose (they never hold another frame's tag).
+static int alloc_device_buffers(cedar_enc *e, const Plan &plan, int luma_sz, int chroma_sz, int G, bool row_rule)
+{
+	Params &P = e->P;
+	const struct cedar_enc_config_ext &ext = e->ext;
+	const int S = ext.n_streams, n_units = S * ext.slice_num, mb_w = P.mb_w, mb_h = P.mb_h;
+	int rc = 0;
+	(void)mb_h;
 	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
 	P.plane_y_stride = (int64_t)plane_y;
 	P.plane_uv_stride = (int64_t)plane_uv;
@@ -1298,6 +1254,17 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 	for (bool &v : e->in_tab_valid)
 		v = false;
 
+	return 0;
+}
+
+// The session's streams and what the probes make of the plan: which deblock streams really run beside the analysis and the
+// entropy stream (frame pipelining polls across them), which hardware queues share a pipe (the roles are dealt by that), the
+// IDR look-ahead streams, cohorts.
+static int setup_streams(cedar_enc *e, const struct cedar_enc_config *cfg, const PlanIn &pin, const Plan &plan)
+{
+	Params &P = e->P;
+	(void)P;
+	(void)cfg;
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
 	e->s_ana[0] = e->s_main;
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
@@ -1477,6 +1444,20 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 			fprintf(stderr, "config: row_pipe %d, deblock streams %d, analysis streams %d, stripes %d, look-ahead %d, depth %d, cohorts %d\n",
 				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth, e->cohorts);
 	}
+	return 0;
+}
+
+// The diagonal stripes of a pipelined P picture's analysis and how many of them are held back (DeferredTail).
+static int setup_stripes(cedar_enc *e)
+{
+	Params &P = e->P;
+	const struct cedar_enc_config_ext &ext = e->ext;
+	const int mb_w = P.mb_w, mb_h = P.mb_h;
+	int rc = 0;
+	(void)ext;
+	(void)mb_w;
+	(void)mb_h;
+	(void)rc;
 	{
 		// diagonal stripes s = x + y of a P picture (the slope of the deblock sweep it follows and is
 		// followed by) and, per stripe, how many of its macroblocks lie in the rows before row r: k_inter
@@ -1550,6 +1531,93 @@ static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct 
 		e->P.dummy_rec = e->d_dummy_rec;
 		e->P.stripe_tab = nullptr;
 	}
+	return 0;
+}
+
+static int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
+{
+	struct cedar_enc_config_ext ext{};
+	if (ext_in) {
+		if (ext_in->size != (int)sizeof(struct cedar_enc_config_ext))
+			return fail(e, -EINVAL, "config_ext.size mismatch");
+		ext = *ext_in;
+	}
+	if (ext.n_streams == 0) ext.n_streams = 1;
+	if (ext.gop_parallel < 0 || ext.gop_parallel > MAX_UNITS || ext.n_streams < 1 || ext.n_streams > MAX_UNITS)
+		return fail(e, -EINVAL, "bad stream/slice layout");
+	// the caller's streams x GOP lanes = the lock-step "streams" everything below batches
+	const int S_user = ext.n_streams, G = ext.gop_parallel > 1 ? ext.gop_parallel : 1;
+	ext.n_streams = S_user * G;
+	if (ext.slice_count == 0) ext.slice_count = 1;
+	if (ext.slice_num == 0) { ext.slice_first = 0; ext.slice_num = ext.slice_count; }
+	ext.search_range = ext.search_range == 0 ? 16 : ext.search_range < 0 ? 0 : ext.search_range;
+	e->chroma_qp_offset = 4 + ext.chroma_qp_offset_minus4; // cedar.c:971-972
+	{
+		const int rc_v = validate_config(e, cfg, ext, S_user, G);
+		if (rc_v)
+			return rc_v;
+	}
+	const int mb_h = cfg->dst_height / 16, mb_w = cfg->dst_width / 16;
+	(void)mb_h;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ext.device < 0 || ext.device >= ndev)
+		return fail(e, -ENODEV, "HIP device %d not available", ext.device);
+	HIP_TRY(e, hipSetDevice(ext.device));
+	e->device = ext.device;
+	e->device_set = true;
+	e->cfg = *cfg;
+	e->ext = ext;
+	e->mb_qp = ext.roi_count > 0;
+	for (int k = 0; k < 5; k++)
+		e->mb_qp = e->mb_qp || ext.mad_dqp[k] != 0;
+	const bool row_rule = e->mb_qp;
+	// rate control over several streams: every stream its own QP per picture, i.e. the kernels that look the
+	// QP up per macroblock (but no QP differs inside a picture: no row rule)
+	e->rc_multi = ext.bitrate > 0 && ext.n_streams > 1 && G == 1;
+	e->rc_lanes = ext.bitrate > 0 && G > 1; // one QP per group of G GOPs (rc_pick_qp_group)
+	e->mb_qp = e->mb_qp || e->rc_multi;
+	e->pcm_session = ext.pcm >= 0 && !e->mb_qp && ext.intra_refresh == 0;
+	if (e->rc_multi) {
+		e->rc_bits_s.assign((size_t)ext.n_streams * 64, 0);
+		e->rc_qp_s.assign((size_t)ext.n_streams * 64, 0);
+	}
+	fill_static_params(e);
+	Params &P = e->P;
+	const int S = ext.n_streams;
+	const int n_units = S * ext.slice_num;
+
+	// The schedule policy is a pure function of geometry, CU count and the CEDAR_* switches (enc_plan.h; held
+	// by tests/test_plan.py without a GPU): frames in flight, wavefront splits, deblock form, what to probe for.
+	static_assert(CEDAR_PLAN_MAX_DEPTH == CEDAR_ENC_PIPELINE_DEPTH, "enc_plan.h");
+	int cus = 0;
+	HIP_TRY(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+	PlanIn pin = plan_input(P.mb_w, P.mb_h, P.slice_count, ext.slice_first, ext.slice_num, S, cus);
+	pin.mb_qp = e->mb_qp ? 1 : 0;
+	const Plan plan = plan_static(pin);
+	if (plan.error)
+		return fail(e, -EINVAL, "picture too tall for the deblock wavefront");
+	e->depth = plan.depth;
+	e->nrec = e->depth + 1;
+	// ---- buffer manager (cedar.c:605-704) ----
+	const int luma_sz = align_up(cfg->src_width * cfg->src_height, 4096);      // cedar.c:612
+	const int chroma_sz = align_up(cfg->src_width * cfg->src_height / 2, 4096); // cedar.c:621
+	// reference: fixed 1 MiB (cedar.c:663), which a 1080p IDR can overflow; size by macroblocks
+	int bs_sz = P.n_mb * 1024 + 4096;
+	if (bs_sz < (1 << 20)) bs_sz = 1 << 20;
+	e->out_cap = (size_t)bs_sz * S;
+	e->stream_out_cap = (size_t)bs_sz;
+	if (e->out_cap > 0x7fffffffULL)
+		return fail(e, -EINVAL, "too many streams for one session");
+	int rc = 0;
+	if ((rc = alloc_host_buffers(e, luma_sz, chroma_sz, S_user, S, n_units)))
+		return rc;
+	if ((rc = alloc_device_buffers(e, plan, luma_sz, chroma_sz, G, row_rule)))
+		return rc;
+
+	if ((rc = setup_streams(e, cfg, pin, plan)))
+		return rc;
+	if ((rc = setup_stripes(e)))
+		return rc;
 	for (int i = 0; i < e->depth; i++) {
 		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
 		for (int c = 0; c < e->cohorts; c++) {
@@ -1915,6 +1983,126 @@ struct SessionLock {
 	}
 };
 
+// The input stage of a submit: H2D of the pinned buffers unless the caller supplied device frames (a replayed frame: its data
+// moves from the slot it was first submitted to), where the kernels find stream s of this frame (kernel arguments up to 8
+// streams, a pointer table beyond), and whether the frame can be read in place (Params::src_direct). in_work: something of
+// this frame was enqueued on s_in.
+static int submit_input(cedar_enc *e, InFlight &f, Params &P, const ReplayIn *replay, int ds, hipStream_t s_in, bool &in_work, bool &any_host)
+{
+	const int S = e->ext.n_streams;
+	any_host = in_work = false;
+	const size_t in_y_slot = (size_t)ds * e->cfg.input_luma_size * S, in_uv_slot = (size_t)ds * e->cfg.input_chroma_size * S;
+	f.in_own.assign((size_t)S, 0);
+	for (int s = 0; s < S; s++) {
+		// a stream without a device frame of its own points at the session's device copy (slot 0 is the mark)
+		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
+		f.in_own[s] = replay ? replay->own[s] : (uint8_t)(e->h_in_ptrs[s] == own);
+		if (!f.in_own[s])
+			continue;
+		uint8_t *dy = e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
+		uint8_t *duv = e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size;
+		if (replay) {
+			// the frame's data sits in the device copy of the slot it was first submitted to: move it to
+			// this slot's, so that "a frame in flight owns the copy of its slot" holds again
+			if (replay->in[s] != dy) {
+				in_work = true;
+				HIP_TRY(e, hipMemcpyAsync(dy, replay->in[s], (size_t)P.width * P.height, hipMemcpyDeviceToDevice, s_in));
+				HIP_TRY(e, hipMemcpyAsync(duv, replay->in[S + s], (size_t)P.width * P.height / 2, hipMemcpyDeviceToDevice, s_in));
+			}
+			continue;
+		}
+		any_host = in_work = true;
+		HIP_TRY(e, hipMemcpyAsync(dy, e->h_luma + (size_t)s * e->cfg.input_luma_size,
+					  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_in));
+		HIP_TRY(e, hipMemcpyAsync(duv, e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
+					  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_in));
+	}
+	auto in_ptr = [&](int s, bool chroma) -> const uint8_t * { // where k_input finds stream s of this frame
+		if (!f.in_own[s])
+			return replay ? replay->in[(chroma ? S : 0) + s] : e->h_in_ptrs[(chroma ? S : 0) + s];
+		return chroma ? e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size
+			      : e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
+	};
+	f.in_used.resize((size_t)2 * S);
+	for (int s = 0; s < S; s++) {
+		f.in_used[s] = in_ptr(s, false);
+		f.in_used[S + s] = in_ptr(s, true);
+	}
+	// (a plain session counts its frames itself; a replayed frame comes with its index, which recover()
+	// has moved up by the frame that was dropped; GOP lanes keep the frame they were given)
+	if (replay)
+		f.lane_gidx = replay->gidx;
+	else if (!e->mux)
+		f.lane_gidx.assign((size_t)S, (long)e->ext.first_frame_index + e->frame_count);
+	else
+		f.lane_gidx = e->lane_gidx;
+	if (replay)
+		e->in_tab_valid[ds] = false; // the table of this slot, if any, describes another frame
+	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
+		P.in_luma = P.in_chroma = nullptr;
+		for (int s = 0; s < S; s++) {
+			P.in_k[s] = in_ptr(s, false);
+			P.in_k[IN_K_STREAMS + s] = in_ptr(s, true);
+		}
+	} else if (!e->in_tab_valid[ds]) {
+		// many streams: a pointer table in device memory per slot (the device copies of host frames
+		// rotate with the slot), uploaded when the caller changed a pointer
+		std::vector<const uint8_t *> &t = e->in_tab[ds];
+		t.resize((size_t)2 * S);
+		for (int s = 0; s < S; s++) {
+			t[s] = in_ptr(s, false);
+			t[S + s] = in_ptr(s, true);
+		}
+		in_work = true;
+		HIP_TRY(e, hipMemcpyAsync((void *)(e->d_in_ptrs + (size_t)ds * 2 * S), t.data(), sizeof(void *) * 2 * S,
+					  hipMemcpyHostToDevice, s_in));
+		e->in_tab_valid[ds] = !replay;
+	}
+	if (S > IN_K_STREAMS) {
+		P.in_luma = (const uint8_t *const *)(e->d_in_ptrs + (size_t)ds * 2 * S);
+		P.in_chroma = P.in_luma + S;
+	}
+	if (any_host)
+		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_in));
+	// No padded copy of the frame (no k_input: -6.3 MB of traffic and a launch per 1080p frame) where the caller's packed
+	// frame can serve as the source planes: a width that is a multiple of 16 (no column to replicate; the rows below the
+	// picture are the last row, which the readers take by clamping) and 16-byte aligned frames (they load 16 bytes a lane).
+	{
+		bool direct = e->src_direct_ok;
+		for (int s = 0; s < 2 * S && direct; s++)
+			direct = ((uintptr_t)f.in_used[s] & 15u) == 0;
+		P.src_direct = direct ? 1 : 0;
+		e->last_src_direct = direct;
+		P.src_last_y = direct ? P.height - 1 : P.ch - 1;
+		P.src_last_c = direct ? P.height / 2 - 1 : P.ch / 2 - 1;
+	}
+	return 0;
+}
+
+static void build_frame_headers(cedar_enc *e, InFlight &f, const Params &P, bool idr)
+{
+	const int S = e->ext.n_streams;
+	// Headers per lane: idr_pic_id and "parameter sets in front of frame 0" follow the GLOBAL frame
+	// index (the reference counts the frames of its one device, cedar.c:1001, :1058-1061; a shard or a
+	// GOP lane starts somewhere in the stream). frame_num restarts with every IDR picture (cedar.c:1001).
+	f.aud = e->ext.aud && e->ext.slice_first == 0 ? (idr ? 1 : 2) : 0; // the first slice's session opens the access unit
+	f.with_ps.assign((size_t)S, 0);
+	for (int s = 0; s < S; s++) {
+		const long gidx = f.lane_gidx[s] < 0 ? 0 : f.lane_gidx[s];
+		const long gop = gidx / e->cfg.keyframe_interval;
+		for (int k = 0; k < e->ext.slice_num; k++) {
+			int r0, r1;
+			slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
+			// (scene cuts put IDR pictures anywhere: two in a row must still differ in idr_pic_id, so it follows their count)
+			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, e->ext.scene_cut > 0 ? (int)(e->idr_count & 1u) : (int)(gop & 1), r0 * P.mb_w,
+									       (e->rc_multi ? (int)f.h_qp_s[s] : P.qp) - e->cfg.qp);
+		}
+		// cedar.c:1058-1061: SPS + PPS in front of the stream's first picture (the IDR picture of GOP 0)
+		f.with_ps[s] = idr && ((e->ext.scene_cut > 0 ? gidx == 0 : gop == 0) || e->ext.repeat_headers) && e->ext.slice_first == 0;
+		f.h_prefix[s] = (f.with_ps[s] ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
+	}
+}
+
 static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 {
 	if (e->fl_count >= e->depth)
@@ -2009,91 +2197,11 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 
 	// ---- input: H2D of the pinned buffers unless the caller supplied device frames ----
 	tm_begin(e, f, CEDAR_ENC_STAGE_INPUT, s_in);
-	bool any_host = false, in_work = false; // (in_work: something of this frame was enqueued on s_in)
-	const size_t in_y_slot = (size_t)ds * e->cfg.input_luma_size * S, in_uv_slot = (size_t)ds * e->cfg.input_chroma_size * S;
-	f.in_own.assign((size_t)S, 0);
-	for (int s = 0; s < S; s++) {
-		// a stream without a device frame of its own points at the session's device copy (slot 0 is the mark)
-		const uint8_t *own = e->d_in_y + (size_t)s * e->cfg.input_luma_size;
-		f.in_own[s] = replay ? replay->own[s] : (uint8_t)(e->h_in_ptrs[s] == own);
-		if (!f.in_own[s])
-			continue;
-		uint8_t *dy = e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
-		uint8_t *duv = e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size;
-		if (replay) {
-			// the frame's data sits in the device copy of the slot it was first submitted to: move it to
-			// this slot's, so that "a frame in flight owns the copy of its slot" holds again
-			if (replay->in[s] != dy) {
-				in_work = true;
-				HIP_TRY(e, hipMemcpyAsync(dy, replay->in[s], (size_t)P.width * P.height, hipMemcpyDeviceToDevice, s_in));
-				HIP_TRY(e, hipMemcpyAsync(duv, replay->in[S + s], (size_t)P.width * P.height / 2, hipMemcpyDeviceToDevice, s_in));
-			}
-			continue;
-		}
-		any_host = in_work = true;
-		HIP_TRY(e, hipMemcpyAsync(dy, e->h_luma + (size_t)s * e->cfg.input_luma_size,
-					  (size_t)P.width * P.height, hipMemcpyHostToDevice, s_in));
-		HIP_TRY(e, hipMemcpyAsync(duv, e->h_chroma + (size_t)s * e->cfg.input_chroma_size,
-					  (size_t)P.width * P.height / 2, hipMemcpyHostToDevice, s_in));
-	}
-	auto in_ptr = [&](int s, bool chroma) -> const uint8_t * { // where k_input finds stream s of this frame
-		if (!f.in_own[s])
-			return replay ? replay->in[(chroma ? S : 0) + s] : e->h_in_ptrs[(chroma ? S : 0) + s];
-		return chroma ? e->d_in_uv + in_uv_slot + (size_t)s * e->cfg.input_chroma_size
-			      : e->d_in_y + in_y_slot + (size_t)s * e->cfg.input_luma_size;
-	};
-	f.in_used.resize((size_t)2 * S);
-	for (int s = 0; s < S; s++) {
-		f.in_used[s] = in_ptr(s, false);
-		f.in_used[S + s] = in_ptr(s, true);
-	}
-	// (a plain session counts its frames itself; a replayed frame comes with its index, which recover()
-	// has moved up by the frame that was dropped; GOP lanes keep the frame they were given)
-	if (replay)
-		f.lane_gidx = replay->gidx;
-	else if (!e->mux)
-		f.lane_gidx.assign((size_t)S, (long)e->ext.first_frame_index + e->frame_count);
-	else
-		f.lane_gidx = e->lane_gidx;
-	if (replay)
-		e->in_tab_valid[ds] = false; // the table of this slot, if any, describes another frame
-	if (S <= IN_K_STREAMS) { // frame pointers ride in the kernel arguments: no table upload
-		P.in_luma = P.in_chroma = nullptr;
-		for (int s = 0; s < S; s++) {
-			P.in_k[s] = in_ptr(s, false);
-			P.in_k[IN_K_STREAMS + s] = in_ptr(s, true);
-		}
-	} else if (!e->in_tab_valid[ds]) {
-		// many streams: a pointer table in device memory per slot (the device copies of host frames
-		// rotate with the slot), uploaded when the caller changed a pointer
-		std::vector<const uint8_t *> &t = e->in_tab[ds];
-		t.resize((size_t)2 * S);
-		for (int s = 0; s < S; s++) {
-			t[s] = in_ptr(s, false);
-			t[S + s] = in_ptr(s, true);
-		}
-		in_work = true;
-		HIP_TRY(e, hipMemcpyAsync((void *)(e->d_in_ptrs + (size_t)ds * 2 * S), t.data(), sizeof(void *) * 2 * S,
-					  hipMemcpyHostToDevice, s_in));
-		e->in_tab_valid[ds] = !replay;
-	}
-	if (S > IN_K_STREAMS) {
-		P.in_luma = (const uint8_t *const *)(e->d_in_ptrs + (size_t)ds * 2 * S);
-		P.in_chroma = P.in_luma + S;
-	}
-	if (any_host)
-		HIP_TRY(e, hipEventRecord(e->ev_host_in, s_in));
-	// No padded copy of the frame (no k_input: -6.3 MB of traffic and a launch per 1080p frame) where the caller's packed
-	// frame can serve as the source planes: a width that is a multiple of 16 (no column to replicate; the rows below the
-	// picture are the last row, which the readers take by clamping) and 16-byte aligned frames (they load 16 bytes a lane).
+	bool in_work = false, any_host = false; // (something of this frame was enqueued on s_in; ... from the pinned buffers)
 	{
-		bool direct = e->src_direct_ok;
-		for (int s = 0; s < 2 * S && direct; s++)
-			direct = ((uintptr_t)f.in_used[s] & 15u) == 0;
-		P.src_direct = direct ? 1 : 0;
-		e->last_src_direct = direct;
-		P.src_last_y = direct ? P.height - 1 : P.ch - 1;
-		P.src_last_c = direct ? P.height / 2 - 1 : P.ch / 2 - 1;
+		const int rc_in = submit_input(e, f, P, replay, ds, s_in, in_work, any_host);
+		if (rc_in)
+			return rc_in;
 	}
 	// (k_input -- k_intra_decide without it -- also zeroes the ticket / abort / progress words of the intra wavefront)
 	*f.h_wf_err = 0;
@@ -2101,25 +2209,7 @@ static int submit_frame(cedar_enc *e, const ReplayIn *replay)
 	P.hdr = f.dv_hdr; // a few words per frame: the kernels read them from pinned host memory
 	P.prefix_len = f.dv_prefix;
 
-	// Headers per lane: idr_pic_id and "parameter sets in front of frame 0" follow the GLOBAL frame
-	// index (the reference counts the frames of its one device, cedar.c:1001, :1058-1061; a shard or a
-	// GOP lane starts somewhere in the stream). frame_num restarts with every IDR picture (cedar.c:1001).
-	f.aud = e->ext.aud && e->ext.slice_first == 0 ? (idr ? 1 : 2) : 0; // the first slice's session opens the access unit
-	f.with_ps.assign((size_t)S, 0);
-	for (int s = 0; s < S; s++) {
-		const long gidx = f.lane_gidx[s] < 0 ? 0 : f.lane_gidx[s];
-		const long gop = gidx / e->cfg.keyframe_interval;
-		for (int k = 0; k < e->ext.slice_num; k++) {
-			int r0, r1;
-			slice_rows(P.mb_h, P.slice_count, e->ext.slice_first + k, &r0, &r1);
-			// (scene cuts put IDR pictures anywhere: two in a row must still differ in idr_pic_id, so it follows their count)
-			f.h_hdr[s * e->ext.slice_num + k] = build_slice_header(e, idr, e->frame_p_count, e->ext.scene_cut > 0 ? (int)(e->idr_count & 1u) : (int)(gop & 1), r0 * P.mb_w,
-									       (e->rc_multi ? (int)f.h_qp_s[s] : P.qp) - e->cfg.qp);
-		}
-		// cedar.c:1058-1061: SPS + PPS in front of the stream's first picture (the IDR picture of GOP 0)
-		f.with_ps[s] = idr && ((e->ext.scene_cut > 0 ? gidx == 0 : gop == 0) || e->ext.repeat_headers) && e->ext.slice_first == 0;
-		f.h_prefix[s] = (f.with_ps[s] ? (uint32_t)e->sps_pps.size() : 0) + (f.aud ? (uint32_t)e->aud_nal[f.aud - 1].size() : 0);
-	}
+	build_frame_headers(e, f, P, idr);
 	// entropy lanes: frames alternate between two streams with scratch buffers of their own
 	const int lane = e->ent_lanes > 1 && e->s_ent2 ? e->frame_count % e->ent_lanes : 0;
 	hipStream_t s_ent = lane ? e->s_ent2 : e->s_ent;
@@ -2455,6 +2545,57 @@ static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again =
 	return 0;
 }
 
+// Development (CEDAR_DEBUG_HANG): what the progress and ticket words, and the device's own event log, say when a hand-off of
+// frame f timed out.
+static void dump_hang_state(cedar_enc *e, const InFlight &f, uint32_t wf_err)
+{
+	const int S = e->ext.n_streams;
+	hipDeviceSynchronize();
+	const int n_units = S * e->ext.slice_num;
+	std::vector<uint32_t> w((size_t)16 + 4 * n_units * PROG_BANDS), sy((size_t)3 * WF_SYNC_WORDS);
+	fprintf(stderr, "HANG: wf_err %u, frame idr %d, seq/tag %u, ds %d, h_done %u %u, frames in flight behind it %d, frame_count %d\n", wf_err, (int)f.idr, f.done_tag, f.ds,
+		f.h_done[0], f.h_done[1], e->fl_count, e->frame_count);
+	uint32_t ab[8] = {};
+	if (hipMemcpy(ab, e->d_abort_all, sizeof(ab), hipMemcpyDeviceToHost) == hipSuccess)
+		fprintf(stderr, " first wait that ran out: band %u planes %u idr %u unit %u | need %u saw %08x %08x %08x at step %u, tag %08x | %dx%d mb, db_bands %d\n", (ab[1] - 1) & 0xff, (ab[1] >> 8) & 15,
+			(ab[1] >> 12) & 1, ab[1] >> 16, ab[2], ab[3], ab[4], ab[5], ab[6], ab[7], e->P.mb_w, e->P.mb_h, e->db_bands);
+	if (e->d_dbg_log) { // the device's own account: code, frame tag, argument, microseconds since the first entry
+		std::vector<uint32_t> lg((size_t)4 + 4 * DBG_LOG_ENTRIES);
+		if (hipMemcpy(lg.data(), e->d_dbg_log, lg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+			const size_t n = std::min<size_t>(lg[0], DBG_LOG_ENTRIES);
+			std::vector<std::array<uint64_t, 3>> ev;
+			for (size_t i = 0; i < n; i++)
+				ev.push_back({ (uint64_t)lg[4 + 4 * i + 2] | (uint64_t)lg[4 + 4 * i + 3] << 32, lg[4 + 4 * i], lg[4 + 4 * i + 1] });
+			std::sort(ev.begin(), ev.end());
+			static const char *const names[12] = { "?", "input", "intra_decide", "intra_rows start", "intra_rows end", "deblock start", "deblock end", "gate start",
+							       "gate end", "inter", "?", "?" };
+			fprintf(stderr, " device log, %zu entries (us since the first | event | frame tag | argument):\n", n);
+			for (size_t i = 0; i < n; i++) {
+				const uint32_t code = (uint32_t)ev[i][1] & 0xff, tag = (uint32_t)ev[i][1] >> 8, arg = (uint32_t)ev[i][2];
+				if (code == 3 || code == 4 || code == 5 || code == 6) {
+					if ((arg & 0xff) != 0 && (arg & 0xff) != (uint32_t)e->db_bands - 1 && (arg & 0xff) != (uint32_t)e->db_bands / 2)
+						continue; // (first, middle and last band of a picture say enough)
+				}
+				fprintf(stderr, "  %10.1f %-16s tag %3u arg %08x\n", (double)(ev[i][0] - ev[0][0]) / 100.0, names[code < 12 ? code : 0], tag, arg);
+			}
+		}
+	}
+	for (int k = 0; k < e->depth; k++) {
+		if (hipMemcpy(w.data(), e->d_prog[k], w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sy.data(), e->d_wf_sync[k], sy.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+			break;
+		fprintf(stderr, " slot %2d%s tag %08x: inter %08x | db_y", k, k == f.ds ? "*" : " ", e->slot_tag[k], w[0]);
+		for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + b]);
+		fprintf(stderr, " | db_c");
+		for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + n_units * PROG_BANDS + b]);
+		fprintf(stderr, " | intra_y");
+		for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + 2 * n_units * PROG_BANDS + b]);
+		fprintf(stderr, " | intra_c");
+		for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + 3 * n_units * PROG_BANDS + b]);
+		fprintf(stderr, " | sync0 %u %u %u %u sync1 %u %u %u sync2 %u %u %u\n", sy[0], sy[1], sy[2], sy[3], sy[WF_SYNC_WORDS], sy[WF_SYNC_WORDS + 1], sy[WF_SYNC_WORDS + 2],
+			sy[2 * WF_SYNC_WORDS], sy[2 * WF_SYNC_WORDS + 1], sy[2 * WF_SYNC_WORDS + 2]);
+	}
+}
+
 static int collect_frame(cedar_enc *e)
 {
 	if (e->fl_count == 0)
@@ -2505,52 +2646,8 @@ static int collect_frame(cedar_enc *e)
 		too_big = too_big || sz[n] > (size_t)n * e->stream_out_cap;
 	}
 	const uint32_t wf_err = *f.h_wf_err;
-	if (wf_err && getenv("CEDAR_DEBUG_HANG")) { // development: what the progress and ticket words say when a hand-off timed out
-		hipDeviceSynchronize();
-		const int n_units = S * e->ext.slice_num;
-		std::vector<uint32_t> w((size_t)16 + 4 * n_units * PROG_BANDS), sy((size_t)3 * WF_SYNC_WORDS);
-		fprintf(stderr, "HANG: wf_err %u, frame idr %d, seq/tag %u, ds %d, h_done %u %u, frames in flight behind it %d, frame_count %d\n", wf_err, (int)f.idr, f.done_tag, f.ds,
-			f.h_done[0], f.h_done[1], e->fl_count, e->frame_count);
-		uint32_t ab[8] = {};
-		if (hipMemcpy(ab, e->d_abort_all, sizeof(ab), hipMemcpyDeviceToHost) == hipSuccess)
-			fprintf(stderr, " first wait that ran out: band %u planes %u idr %u unit %u | need %u saw %08x %08x %08x at step %u, tag %08x | %dx%d mb, db_bands %d\n", (ab[1] - 1) & 0xff, (ab[1] >> 8) & 15,
-				(ab[1] >> 12) & 1, ab[1] >> 16, ab[2], ab[3], ab[4], ab[5], ab[6], ab[7], e->P.mb_w, e->P.mb_h, e->db_bands);
-		if (e->d_dbg_log) { // the device's own account: code, frame tag, argument, microseconds since the first entry
-			std::vector<uint32_t> lg((size_t)4 + 4 * DBG_LOG_ENTRIES);
-			if (hipMemcpy(lg.data(), e->d_dbg_log, lg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
-				const size_t n = std::min<size_t>(lg[0], DBG_LOG_ENTRIES);
-				std::vector<std::array<uint64_t, 3>> ev;
-				for (size_t i = 0; i < n; i++)
-					ev.push_back({ (uint64_t)lg[4 + 4 * i + 2] | (uint64_t)lg[4 + 4 * i + 3] << 32, lg[4 + 4 * i], lg[4 + 4 * i + 1] });
-				std::sort(ev.begin(), ev.end());
-				static const char *const names[12] = { "?", "input", "intra_decide", "intra_rows start", "intra_rows end", "deblock start", "deblock end", "gate start",
-								       "gate end", "inter", "?", "?" };
-				fprintf(stderr, " device log, %zu entries (us since the first | event | frame tag | argument):\n", n);
-				for (size_t i = 0; i < n; i++) {
-					const uint32_t code = (uint32_t)ev[i][1] & 0xff, tag = (uint32_t)ev[i][1] >> 8, arg = (uint32_t)ev[i][2];
-					if (code == 3 || code == 4 || code == 5 || code == 6) {
-						if ((arg & 0xff) != 0 && (arg & 0xff) != (uint32_t)e->db_bands - 1 && (arg & 0xff) != (uint32_t)e->db_bands / 2)
-							continue; // (first, middle and last band of a picture say enough)
-					}
-					fprintf(stderr, "  %10.1f %-16s tag %3u arg %08x\n", (double)(ev[i][0] - ev[0][0]) / 100.0, names[code < 12 ? code : 0], tag, arg);
-				}
-			}
-		}
-		for (int k = 0; k < e->depth; k++) {
-			if (hipMemcpy(w.data(), e->d_prog[k], w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sy.data(), e->d_wf_sync[k], sy.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
-				break;
-			fprintf(stderr, " slot %2d%s tag %08x: inter %08x | db_y", k, k == f.ds ? "*" : " ", e->slot_tag[k], w[0]);
-			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + b]);
-			fprintf(stderr, " | db_c");
-			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + n_units * PROG_BANDS + b]);
-			fprintf(stderr, " | intra_y");
-			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + 2 * n_units * PROG_BANDS + b]);
-			fprintf(stderr, " | intra_c");
-			for (int b = 0; b < std::min(e->db_bands, 20); b++) fprintf(stderr, " %x", w[16 + 3 * n_units * PROG_BANDS + b]);
-			fprintf(stderr, " | sync0 %u %u %u %u sync1 %u %u %u sync2 %u %u %u\n", sy[0], sy[1], sy[2], sy[3], sy[WF_SYNC_WORDS], sy[WF_SYNC_WORDS + 1], sy[WF_SYNC_WORDS + 2],
-				sy[2 * WF_SYNC_WORDS], sy[2 * WF_SYNC_WORDS + 1], sy[2 * WF_SYNC_WORDS + 2]);
-		}
-	}
+	if (wf_err && getenv("CEDAR_DEBUG_HANG"))
+		dump_hang_state(e, f, wf_err);
 	// Scene cut (cedar_enc_config_ext.scene_cut): enough macroblocks of this P picture said their own mean predicts them
 	// better than the best vector: the picture is coded again as an IDR picture that starts a new GOP, and the frames
 	// submitted behind it after it -- the machinery of a failed frame, with the frame itself put back first.
