@@ -201,7 +201,9 @@ inline Plan plan_static(const PlanIn &in)
 	const int wgs2 = 2 * W_db; // workgroups of two pictures
 	const bool rows_fit = n_units <= 8 && wgs2 <= in.cus * 3 / 4 && 2 * px(W_db) + old_intra <= xcd_cus - 2;
 	p.idr_beside_ok = rows_fit && 3 * px(W_db) + old_intra <= xcd_cus - 2;
-	const bool rows_b2b = !rows_fit && n_units >= 6 && n_units < 24;
+	// (round 4, with the entropy chain at 3 launches: 4 streams 95.9 against 91.0 with the wave pairs pipelined, 5: 109.2 against 106.3,
+	// 3: 78 against 82)
+	const bool rows_b2b = !rows_fit && n_units >= 4 && n_units < 24;
 	p.db_rows = (set(in.env_deblock_rows) ? in.env_deblock_rows == 2 || (in.env_deblock_rows != 0 && (rows_fit || rows_b2b)) : rows_fit || rows_b2b) &&
 		    (long long)n_units * nb_hi <= WF_SYNC_WORDS - 16; // (a progress word per band in the sync region)
 	p.db_lds_kb = rows_fit ? 81 : 16;
@@ -242,7 +244,8 @@ inline PlanRun plan_run(const PlanIn &in, const Plan &p, const PlanProbe &pr)
 	// (k_deblock_rows: 3 at any size -- 1080p, 8 / 3 runs each, the driver's K 20 arguments and the default K 300: 5 stripes
 	// 38.4 / 50.2 M MB/s, 4: 40.5 / 50.5, 3: 41.0 / 51.0, 2: 43.0 / 49.0, 1: 34.1 / 35.1; every stripe is two launches of
 	// the 85 us a submit takes, and the K 20 region waits for its IDR picture's submit)
-	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 && !p.db_rows ? 5 : 3);
+	// (round 4, k_pack_out and no k_input: 2 / 3 / 4 / 5 stripes 52.8 / 58.5 / 59.7 / 60.2 M at K 300, 50.1 / 56.3 / 55.4 / 55.8 at K 20)
+	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 ? 5 : 3);
 	r.defer_default = 0;
 	if (r.row_pipe && p.defer_wanted && r.db_streams >= 3 && n_mbs >= 4000) {
 		if (!set(in.env_inter_bands))

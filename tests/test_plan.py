@@ -51,12 +51,12 @@ def test_few_units_deblock_with_a_wave_per_macroblock_row(plan):
     most of the chip; two deblock streams, nothing held back. Many units keep the wave pairs of k_deblock2_planes."""
     r = plan()
     assert r.deblock_rows == 1 and (r.want_row_pipe, r.db_streams_wanted) == (1, 2)
-    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 3, 0, 1)
-    assert plan(w=3840, h=2160).inter_bands == 3 and plan(inter_bands=5).inter_bands == 5
+    assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 5, 0, 1)   # (5 stripes since round 4's back end)
+    assert plan(w=3840, h=2160).inter_bands == 5 and plan(w=854, h=480).inter_bands == 3 and plan(inter_bands=4).inter_bands == 4
     assert plan(usable=1).db_streams == 1 and plan(usable=0).row_pipe == 0
     for kw, rows, pipe in ((dict(w=854, h=480), 1, 1), (dict(w=3840, h=2160), 1, 1), (dict(w=3840, h=2160, slices=4), 1, 1),   # 2 pictures: 32 / 136 / 144 workgroups
-                           (dict(streams=2), 1, 1), (dict(streams=3), 0, 1), (dict(streams=5), 0, 1),                             # 136 / 204 (3/4 x 256 = 192): wave pairs
-                           (dict(streams=6), 1, 0), (dict(streams=8), 1, 0), (dict(streams=23), 1, 0),                            # 6 .. 23 units: rows, frames back to back
+                           (dict(streams=2), 1, 1), (dict(streams=3), 0, 1),                                                      # 136 / 204 (3/4 x 256 = 192): wave pairs
+                           (dict(streams=4), 1, 0), (dict(streams=5), 1, 0), (dict(streams=8), 1, 0), (dict(streams=23), 1, 0),   # 4 .. 23 units: rows, frames back to back
                            (dict(streams=24), 0, 0), (dict(streams=32), 0, 0),
                            (dict(w=3840, h=2160, slices=4, streams=2), 1, 0), (dict(w=320, h=240, streams=8), 1, 1), (dict(w=320, h=240, streams=9), 1, 0)):
         r = plan(**kw)
@@ -177,6 +177,7 @@ def test_resident_deblock_workgroups_always_leave_every_xcd_room(plan):
     assert plan(w=3840, h=2160).idr_beside_ok == 1 and plan(w=3840, h=2160).db_wgs_per_xcd == 9   # 68 a picture: 3 x 9 <= 30
     r = plan(w=2560, h=1440, streams=2)                                            # 92 a picture: 2 x 12 <= 30 < 3 x 12
     assert (r.deblock_rows, r.row_pipe, r.db_wgs_per_xcd, r.idr_beside_ok) == (1, 1, 12, 0)
-    assert plan(streams=4).row_pipe == 1 and plan(streams=4).deblock_rows == 0     # 4 x 1080p: 136 a picture, 2 x 17 > 30 -> the wave pairs
+    assert plan(streams=3).row_pipe == 1 and plan(streams=3).deblock_rows == 0     # 3 x 1080p: 102 a picture, 2 x 102 > 3/4 of the CUs -> the wave pairs
+    assert plan(streams=4).row_pipe == 0 and plan(streams=4).deblock_rows == 1     # 4 x 1080p: 2 x 17 > 30 on an XCD -> this kernel, frames back to back
     # back to back nothing waits: no claim
     assert plan(streams=8).deblock_rows == 1 and plan(streams=8).row_pipe == 0 and plan(streams=8).db_lds_kb == 16
