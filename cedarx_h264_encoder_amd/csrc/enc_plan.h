@@ -245,7 +245,8 @@ inline PlanRun plan_run(const PlanIn &in, const Plan &p, const PlanProbe &pr)
 	// 38.4 / 50.2 M MB/s, 4: 40.5 / 50.5, 3: 41.0 / 51.0, 2: 43.0 / 49.0, 1: 34.1 / 35.1; every stripe is two launches of
 	// the 85 us a submit takes, and the K 20 region waits for its IDR picture's submit)
 	// (round 4, k_pack_out and no k_input: 2 / 3 / 4 / 5 stripes 52.8 / 58.5 / 59.7 / 60.2 M at K 300, 50.1 / 56.3 / 55.4 / 55.8 at K 20)
-	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 ? 5 : 3);
+	// (one unit only: 3840x2160 in 4 slices 90.4 M with 3 stripes, 83.5 with 5; in one slice 83.1 -> 87.7)
+	int nb = set(in.env_inter_bands) ? in.env_inter_bands : (n_mbs >= 4000 && (n_units == 1 || !p.db_rows) ? 5 : 3);
 	r.defer_default = 0;
 	if (r.row_pipe && p.defer_wanted && r.db_streams >= 3 && n_mbs >= 4000) {
 		if (!set(in.env_inter_bands))

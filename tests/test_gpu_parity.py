@@ -735,12 +735,14 @@ def test_1080p_wavefront_shapes_match_oracle(ce, monkeypatch, env):
     assert got == want
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "0", "1+write-through"])
 def test_both_entropy_back_ends_give_the_oracles_bytes(ce, monkeypatch, fused):
     """k_pack_out (one launch behind k_scan: bits, emulation prevention, NAL layout, bytes on the host) and the chain it
     replaces (CEDAR_ENTROPY_FUSED=0) on what stresses a back end: slices and lock-step streams (many NAL units to lay out),
     I_PCM pictures (byte-aligned raw samples, long zero runs to escape: a black picture), pictures of a few bytes."""
-    monkeypatch.setenv("CEDAR_ENTROPY_FUSED", fused)
+    monkeypatch.setenv("CEDAR_ENTROPY_FUSED", fused[0])
+    if "write-through" in fused:   # k_pack_out's other way to the host: write-through stores, the flag from its last workgroup
+        monkeypatch.setenv("CEDAR_PK_DELIVER", "1")
     rng = np.random.RandomState(7)
     cases = [(320, 240, 24, 3, 3, "B"), (640, 368, 1, 1, 1, "noise"), (96, 64, 4, 2, 2, "black"), (1920, 1080, 40, 1, 1, "static")]
     for w, h, qp, slices, streams, kind in cases:

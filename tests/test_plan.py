@@ -53,6 +53,7 @@ def test_few_units_deblock_with_a_wave_per_macroblock_row(plan):
     assert r.deblock_rows == 1 and (r.want_row_pipe, r.db_streams_wanted) == (1, 2)
     assert (r.row_pipe, r.db_streams, r.inter_bands, r.defer_default, r.cohorts) == (1, 2, 5, 0, 1)   # (5 stripes since round 4's back end)
     assert plan(w=3840, h=2160).inter_bands == 5 and plan(w=854, h=480).inter_bands == 3 and plan(inter_bands=4).inter_bands == 4
+    assert plan(w=3840, h=2160, slices=4).inter_bands == 3 and plan(streams=2).inter_bands == 3   # (several units on this kernel keep 3)
     assert plan(usable=1).db_streams == 1 and plan(usable=0).row_pipe == 0
     for kw, rows, pipe in ((dict(w=854, h=480), 1, 1), (dict(w=3840, h=2160), 1, 1), (dict(w=3840, h=2160, slices=4), 1, 1),   # 2 pictures: 32 / 136 / 144 workgroups
                            (dict(streams=2), 1, 1), (dict(streams=3), 0, 1),                                                      # 136 / 204 (3/4 x 256 = 192): wave pairs
