@@ -1754,8 +1754,17 @@ int Launch::entropy(const Params &p, void *stream)
 	}
 	if (version == 2 || (version == 0 && (long)mbs * p.n_streams <= 40000))
 		hipLaunchKernelGGL(k_cavlc2, dim3((mbs + 1) / 2, p.n_streams), dim3(64), 0, s, p);
-	else
-		hipLaunchKernelGGL(k_cavlc, dim3((mbs + 63) / 64, p.n_streams), dim3(64), 0, s, p);
+	else {
+		// (a wave of fewer macroblocks diverges less and leaves room for more waves: CEDAR_CAVLC_LANES, development)
+		static int lanes = 0;
+		if (!lanes) {
+			const char *e = getenv("CEDAR_CAVLC_LANES");
+			lanes = e ? atoi(e) : 64;
+			if (lanes != 8 && lanes != 16 && lanes != 32)
+				lanes = 64;
+		}
+		hipLaunchKernelGGL(k_cavlc, dim3((mbs + lanes - 1) / lanes, p.n_streams), dim3(lanes), 0, s, p);
+	}
 	hipLaunchKernelGGL(k_scan, dim3(n_units), dim3(n_units > 8 ? 256 : 1024), 0, s, p);
 	if (p.ent_rec) // the fused back end: Launch::entropy_out adds k_pack_out
 		return (int)hipGetLastError();
