@@ -18,7 +18,7 @@ LIB = os.path.join(PKG, "lib")
 OBJ = os.path.join(LIB, "obj")
 ARCH = "gfx950"
 
-SOURCES = ["enc_session.cpp", "enc_k_parallel.hip", "enc_k_wavefront.hip", "enc_k_deblock.hip", "enc_k_intra.hip", "enc_k_entropy.hip"]
+SOURCES = ["enc_session.cpp", "enc_config.cpp", "enc_headers.cpp", "enc_submit.cpp", "enc_k_parallel.hip", "enc_k_wavefront.hip", "enc_k_deblock.hip", "enc_k_intra.hip", "enc_k_entropy.hip"]
 LIB_PATH = os.path.join(LIB, "libcedar_h264enc.so")
 CLI_PATH = os.path.join(LIB, "h264enc")
 
