@@ -393,84 +393,65 @@ static int alloc_host_buffers(cedar_enc *e, int luma_sz, int chroma_sz, int S_us
 	return 0;
 }
 
-// The device side of the buffer manager: per ring slot the frame's planes, records, levels and hand-off words; per entropy
-// lane the bit slots and what k_scan / k_pack_out meet in; the tables. Sizes follow the plan (frames in flight, which wavefront
-// kernels, how many bands); everything is cleared (dalloc), tagged words on purpose (they never hold another frame's tag).
-static int alloc_device_buffers(cedar_enc *e, const Plan &plan, int luma_sz, int chroma_sz, int G, bool row_rule)
+// Macroblocks that differ in QP (regions of interest, MAD classes, rate control over several streams): the offset of every
+// macroblock and one row of derived parameters per QP_Y.
+static int alloc_qp_tables(cedar_enc *e, bool row_rule)
 {
 	Params &P = e->P;
 	const struct cedar_enc_config_ext &ext = e->ext;
-	const int S = ext.n_streams, n_units = S * ext.slice_num, mb_w = P.mb_w, mb_h = P.mb_h;
 	int rc = 0;
-	(void)mb_h;
-	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
-	P.plane_y_stride = (int64_t)plane_y;
-	P.plane_uv_stride = (int64_t)plane_uv;
-	// (GOP lanes take their frames from the mux's ring, never from these per-slot copies)
-	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S * (G > 1 ? 1 : e->depth)))) return rc;
-	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S * (G > 1 ? 1 : e->depth)))) return rc;
-	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S * e->depth))) return rc;
-	for (int i = 0; i < e->nrec; i++) {
-		if ((rc = dalloc(e, &e->d_rec_y[i], plane_y * S))) return rc;
-		if ((rc = dalloc(e, &e->d_rec_uv[i], plane_uv * S))) return rc;
-	}
-	for (int i = 0; i < e->depth; i++) {
-		if ((rc = dalloc(e, &e->d_src_y[i], plane_y * S))) return rc;
-		if ((rc = dalloc(e, &e->d_src_uv[i], plane_uv * S))) return rc;
-		// + 1 macroblock: the dummy slot idle k_inter waves write to
-		if ((rc = dalloc(e, &e->d_mbi[i], (size_t)P.n_mb * S + 1))) return rc;
-		if ((rc = dalloc(e, &e->d_i4[i], ((size_t)P.n_mb * S + 1) * 16))) return rc;
-		if ((rc = dalloc(e, &e->d_nnz[i], ((size_t)P.n_mb * S + 1) * NNZ_PER_MB))) return rc;
-		if ((rc = dalloc(e, &e->d_coef[i], ((size_t)P.n_mb * S + 1) * COEF_PER_MB))) return rc;
-		if (e->mb_qp) {
-			if ((rc = dalloc(e, &e->d_qp_eff[i], (size_t)P.n_mb * S))) return rc;
-			if ((rc = dalloc(e, &e->d_qp_t[i], (size_t)P.n_mb * S))) return rc;
-		}
-	}
-	if (e->mb_qp) {
-		// the offset of every macroblock (the first region that covers it; all zero when only the MAD
-		// classes move QPs), and one row of derived parameters per QP_Y
-		std::vector<int8_t> off((size_t)P.n_mb, 0);
-		for (int my = 0; my < P.mb_h; my++)
-			for (int mx = 0; mx < P.mb_w; mx++)
-				for (int k = 0; k < ext.roi_count; k++) {
-					const int *r = ext.roi[k];
-					if (mx >= r[0] && mx < r[0] + r[2] && my >= r[1] && my < r[1] + r[3]) {
-						off[(size_t)my * P.mb_w + mx] = (int8_t)r[4];
-						break;
-					}
+	// the offset of every macroblock (the first region that covers it; all zero when only the MAD
+	// classes move QPs), and one row of derived parameters per QP_Y
+	std::vector<int8_t> off((size_t)P.n_mb, 0);
+	for (int my = 0; my < P.mb_h; my++)
+		for (int mx = 0; mx < P.mb_w; mx++)
+			for (int k = 0; k < ext.roi_count; k++) {
+				const int *r = ext.roi[k];
+				if (mx >= r[0] && mx < r[0] + r[2] && my >= r[1] && my < r[1] + r[3]) {
+					off[(size_t)my * P.mb_w + mx] = (int8_t)r[4];
+					break;
 				}
-		std::vector<QpRow> rows(52);
-		for (int q = 0; q < 52; q++) {
-			QpRow &r = rows[q];
-			const int qi = q + e->chroma_qp_offset;
-			for (int k = 0; k < 3; k++) {
-				r.mf[k] = kQuantMF[q % 6][k];
-				r.dv[k] = kDequantV[q % 6][k];
-				r.tc0[k] = kTc0[q][k];
 			}
-			r.qbits = 15 + q / 6;
-			r.qshift = q / 6;
-			r.lambda = lambda_of_qp(q);
-			r.qpc = kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi];
-			r.alpha = kAlpha[q];
-			r.beta = kBeta[q];
-			r.pad = 0;
+	std::vector<QpRow> rows(52);
+	for (int q = 0; q < 52; q++) {
+		QpRow &r = rows[q];
+		const int qi = q + e->chroma_qp_offset;
+		for (int k = 0; k < 3; k++) {
+			r.mf[k] = kQuantMF[q % 6][k];
+			r.dv[k] = kDequantV[q % 6][k];
+			r.tc0[k] = kTc0[q][k];
 		}
-		if ((rc = dalloc(e, &e->d_roi_off, (size_t)P.n_mb))) return rc;
-		if ((rc = dalloc(e, &e->d_qtab, (size_t)52))) return rc;
-		HIP_TRY(e, hipMemcpy(e->d_roi_off, off.data(), off.size(), hipMemcpyHostToDevice));
-		HIP_TRY(e, hipMemcpy(e->d_qtab, rows.data(), rows.size() * sizeof(QpRow), hipMemcpyHostToDevice));
-		P.roi_off = e->d_roi_off;
-		P.qtab = e->d_qtab;
-		P.row_rule = row_rule ? 1 : 0;
-		for (int k = 0; k < 5; k++) {
-			P.mad_dqp[k] = ext.mad_dqp[k];
-			P.mad_on |= ext.mad_dqp[k] != 0;
-			if (k < 4)
-				P.mad_th[k] = ext.mad_th[k];
-		}
+		r.qbits = 15 + q / 6;
+		r.qshift = q / 6;
+		r.lambda = lambda_of_qp(q);
+		r.qpc = kChromaQp[qi < 0 ? 0 : qi > 51 ? 51 : qi];
+		r.alpha = kAlpha[q];
+		r.beta = kBeta[q];
+		r.pad = 0;
 	}
+	if ((rc = dalloc(e, &e->d_roi_off, (size_t)P.n_mb))) return rc;
+	if ((rc = dalloc(e, &e->d_qtab, (size_t)52))) return rc;
+	HIP_TRY(e, hipMemcpy(e->d_roi_off, off.data(), off.size(), hipMemcpyHostToDevice));
+	HIP_TRY(e, hipMemcpy(e->d_qtab, rows.data(), rows.size() * sizeof(QpRow), hipMemcpyHostToDevice));
+	P.roi_off = e->d_roi_off;
+	P.qtab = e->d_qtab;
+	P.row_rule = row_rule ? 1 : 0;
+	for (int k = 0; k < 5; k++) {
+		P.mad_dqp[k] = ext.mad_dqp[k];
+		P.mad_on |= ext.mad_dqp[k] != 0;
+		if (k < 4)
+			P.mad_th[k] = ext.mad_th[k];
+	}
+	return 0;
+}
+
+// Per entropy lane the bit slots of the CAVLC kernels and what k_scan / k_pack_out (or the round-3 chain) meet in.
+static int alloc_entropy_scratch(cedar_enc *e)
+{
+	Params &P = e->P;
+	const struct cedar_enc_config_ext &ext = e->ext;
+	const int S = ext.n_streams, n_units = S * ext.slice_num, mb_w = P.mb_w;
+	int rc = 0;
 	{
 		// A second entropy lane (frames alternating between two streams with scratch of their own)
 		// is there for the asking; measured, one lane keeps up (1080p: 32.5 M MB/s either way)
@@ -515,11 +496,14 @@ static int alloc_device_buffers(cedar_enc *e, const Plan &plan, int luma_sz, int
 	}
 	for (int i = 0; i < e->depth && !e->ent_fused; i++)
 		if ((rc = dalloc(e, &e->d_out[i], e->out_cap + 16))) return rc; // k_copy_out moves whole 16-byte chunks
-	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
-	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
-	if (getenv("CEDAR_DEBUG_HANG") && (rc = dalloc(e, &e->d_dbg_log, (size_t)4 + 4 * DBG_LOG_ENTRIES))) return rc;
-	for (int i = 0; i < e->depth && ext.scene_cut > 0; i++)
-		if ((rc = dalloc(e, &e->d_cut_votes[i], (size_t)4))) return rc;
+	return 0;
+}
+
+// What the plan chose for the two wavefronts, and per ring slot their sync words, hand-off buffers and progress words.
+static int alloc_wavefront_words(cedar_enc *e, const Plan &plan)
+{
+	const int mb_w = e->P.mb_w, n_units = e->ext.n_streams * e->ext.slice_num;
+	int rc = 0;
 	e->wf_split = plan.wf_split;
 	e->wf_split_intra = plan.wf_split_intra;
 	e->db_pairs = plan.db_pairs;
@@ -545,9 +529,55 @@ static int alloc_device_buffers(cedar_enc *e, const Plan &plan, int luma_sz, int
 		if ((rc = dalloc(e, &e->d_prog[i], (size_t)16 + 4 * n_units * PROG_BANDS))) return rc;
 		HIP_TRY(e, hipMemset(e->d_prog[i], 0, sizeof(uint32_t) * (16 + 4 * (size_t)n_units * PROG_BANDS)));
 	}
-	{
-		e->prev_slot = e->prev2_slot = -1;
+	return 0;
+}
+
+// The device side of the buffer manager: per ring slot the frame's planes, records, levels and hand-off words; per entropy
+// lane the bit slots and what k_scan / k_pack_out meet in; the tables. Sizes follow the plan (frames in flight, which wavefront
+// kernels, how many bands); everything is cleared (dalloc), tagged words on purpose (they never hold another frame's tag).
+static int alloc_device_buffers(cedar_enc *e, const Plan &plan, int luma_sz, int chroma_sz, int G, bool row_rule)
+{
+	Params &P = e->P;
+	const struct cedar_enc_config_ext &ext = e->ext;
+	const int S = ext.n_streams, n_units = S * ext.slice_num, mb_w = P.mb_w, mb_h = P.mb_h;
+	int rc = 0;
+	(void)mb_h;
+	const size_t plane_y = (size_t)P.cw * P.ch, plane_uv = plane_y / 2;
+	P.plane_y_stride = (int64_t)plane_y;
+	P.plane_uv_stride = (int64_t)plane_uv;
+	// (GOP lanes take their frames from the mux's ring, never from these per-slot copies)
+	if ((rc = dalloc(e, &e->d_in_y, (size_t)luma_sz * S * (G > 1 ? 1 : e->depth)))) return rc;
+	if ((rc = dalloc(e, &e->d_in_uv, (size_t)chroma_sz * S * (G > 1 ? 1 : e->depth)))) return rc;
+	if ((rc = dalloc(e, &e->d_in_ptrs, (size_t)2 * S * e->depth))) return rc;
+	for (int i = 0; i < e->nrec; i++) {
+		if ((rc = dalloc(e, &e->d_rec_y[i], plane_y * S))) return rc;
+		if ((rc = dalloc(e, &e->d_rec_uv[i], plane_uv * S))) return rc;
 	}
+	for (int i = 0; i < e->depth; i++) {
+		if ((rc = dalloc(e, &e->d_src_y[i], plane_y * S))) return rc;
+		if ((rc = dalloc(e, &e->d_src_uv[i], plane_uv * S))) return rc;
+		// + 1 macroblock: the dummy slot idle k_inter waves write to
+		if ((rc = dalloc(e, &e->d_mbi[i], (size_t)P.n_mb * S + 1))) return rc;
+		if ((rc = dalloc(e, &e->d_i4[i], ((size_t)P.n_mb * S + 1) * 16))) return rc;
+		if ((rc = dalloc(e, &e->d_nnz[i], ((size_t)P.n_mb * S + 1) * NNZ_PER_MB))) return rc;
+		if ((rc = dalloc(e, &e->d_coef[i], ((size_t)P.n_mb * S + 1) * COEF_PER_MB))) return rc;
+		if (e->mb_qp) {
+			if ((rc = dalloc(e, &e->d_qp_eff[i], (size_t)P.n_mb * S))) return rc;
+			if ((rc = dalloc(e, &e->d_qp_t[i], (size_t)P.n_mb * S))) return rc;
+		}
+	}
+	if (e->mb_qp && (rc = alloc_qp_tables(e, row_rule)))
+		return rc;
+	if ((rc = alloc_entropy_scratch(e)))
+		return rc;
+	if ((rc = dalloc(e, &e->d_pred4, (size_t)9 * 16))) return rc;
+	if ((rc = dalloc(e, &e->d_abort_all, (size_t)16))) return rc;
+	if (getenv("CEDAR_DEBUG_HANG") && (rc = dalloc(e, &e->d_dbg_log, (size_t)4 + 4 * DBG_LOG_ENTRIES))) return rc;
+	for (int i = 0; i < e->depth && ext.scene_cut > 0; i++)
+		if ((rc = dalloc(e, &e->d_cut_votes[i], (size_t)4))) return rc;
+	if ((rc = alloc_wavefront_words(e, plan)))
+		return rc;
+	e->prev_slot = e->prev2_slot = -1;
 	uint8_t tab[9 * 16];
 	build_pred4_table(tab);
 	HIP_TRY(e, hipMemcpy(e->d_pred4, tab, sizeof(tab), hipMemcpyHostToDevice));
@@ -559,6 +589,172 @@ static int alloc_device_buffers(cedar_enc *e, const Plan &plan, int luma_sz, int
 	for (bool &v : e->in_tab_valid)
 		v = false;
 
+	return 0;
+}
+
+// One pipelined session per device, across sessions and processes (see pipe_lock_acquire).
+static void take_pipe_token(cedar_enc *e)
+{
+	if (e->holds_pipe_token)
+		return;
+	if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0) {
+		e->pipe_lock_fd = pipe_lock_acquire(e->device);
+		if (e->pipe_lock_fd == -1) // taken by a session of another process
+			g_pipelined_sessions[e->device & 63].fetch_sub(1);
+		else
+			e->holds_pipe_token = true;
+	} else {
+		g_pipelined_sessions[e->device & 63].fetch_sub(1);
+	}
+}
+
+// The deblock streams that really run beside s_main, the entropy stream and each other, moved to the front of s_db[]
+// (at most db_max of them; *usable = how many).
+static int probe_deblock_streams(cedar_enc *e, bool want, int db_max, int *usable_out)
+{
+	int usable = 0;
+	for (int i = 0; want && i < DB_STREAMS && usable < db_max; i++) {
+		bool ok = false, ok2 = true;
+		if (Launch::probe_overlap(e->s_db[i], e->s_main, e->d_prog[0], &ok))
+			return fail(e, -EIO, "stream probe failed");
+		// ... and beside the entropy stream, or every frame's bitstream would queue behind a
+		// deblock kernel that is resident for a whole frame time
+		if (ok && (Launch::probe_overlap(e->s_db[i], e->s_ent, e->d_prog[0], &ok2) || !ok2))
+			ok = false;
+		ok2 = true;
+		for (int j = 0; ok && j < usable; j++) // and beside the deblock streams already accepted
+			if (Launch::probe_overlap(e->s_db[i], e->s_db[j], e->d_prog[0], &ok2) || !ok2)
+				ok = false;
+		if (ok) {
+			hipStream_t t = e->s_db[usable];
+			e->s_db[usable] = e->s_db[i];
+			e->s_db[i] = t;
+			usable++;
+		}
+	}
+	HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
+	*usable_out = usable;
+	return 0;
+}
+
+static int probe_analysis_streams(cedar_enc *e)
+{
+	// further analysis streams: each must run beside every deblock stream and every analysis
+	// stream already accepted (a frame's gate kernels spin while the next frame's run)
+	int an = 1;
+	const char *enva = getenv("CEDAR_ANALYSIS_STREAMS");
+	const int an_max = enva ? atoi(enva) : 1;
+	for (int i = 1; e->row_pipe && i < AN_STREAMS && an < an_max; i++) {
+		bool ok = true, o = false;
+		for (int j = 0; ok && j < e->db_streams; j++)
+			if (Launch::probe_overlap(e->s_ana[i], e->s_db[j], e->d_prog[0], &o) || !o)
+				ok = false;
+		for (int j = 0; ok && j < an; j++)
+			if (Launch::probe_overlap(e->s_ana[i], e->s_ana[j], e->d_prog[0], &o) || !o)
+				ok = false;
+		if (ok) {
+			hipStream_t t = e->s_ana[an];
+			e->s_ana[an] = e->s_ana[i];
+			e->s_ana[i] = t;
+			an++;
+		}
+	}
+	e->an_streams = an;
+	return 0;
+}
+
+static int setup_lookahead(cedar_enc *e, const struct cedar_enc_config *cfg, const Plan &plan)
+{
+	// Look-ahead for IDR pictures: two more streams -- the IDR picture's analysis (busy for
+	// milliseconds) and the input of all frames (which must never queue behind that, nor behind
+	// a gate on s_main) -- dealt by assign_stream_roles; each must run beside every stream in use.
+	// The IDR picture's deblocking: on a stream of its own, resident beside the intra wavefront it follows band by
+	// band (k_deblock_rows, GOPs of 20 pictures and more: 1080p keyint 25, K 300 47.0 -> 48.0 M MB/s, the driver's K 20
+	// 34.8 -> 38.3 M: its 0.3 ms no longer come after the intra kernel's 1.9 ms), or behind it on the same stream --
+	// k_deblock2_planes, whose whole-CU workgroups measured slower beside it (one more queue that blocks a pipe), and
+	// SHORT GOPs on either kernel: the stream that would carry it carries every other IDR picture instead (s_idr2),
+	// and a stream of short GOPs is bound by its IDR pictures (keyint 1 / 4 / 8 / 12: 7.2 / 25.1 / 44.5 / 46.2 M MB/s
+	// behind against 4.1 / 15.1 / 29.3 / 42.2 beside). CEDAR_IDR_DEBLOCK_INLINE.
+	const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
+	e->lookahead = false;
+	e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows || cfg->keyframe_interval < 20 || !plan.idr_beside_ok;
+	// (sessions whose frames run back to back take the IDR picture out of line too: nothing polls
+	// there, the P picture after it waits for its events, and with 4 frames in flight it gets a
+	// three-frame head start)
+	const char *envlb = getenv("CEDAR_LOOKAHEAD_BATCH");
+	if ((e->row_pipe ? e->depth > 4 : ((!envlb || atoi(envlb) != 0) && e->depth >= 3)) && (!envl || atoi(envl) != 0)) {
+		// streams not taken by the deblock / analysis roles, in the order assign_stream_roles meant
+		// them for: IDR analysis, input, then the spare one (second entropy lane)
+		std::vector<hipStream_t> used = { e->s_main, e->s_ent }, spare, got;
+		for (int i = 0; i < e->db_streams; i++)
+			used.push_back(e->s_db[i]);
+		for (int i = 1; i < e->an_streams; i++)
+			used.push_back(e->s_ana[i]);
+		for (int i = e->an_streams; i < AN_STREAMS; i++)
+			spare.push_back(e->s_ana[i]);
+		for (int i = e->db_streams; i < DB_STREAMS; i++)
+			spare.push_back(e->s_db[i]);
+		const size_t want = e->idr_deblock_inline ? 3 : 4;
+		for (size_t c = 0; c < spare.size() && got.size() < want; c++) {
+			bool ok = true, o = false;
+			for (size_t j = 0; ok && j < used.size(); j++)
+				if (Launch::probe_overlap(spare[c], used[j], e->d_prog[0], &o) || !o)
+					ok = false;
+			if (ok) {
+				got.push_back(spare[c]);
+				used.push_back(spare[c]);
+			}
+		}
+		HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
+		HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
+		if (got.size() >= (e->idr_deblock_inline ? 2u : 3u)) {
+			e->s_idr = got[0];
+			e->s_in = got[1];
+			size_t k = 2;
+			e->s_db_idr = e->idr_deblock_inline ? nullptr : got[k++];
+			const char *envl2 = getenv("CEDAR_ENTROPY_LANES");
+			e->s_ent2 = k < got.size() && e->ent_lanes > 1 && (!envl2 || atoi(envl2) > 1) ? got[k] : nullptr;
+			// the spare stream otherwise carries every other IDR picture: consecutive IDR pictures
+			// depend on nothing either, which doubles the rate of short GOPs (keyint 1: all of them)
+			e->s_idr2 = !e->s_ent2 && e->idr_deblock_inline && k < got.size() ? got[k] : nullptr;
+			e->lookahead = true;
+		}
+	}
+	return 0;
+}
+
+static int setup_cohorts(cedar_enc *e, const PlanRun &run)
+{
+	// cohorts (submit_frame): two from 32 units on. With whole-CU deblock workgroups the deblocking
+	// of one cohort never ran beside the search of the other (16 waves of 128 registers find no
+	// empty CU while k_inter's small workgroups keep refilling them: 32 x 1080p 2.29 ms per step
+	// against 2.20 ms with one cohort; CU masks 2.96 ms; stream priority no change). With the
+	// 2-pair workgroups it does: 32 x 1080p 1.87 -> 1.73 ms (139 -> 151 M MB/s), 64: 3.58 -> 3.18 ms
+	// (146 -> 164 M). Not below: the deblock wavefront of a picture takes its ~0.45 ms however few
+	// pictures there are, and half of 16 streams' search is shorter than that (16: 120 -> 92 M).
+	// Three or four cohorts lose everywhere (more, smaller launches on the same four hardware queues).
+	// Wave priority (s_setprio) for the deblock waves and sleeping instead of spinning in their
+	// waits changed nothing either way.
+	const int C = run.cohorts;
+	e->cohorts = C;
+	// CEDAR_COHORT_STREAMS (development): bit 0 the deblocking, bit 1 the entropy chain of cohort c > 0 on a
+	// stream of its own. Off by default: measured at 32 x 1080p, both on 162.7 M MB/s against 168.9 M on the
+	// shared streams -- more queues holding resident kernels slow each other's launches.
+	const char *envs = getenv("CEDAR_COHORT_STREAMS"), *envr = getenv("CEDAR_BATCH_SELF_RESET");
+	const int cs = envs ? atoi(envs) : 0;
+	e->batch_self_reset = envr && atoi(envr) != 0;
+	if (C > 1 && cs) {
+		for (int c = 1; c < C; c++) {
+			if ((cs & 1) && c < DB_STREAMS)
+				e->s_db_c[c] = e->s_db[DB_STREAMS - c]; // (the session's spare deblock streams, from the far end: s_db[1] may carry every other IDR picture)
+			if (cs & 2)
+				HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent_c[c], hipStreamNonBlocking));
+		}
+		if (cs & 2)
+			for (int i = 0; i < e->depth * MAX_COHORTS; i++)
+				HIP_TRY(e, hipEventCreateWithFlags(&e->ev_entropy[i], hipEventDisableTiming));
+	}
 	return 0;
 }
 
@@ -599,152 +795,23 @@ static int setup_streams(cedar_enc *e, const struct cedar_enc_config *cfg, const
 		// analysis they wait for finds no CU to run on.
 		const int db_max = plan.db_streams_wanted;
 		bool want = plan.want_row_pipe != 0;
-		if (want && !e->holds_pipe_token) {
-			if (g_pipelined_sessions[e->device & 63].fetch_add(1) == 0) {
-				e->pipe_lock_fd = pipe_lock_acquire(e->device);
-				if (e->pipe_lock_fd == -1) // taken by a session of another process
-					g_pipelined_sessions[e->device & 63].fetch_sub(1);
-				else
-					e->holds_pipe_token = true;
-			} else {
-				g_pipelined_sessions[e->device & 63].fetch_sub(1);
-			}
-		}
+		if (want)
+			take_pipe_token(e);
 		want = want && e->holds_pipe_token;
 		int usable = 0;
-		for (int i = 0; want && i < DB_STREAMS && usable < db_max; i++) {
-			bool ok = false, ok2 = true;
-			if (Launch::probe_overlap(e->s_db[i], e->s_main, e->d_prog[0], &ok))
-				return fail(e, -EIO, "stream probe failed");
-			// ... and beside the entropy stream, or every frame's bitstream would queue behind a
-			// deblock kernel that is resident for a whole frame time
-			if (ok && (Launch::probe_overlap(e->s_db[i], e->s_ent, e->d_prog[0], &ok2) || !ok2))
-				ok = false;
-			ok2 = true;
-			for (int j = 0; ok && j < usable; j++) // and beside the deblock streams already accepted
-				if (Launch::probe_overlap(e->s_db[i], e->s_db[j], e->d_prog[0], &ok2) || !ok2)
-					ok = false;
-			if (ok) {
-				hipStream_t t = e->s_db[usable];
-				e->s_db[usable] = e->s_db[i];
-				e->s_db[i] = t;
-				usable++;
-			}
-		}
-		HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
-	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
+		if (int rc_p = probe_deblock_streams(e, want, db_max, &usable))
+			return rc_p;
 		const PlanRun run = plan_run(pin, plan, PlanProbe{ usable, e->holds_pipe_token ? 1 : 0 });
 		e->row_pipe = run.row_pipe != 0;
 		e->db_streams = run.db_streams;
-		// further analysis streams: each must run beside every deblock stream and every analysis
-		// stream already accepted (a frame's gate kernels spin while the next frame's run)
-		int an = 1;
-		const char *enva = getenv("CEDAR_ANALYSIS_STREAMS");
-		const int an_max = enva ? atoi(enva) : 1;
-		for (int i = 1; e->row_pipe && i < AN_STREAMS && an < an_max; i++) {
-			bool ok = true, o = false;
-			for (int j = 0; ok && j < e->db_streams; j++)
-				if (Launch::probe_overlap(e->s_ana[i], e->s_db[j], e->d_prog[0], &o) || !o)
-					ok = false;
-			for (int j = 0; ok && j < an; j++)
-				if (Launch::probe_overlap(e->s_ana[i], e->s_ana[j], e->d_prog[0], &o) || !o)
-					ok = false;
-			if (ok) {
-				hipStream_t t = e->s_ana[an];
-				e->s_ana[an] = e->s_ana[i];
-				e->s_ana[i] = t;
-				an++;
-			}
-		}
-		e->an_streams = an;
+		if (int rc_p = probe_analysis_streams(e))
+			return rc_p;
 		e->inter_bands = run.inter_bands;
 		e->defer_default = run.defer_default;
-		// Look-ahead for IDR pictures: two more streams -- the IDR picture's analysis (busy for
-		// milliseconds) and the input of all frames (which must never queue behind that, nor behind
-		// a gate on s_main) -- dealt by assign_stream_roles; each must run beside every stream in use.
-		// The IDR picture's deblocking: on a stream of its own, resident beside the intra wavefront it follows band by
-		// band (k_deblock_rows, GOPs of 20 pictures and more: 1080p keyint 25, K 300 47.0 -> 48.0 M MB/s, the driver's K 20
-		// 34.8 -> 38.3 M: its 0.3 ms no longer come after the intra kernel's 1.9 ms), or behind it on the same stream --
-		// k_deblock2_planes, whose whole-CU workgroups measured slower beside it (one more queue that blocks a pipe), and
-		// SHORT GOPs on either kernel: the stream that would carry it carries every other IDR picture instead (s_idr2),
-		// and a stream of short GOPs is bound by its IDR pictures (keyint 1 / 4 / 8 / 12: 7.2 / 25.1 / 44.5 / 46.2 M MB/s
-		// behind against 4.1 / 15.1 / 29.3 / 42.2 beside). CEDAR_IDR_DEBLOCK_INLINE.
-		const char *envl = getenv("CEDAR_LOOKAHEAD"), *envi = getenv("CEDAR_IDR_DEBLOCK_INLINE");
-		e->lookahead = false;
-		e->idr_deblock_inline = envi ? atoi(envi) != 0 : !e->db_rows || cfg->keyframe_interval < 20 || !plan.idr_beside_ok;
-		// (sessions whose frames run back to back take the IDR picture out of line too: nothing polls
-		// there, the P picture after it waits for its events, and with 4 frames in flight it gets a
-		// three-frame head start)
-		const char *envlb = getenv("CEDAR_LOOKAHEAD_BATCH");
-		if ((e->row_pipe ? e->depth > 4 : ((!envlb || atoi(envlb) != 0) && e->depth >= 3)) && (!envl || atoi(envl) != 0)) {
-			// streams not taken by the deblock / analysis roles, in the order assign_stream_roles meant
-			// them for: IDR analysis, input, then the spare one (second entropy lane)
-			std::vector<hipStream_t> used = { e->s_main, e->s_ent }, spare, got;
-			for (int i = 0; i < e->db_streams; i++)
-				used.push_back(e->s_db[i]);
-			for (int i = 1; i < e->an_streams; i++)
-				used.push_back(e->s_ana[i]);
-			for (int i = e->an_streams; i < AN_STREAMS; i++)
-				spare.push_back(e->s_ana[i]);
-			for (int i = e->db_streams; i < DB_STREAMS; i++)
-				spare.push_back(e->s_db[i]);
-			const size_t want = e->idr_deblock_inline ? 3 : 4;
-			for (size_t c = 0; c < spare.size() && got.size() < want; c++) {
-				bool ok = true, o = false;
-				for (size_t j = 0; ok && j < used.size(); j++)
-					if (Launch::probe_overlap(spare[c], used[j], e->d_prog[0], &o) || !o)
-						ok = false;
-				if (ok) {
-					got.push_back(spare[c]);
-					used.push_back(spare[c]);
-				}
-			}
-			HIP_TRY(e, hipMemset(e->d_prog[0], 0, 64));
-	HIP_TRY(e, hipStreamSynchronize(nullptr)); // (the null stream's clear before the probes' own streams touch the words)
-			if (got.size() >= (e->idr_deblock_inline ? 2u : 3u)) {
-				e->s_idr = got[0];
-				e->s_in = got[1];
-				size_t k = 2;
-				e->s_db_idr = e->idr_deblock_inline ? nullptr : got[k++];
-				const char *envl2 = getenv("CEDAR_ENTROPY_LANES");
-				e->s_ent2 = k < got.size() && e->ent_lanes > 1 && (!envl2 || atoi(envl2) > 1) ? got[k] : nullptr;
-				// the spare stream otherwise carries every other IDR picture: consecutive IDR pictures
-				// depend on nothing either, which doubles the rate of short GOPs (keyint 1: all of them)
-				e->s_idr2 = !e->s_ent2 && e->idr_deblock_inline && k < got.size() ? got[k] : nullptr;
-				e->lookahead = true;
-			}
-		}
-		{
-			// cohorts (submit_frame): two from 32 units on. With whole-CU deblock workgroups the deblocking
-			// of one cohort never ran beside the search of the other (16 waves of 128 registers find no
-			// empty CU while k_inter's small workgroups keep refilling them: 32 x 1080p 2.29 ms per step
-			// against 2.20 ms with one cohort; CU masks 2.96 ms; stream priority no change). With the
-			// 2-pair workgroups it does: 32 x 1080p 1.87 -> 1.73 ms (139 -> 151 M MB/s), 64: 3.58 -> 3.18 ms
-			// (146 -> 164 M). Not below: the deblock wavefront of a picture takes its ~0.45 ms however few
-			// pictures there are, and half of 16 streams' search is shorter than that (16: 120 -> 92 M).
-			// Three or four cohorts lose everywhere (more, smaller launches on the same four hardware queues).
-			// Wave priority (s_setprio) for the deblock waves and sleeping instead of spinning in their
-			// waits changed nothing either way.
-			const int C = run.cohorts;
-			e->cohorts = C;
-			// CEDAR_COHORT_STREAMS (development): bit 0 the deblocking, bit 1 the entropy chain of cohort c > 0 on a
-			// stream of its own. Off by default: measured at 32 x 1080p, both on 162.7 M MB/s against 168.9 M on the
-			// shared streams -- more queues holding resident kernels slow each other's launches.
-			const char *envs = getenv("CEDAR_COHORT_STREAMS"), *envr = getenv("CEDAR_BATCH_SELF_RESET");
-			const int cs = envs ? atoi(envs) : 0;
-			e->batch_self_reset = envr && atoi(envr) != 0;
-			if (C > 1 && cs) {
-				for (int c = 1; c < C; c++) {
-					if ((cs & 1) && c < DB_STREAMS)
-						e->s_db_c[c] = e->s_db[DB_STREAMS - c]; // (the session's spare deblock streams, from the far end: s_db[1] may carry every other IDR picture)
-					if (cs & 2)
-						HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent_c[c], hipStreamNonBlocking));
-				}
-				if (cs & 2)
-					for (int i = 0; i < e->depth * MAX_COHORTS; i++)
-						HIP_TRY(e, hipEventCreateWithFlags(&e->ev_entropy[i], hipEventDisableTiming));
-			}
-		}
+		if (int rc_p = setup_lookahead(e, cfg, plan))
+			return rc_p;
+		if (int rc_p = setup_cohorts(e, run))
+			return rc_p;
 		if (getenv("CEDAR_TRACE_SUBMIT"))
 			fprintf(stderr, "config: row_pipe %d, deblock streams %d, analysis streams %d, stripes %d, look-ahead %d, depth %d, cohorts %d\n",
 				(int)e->row_pipe, e->db_streams, e->an_streams, e->inter_bands, (int)e->lookahead, e->depth, e->cohorts);
@@ -839,6 +906,116 @@ static int setup_stripes(cedar_enc *e)
 	return 0;
 }
 
+// the events of every device slot: input there, analysis complete, reconstruction deblocked (per cohort), the stage timers
+static int create_events(cedar_enc *e)
+{
+	for (int i = 0; i < e->depth; i++) {
+		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
+		for (int c = 0; c < e->cohorts; c++) {
+			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input[i * MAX_COHORTS + c], hipEventDisableTiming));
+			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis[i * MAX_COHORTS + c], hipEventDisableTiming));
+			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_deblocked[i * MAX_COHORTS + c], hipEventDisableTiming));
+		}
+		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_ent, hipEventDisableTiming));
+		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
+			for (int k = 0; k < 2; k++)
+				HIP_TRY(e, hipEventCreate(&e->fl[i].tm.ev[s][k]));
+	}
+	return 0;
+}
+
+// everything of Params that is a device pointer or a choice of the plan: what submit_frame copies and then points at the
+// frame's own slot
+static void static_pointers(cedar_enc *e, int n_units, int mb_w)
+{
+	Params &P = e->P;
+	const int S = e->ext.n_streams;
+	P.in_luma = (const uint8_t *const *)e->d_in_ptrs;
+	P.in_chroma = (const uint8_t *const *)(e->d_in_ptrs + S);
+	P.src_y = e->d_src_y[0];
+	P.src_uv = e->d_src_uv[0];
+	P.slot = e->d_slot[0];
+	P.mb_bits = e->d_mb_bits[0];
+	P.skip = e->d_skip[0];
+	P.mvd = nullptr;
+	P.bit_off = e->d_bit_off[0];
+	P.run_before = e->d_run[0];
+	P.src_direct = 0;
+	P.src_last_y = P.ch - 1;
+	P.src_last_c = P.ch / 2 - 1;
+	P.ent_rec = e->d_ent_rec[0];
+	P.pk_first = e->d_pk_first[0];
+	P.pk_agg = e->d_pk_agg[0];
+	P.pk_unit = e->d_pk_unit[0];
+	P.unit_bits = e->d_unit_bits[0];
+	P.rbsp = e->d_rbsp[0];
+	P.esc_cnt = e->d_esc[0];
+	P.nal_off = e->d_nal_off[0];
+	P.nal_size = e->d_nal_size[0];
+	P.stream_size = e->d_stream_size[0];
+	P.out = e->d_out[0];
+	P.hdr = nullptr; // per frame: the frame's own pinned header words
+	P.prefix_len = nullptr;
+	P.pred4_tab = e->d_pred4;
+	P.abort_all = e->d_abort_all;
+	P.dbg_log = e->d_dbg_log;
+	P.wf_sync = e->d_wf_sync[0];
+	P.wf_hbuf = e->d_wf_hbuf[0];
+	P.db_hbuf = e->d_db_hbuf[0];
+	P.db_tag = 0;
+	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES;
+	P.prog_inter = nullptr;
+	P.prog_db = nullptr;
+	P.prog_intra = nullptr;
+	P.prog_intra_c = nullptr;
+	P.prev_db = nullptr;
+	P.stripe_s0 = 0;
+	P.stripe_s1 = 0;
+	P.prog_tag = P.prev_tag = 0;
+	P.wf_split = e->wf_split;
+	P.db_pairs = e->db_pairs;
+	P.wf_hb_slots = e->hb_slots;
+	P.db_rows = e->db_rows ? 1 : 0;
+	P.db_lds_kb = getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb; // (see launch_deblock_rows)
+	P.db_bands = e->db_bands;
+	P.wf_split_intra = e->wf_split_intra;
+	P.ir_rows = e->ir_rows ? 1 : 0;
+	P.ir_bands = e->db_bands;
+	P.ir_lds_kb = getenv("CEDAR_INTRA_LDS_KB") ? std::max(0, atoi(getenv("CEDAR_INTRA_LDS_KB"))) : e->ir_lds_kb; // (see launch_intra_rows)
+	P.ir_hbuf = e->d_ir_hbuf[0];
+	{
+		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO
+		P.fault_inject = env ? atoi(env) : 0;
+		env = getenv("CEDAR_FAULT_INJECT_AT"); // ... of the n-th submit only (1-based; default: of every frame)
+		e->fault_at = env ? (uint32_t)atoi(env) : 0;
+	}
+}
+
+// gop_parallel: the rings between the caller's frame order and the lock-step lanes (GopMux)
+static int setup_gop_lanes(cedar_enc *e, const struct cedar_enc_config *cfg, int G, int S_user)
+{
+	const struct cedar_enc_config_ext &ext = e->ext;
+	GopMux *m = new (std::nothrow) GopMux();
+	if (!m)
+		return fail(e, -ENOMEM, "out of memory");
+	e->mux = m;
+	m->G = G;
+	m->K = cfg->keyframe_interval;
+	m->S = S_user;
+	// frames the caller may have in flight: (G-1) K is the least (frame n needs frame n + (G-1) K in),
+	// + the session's ring; with `ahead` another (G-1) K + 8, so that the IDR step of the NEXT group of
+	// GOPs has its input while this group's last steps still run and hides beside them (the session's
+	// IDR look-ahead; measured below) -- at the price of twice the latency
+	m->ahead = !ext.gop_low_latency;
+	m->user_depth = (G - 1) * m->K + e->depth + (m->ahead ? (G - 1) * m->K + 8 : 0);
+	m->cap = m->user_depth + m->K + 1;
+	m->in_ring.assign((size_t)m->cap * 2 * S_user, nullptr);
+	m->out_ring.resize((size_t)m->cap * S_user);
+	m->out_rc.assign((size_t)m->cap, INT32_MIN);
+	m->user_in.assign((size_t)2 * S_user, nullptr);
+	return 0;
+}
+
 int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_enc_config_ext *ext_in)
 {
 	struct cedar_enc_config_ext ext{};
@@ -923,80 +1100,11 @@ int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_e
 		return rc;
 	if ((rc = setup_stripes(e)))
 		return rc;
-	for (int i = 0; i < e->depth; i++) {
-		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_main, hipEventDisableTiming));
-		for (int c = 0; c < e->cohorts; c++) {
-			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_input[i * MAX_COHORTS + c], hipEventDisableTiming));
-			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_analysis[i * MAX_COHORTS + c], hipEventDisableTiming));
-			HIP_TRY(e, hipEventCreateWithFlags(&e->ev_deblocked[i * MAX_COHORTS + c], hipEventDisableTiming));
-		}
-		HIP_TRY(e, hipEventCreateWithFlags(&e->fl[i].done_ent, hipEventDisableTiming));
-		for (int s = 0; s < CEDAR_ENC_STAGE_COUNT; s++)
-			for (int k = 0; k < 2; k++)
-				HIP_TRY(e, hipEventCreate(&e->fl[i].tm.ev[s][k]));
-	}
+	if ((rc = create_events(e)))
+		return rc;
 	HIP_TRY(e, hipDeviceSynchronize());
 
-	// static device pointers
-	P.in_luma = (const uint8_t *const *)e->d_in_ptrs;
-	P.in_chroma = (const uint8_t *const *)(e->d_in_ptrs + S);
-	P.src_y = e->d_src_y[0];
-	P.src_uv = e->d_src_uv[0];
-	P.slot = e->d_slot[0];
-	P.mb_bits = e->d_mb_bits[0];
-	P.skip = e->d_skip[0];
-	P.mvd = nullptr;
-	P.bit_off = e->d_bit_off[0];
-	P.run_before = e->d_run[0];
-	P.src_direct = 0;
-	P.src_last_y = P.ch - 1;
-	P.src_last_c = P.ch / 2 - 1;
-	P.ent_rec = e->d_ent_rec[0];
-	P.pk_first = e->d_pk_first[0];
-	P.pk_agg = e->d_pk_agg[0];
-	P.pk_unit = e->d_pk_unit[0];
-	P.unit_bits = e->d_unit_bits[0];
-	P.rbsp = e->d_rbsp[0];
-	P.esc_cnt = e->d_esc[0];
-	P.nal_off = e->d_nal_off[0];
-	P.nal_size = e->d_nal_size[0];
-	P.stream_size = e->d_stream_size[0];
-	P.out = e->d_out[0];
-	P.hdr = nullptr; // per frame: the frame's own pinned header words
-	P.prefix_len = nullptr;
-	P.pred4_tab = e->d_pred4;
-	P.abort_all = e->d_abort_all;
-	P.dbg_log = e->d_dbg_log;
-	P.wf_sync = e->d_wf_sync[0];
-	P.wf_hbuf = e->d_wf_hbuf[0];
-	P.db_hbuf = e->d_db_hbuf[0];
-	P.db_tag = 0;
-	P.wf_hbuf_intra = e->d_wf_hbuf[0] + (size_t)n_units * e->hb_slots * mb_w * WF_HBUF_GRANULES;
-	P.prog_inter = nullptr;
-	P.prog_db = nullptr;
-	P.prog_intra = nullptr;
-	P.prog_intra_c = nullptr;
-	P.prev_db = nullptr;
-	P.stripe_s0 = 0;
-	P.stripe_s1 = 0;
-	P.prog_tag = P.prev_tag = 0;
-	P.wf_split = e->wf_split;
-	P.db_pairs = e->db_pairs;
-	P.wf_hb_slots = e->hb_slots;
-	P.db_rows = e->db_rows ? 1 : 0;
-	P.db_lds_kb = getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb; // (see launch_deblock_rows)
-	P.db_bands = e->db_bands;
-	P.wf_split_intra = e->wf_split_intra;
-	P.ir_rows = e->ir_rows ? 1 : 0;
-	P.ir_bands = e->db_bands;
-	P.ir_lds_kb = getenv("CEDAR_INTRA_LDS_KB") ? std::max(0, atoi(getenv("CEDAR_INTRA_LDS_KB"))) : e->ir_lds_kb; // (see launch_intra_rows)
-	P.ir_hbuf = e->d_ir_hbuf[0];
-	{
-		const char *env = getenv("CEDAR_FAULT_INJECT"); // tests: lose a hand-off, see that the grid drains and collect says -EIO
-		P.fault_inject = env ? atoi(env) : 0;
-		env = getenv("CEDAR_FAULT_INJECT_AT"); // ... of the n-th submit only (1-based; default: of every frame)
-		e->fault_at = env ? (uint32_t)atoi(env) : 0;
-	}
+	static_pointers(e, n_units, mb_w);
 
 	e->rc_target = ext.bitrate > 0 ? (int64_t)ext.bitrate * (ext.fps_num > 0 ? ext.fps_den : 1) / (ext.fps_num > 0 ? ext.fps_num : 30) : 0;
 	build_sps_pps(e);
@@ -1006,26 +1114,8 @@ int config_impl(cedar_enc *e, struct cedar_enc_config *cfg, const struct cedar_e
 	e->res_size.assign(S, 0);
 	e->lane_gidx.assign(S, 0);
 	e->S_user = S_user;
-	if (G > 1) {
-		GopMux *m = new (std::nothrow) GopMux();
-		if (!m)
-			return fail(e, -ENOMEM, "out of memory");
-		e->mux = m;
-		m->G = G;
-		m->K = cfg->keyframe_interval;
-		m->S = S_user;
-		// frames the caller may have in flight: (G-1) K is the least (frame n needs frame n + (G-1) K in),
-		// + the session's ring; with `ahead` another (G-1) K + 8, so that the IDR step of the NEXT group of
-		// GOPs has its input while this group's last steps still run and hides beside them (the session's
-		// IDR look-ahead; measured below) -- at the price of twice the latency
-		m->ahead = !ext.gop_low_latency;
-		m->user_depth = (G - 1) * m->K + e->depth + (m->ahead ? (G - 1) * m->K + 8 : 0);
-		m->cap = m->user_depth + m->K + 1;
-		m->in_ring.assign((size_t)m->cap * 2 * S_user, nullptr);
-		m->out_ring.resize((size_t)m->cap * S_user);
-		m->out_rc.assign((size_t)m->cap, INT32_MIN);
-		m->user_in.assign((size_t)2 * S_user, nullptr);
-	}
+	if (G > 1 && (rc = setup_gop_lanes(e, cfg, G, S_user)))
+		return rc;
 	e->configured = true;
 
 	// outputs (cedar.c:840-860), host pointers instead of DMA addresses

@@ -1,5 +1,5 @@
 // cedarx_h264_encoder_amd/csrc/enc_internal.h
-// Shared between the host session code (enc_session.cpp) and the gfx950
+// Shared between the host session code (enc_session.h and the four .cpp files behind it) and the gfx950
 // kernels (enc_kernels.hip). Not part of the C-ABI (include/cedar_h264enc.h).
 #pragma once
 

@@ -2,7 +2,7 @@
 // The schedule policy of a session as PURE functions of its geometry, the device's CU count, what the stream
 // probes found and the CEDAR_* development switches: how many frames in flight, how the two wavefront kernels
 // are split over workgroups, which deblock form, whether frames are pipelined on the device, how many stripes
-// and how many of them are held back, how many cohorts. No HIP, no session state: enc_session.cpp calls them
+// and how many of them are held back, how many cohorts. No HIP, no session state: enc_config.cpp calls them
 // from CONFIG, and tests/test_plan.py holds every threshold through cedar_enc_plan() on a box without a GPU
 // (the 4K deadlock of round 2 -- more bands than wave pairs -- lived in exactly this code).
 // Every number here was measured on MI355X; DESIGN.md 5.1-5.5 says with what.
@@ -27,7 +27,7 @@ struct PlanIn {
 	int mb_qp = 0;          // the session's macroblocks differ in QP (regions of interest, MAD classes, rate control over several streams)
 };
 constexpr int PLAN_UNSET = PLAN_UNSET_INIT;
-constexpr int CEDAR_PLAN_MAX_DEPTH = 16; // = CEDAR_ENC_PIPELINE_DEPTH of the public header (asserted in enc_session.cpp)
+constexpr int CEDAR_PLAN_MAX_DEPTH = 16; // = CEDAR_ENC_PIPELINE_DEPTH of the public header (asserted in enc_config.cpp)
 
 struct Plan {
 	int error;              // 0, or 1: a slice too tall for the deblock wavefront
@@ -151,7 +151,7 @@ inline Plan plan_static(const PlanIn &in)
 	p.split_planes = set(in.env_deblock_planes) ? in.env_deblock_planes != 0 : n_units < 32;
 
 	// One stream, one slice: the last stripes of a P picture are held back and go out between the first ones of the
-	// next (DeferredTail in enc_session.cpp), which wants a third deblock stream. 1080p, M MB/s: 5 stripes / 2
+	// next (DeferredTail in enc_session.h), which wants a third deblock stream. 1080p, M MB/s: 5 stripes / 2
 	// streams 36.0; 8 stripes none held, 3 streams 36.4; 8 stripes 3 held, 2 streams 37.6; 8 stripes 3 held, 3 streams
 	// 42.1-43.6. CEDAR_DEFER=0 switches it off.
 	// Which deblock kernel. k_deblock_rows gives every band of 4 rows a workgroup of 7 waves and every macroblock row a

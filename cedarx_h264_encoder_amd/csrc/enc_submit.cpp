@@ -866,6 +866,102 @@ static void dump_hang_state(cedar_enc *e, const InFlight &f, uint32_t wf_err)
 	}
 }
 
+// "wait for the IRQ" (cedar.c:1178-1180). False: the device reported an error.
+static bool wait_frame(InFlight &f)
+{
+	bool hip_failed = false;
+	// poll the frame's own completion flags (see InFlight::h_done); fall back to the events
+	// if they do not show up (they are written after everything the events cover)
+	const double t_poll = now_ms();
+	unsigned spins = 0;
+	while (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
+		if ((++spins & 63) == 0) {
+			if (now_ms() - t_poll > 2000.0)
+				break;
+			sched_yield();
+		}
+	}
+	if (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
+		// (pipelined frames record no events: their streams are kept to the fewest packets)
+		hipError_t r1 = f.events ? hipEventSynchronize(f.done_ent) : hipStreamSynchronize(f.s_ent);
+		hipError_t r2 = f.events ? hipEventSynchronize(f.done_main) : hipStreamSynchronize(f.s_db);
+		hip_failed = r1 != hipSuccess || r2 != hipSuccess;
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	return !hip_failed;
+}
+
+// where every stream's access unit lies in the frame's host buffer, with the AUD / SPS / PPS bytes the host writes in front
+static void place_outputs(cedar_enc *e, const InFlight &f, int slot)
+{
+	const int S = e->ext.n_streams, C = e->cohorts;
+	for (int c = 0; c < C; c++) {
+		const int s0 = S * c / C, s1 = S * (c + 1) / C;
+		const uint32_t *sz = e->h_sizes[slot] + (size_t)c * (S + 2);
+		uint32_t off = (uint32_t)((size_t)s0 * (C > 1 ? e->stream_out_cap : 0));
+		for (int s = s0; s < s1; s++) {
+			e->res_off[s] = off;
+			e->res_size[s] = sz[s - s0];
+			e->pk_seen[f.idr ? 1 : 0] = std::max(e->pk_seen[f.idr ? 1 : 0], (int)(sz[s - s0] / PK_CHUNK) + 1);
+			uint8_t *front = e->h_out[f.host_out] + off;
+			if (f.aud) {
+				const std::vector<uint8_t> &a = e->aud_nal[f.aud - 1];
+				memcpy(front, a.data(), a.size());
+				front += a.size();
+			}
+			if (f.with_ps[s])
+				memcpy(front, e->sps_pps.data(), e->sps_pps.size());
+			off += sz[s - s0];
+		}
+	}
+}
+
+// what the rate law and the stage timers keep of a frame that worked
+static void account_frame(cedar_enc *e, InFlight &f, uint32_t total)
+{
+	const int S = e->ext.n_streams;
+	e->rc_bits[f.before.frame_count & 63] = (int64_t)total * 8;
+	e->rc_qp[f.before.frame_count & 63] = f.qp;
+	if (e->rc_lanes) { // (a lock-step step = one frame of every lane of its group)
+		const long m = f.before.frame_count / e->cfg.keyframe_interval;
+		if (e->grp_id1[m & 31] != m + 1) {
+			e->grp_id1[m & 31] = m + 1;
+			e->grp_sum[m & 31] = 0;
+			e->grp_n[m & 31] = 0;
+		}
+		for (int s = 0; s < S; s++)
+			if (f.lane_gidx[s] >= 0) { // (idle lanes of the last group code a frame nobody reads)
+				e->grp_sum[m & 31] += ((int64_t)e->res_size[s] * 8 * rc_pow2_6_q16(f.qp - e->cfg.qp)) >> 16;
+				e->grp_n[m & 31]++;
+			}
+	}
+	if (e->rc_multi)
+		for (int s = 0; s < S; s++) {
+			e->rc_bits_s[(size_t)s * 64 + (f.before.frame_count & 63)] = (int64_t)e->res_size[s] * 8;
+			e->rc_qp_s[(size_t)s * 64 + (f.before.frame_count & 63)] = f.h_qp_s[s];
+		}
+	e->stats.frame_qp = f.qp;
+	if (e->profiling) {
+		static const char *const stage_name[CEDAR_ENC_STAGE_COUNT] = { "input", "intra_decide", "intra_recon", "inter", "deblock", "entropy" };
+		const bool timeline = e->ev_base && getenv("CEDAR_TRACE_TIMELINE");
+		for (int st = 0; st < CEDAR_ENC_STAGE_COUNT; st++)
+			if (f.tm.used[st]) {
+				float ms = 0;
+				// (a pipelined frame's done flags are raised from inside its last kernels: the
+				// marker behind such a kernel may be a few microseconds away still)
+				hipEventSynchronize(f.tm.ev[st][1]);
+				if (hipEventElapsedTime(&ms, f.tm.ev[st][0], f.tm.ev[st][1]) == hipSuccess) {
+					e->stats.ms[st] += ms;
+					e->stats.launches[st]++;
+				}
+				float a = 0, b = 0; // when the stage ran on the device, relative to the session's base event
+				if (timeline && hipEventElapsedTime(&a, e->ev_base, f.tm.ev[st][0]) == hipSuccess &&
+				    hipEventElapsedTime(&b, e->ev_base, f.tm.ev[st][1]) == hipSuccess)
+					fprintf(stderr, "timeline frame %llu %s %.3f %.3f\n", (unsigned long long)e->stats.frames, stage_name[st], a, b);
+			}
+	}
+}
+
 int collect_frame(cedar_enc *e)
 {
 	if (e->fl_count == 0)
@@ -880,27 +976,7 @@ int collect_frame(cedar_enc *e)
 		if (rc_f)
 			return rc_f;
 	}
-	bool hip_failed = false;
-	{
-		// poll the frame's own completion flags (see InFlight::h_done); fall back to the events
-		// if they do not show up (they are written after everything the events cover)
-		const double t_poll = now_ms();
-		unsigned spins = 0;
-		while (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
-			if ((++spins & 63) == 0) {
-				if (now_ms() - t_poll > 2000.0)
-					break;
-				sched_yield();
-			}
-		}
-		if (f.h_done[0] != f.done_tag || f.h_done[1] != f.done_tag) {
-			// (pipelined frames record no events: their streams are kept to the fewest packets)
-			hipError_t r1 = f.events ? hipEventSynchronize(f.done_ent) : hipStreamSynchronize(f.s_ent);
-			hipError_t r2 = f.events ? hipEventSynchronize(f.done_main) : hipStreamSynchronize(f.s_db);
-			hip_failed = r1 != hipSuccess || r2 != hipSuccess;
-		}
-		std::atomic_thread_fence(std::memory_order_acquire);
-	}
+	const bool hip_failed = !wait_frame(f);
 	e->fl_head = (e->fl_head + 1) % e->depth;
 	e->fl_count--;
 	f.active = false;
@@ -964,67 +1040,10 @@ int collect_frame(cedar_enc *e)
 			return fail(e, -EOVERFLOW, "a macroblock exceeds 3200 bits (H.264 A.3.1): raise the QP");
 		return fail(e, -ENOSPC, "bytestream buffer too small (flags %u, %u bytes)", flags, total);
 	}
-	for (int c = 0; c < C; c++) {
-		const int s0 = S * c / C, s1 = S * (c + 1) / C;
-		const uint32_t *sz = e->h_sizes[slot] + (size_t)c * (S + 2);
-		uint32_t off = (uint32_t)((size_t)s0 * (C > 1 ? e->stream_out_cap : 0));
-		for (int s = s0; s < s1; s++) {
-			e->res_off[s] = off;
-			e->res_size[s] = sz[s - s0];
-			e->pk_seen[f.idr ? 1 : 0] = std::max(e->pk_seen[f.idr ? 1 : 0], (int)(sz[s - s0] / PK_CHUNK) + 1);
-			uint8_t *front = e->h_out[f.host_out] + off;
-			if (f.aud) {
-				const std::vector<uint8_t> &a = e->aud_nal[f.aud - 1];
-				memcpy(front, a.data(), a.size());
-				front += a.size();
-			}
-			if (f.with_ps[s])
-				memcpy(front, e->sps_pps.data(), e->sps_pps.size());
-			off += sz[s - s0];
-		}
-	}
+	place_outputs(e, f, slot);
 	e->res_host = f.host_out;
 	e->last_total = total;
-	e->rc_bits[f.before.frame_count & 63] = (int64_t)total * 8;
-	e->rc_qp[f.before.frame_count & 63] = f.qp;
-	if (e->rc_lanes) { // (a lock-step step = one frame of every lane of its group)
-		const long m = f.before.frame_count / e->cfg.keyframe_interval;
-		if (e->grp_id1[m & 31] != m + 1) {
-			e->grp_id1[m & 31] = m + 1;
-			e->grp_sum[m & 31] = 0;
-			e->grp_n[m & 31] = 0;
-		}
-		for (int s = 0; s < S; s++)
-			if (f.lane_gidx[s] >= 0) { // (idle lanes of the last group code a frame nobody reads)
-				e->grp_sum[m & 31] += ((int64_t)e->res_size[s] * 8 * rc_pow2_6_q16(f.qp - e->cfg.qp)) >> 16;
-				e->grp_n[m & 31]++;
-			}
-	}
-	if (e->rc_multi)
-		for (int s = 0; s < S; s++) {
-			e->rc_bits_s[(size_t)s * 64 + (f.before.frame_count & 63)] = (int64_t)e->res_size[s] * 8;
-			e->rc_qp_s[(size_t)s * 64 + (f.before.frame_count & 63)] = f.h_qp_s[s];
-		}
-	e->stats.frame_qp = f.qp;
-	if (e->profiling) {
-		static const char *const stage_name[CEDAR_ENC_STAGE_COUNT] = { "input", "intra_decide", "intra_recon", "inter", "deblock", "entropy" };
-		const bool timeline = e->ev_base && getenv("CEDAR_TRACE_TIMELINE");
-		for (int st = 0; st < CEDAR_ENC_STAGE_COUNT; st++)
-			if (f.tm.used[st]) {
-				float ms = 0;
-				// (a pipelined frame's done flags are raised from inside its last kernels: the
-				// marker behind such a kernel may be a few microseconds away still)
-				hipEventSynchronize(f.tm.ev[st][1]);
-				if (hipEventElapsedTime(&ms, f.tm.ev[st][0], f.tm.ev[st][1]) == hipSuccess) {
-					e->stats.ms[st] += ms;
-					e->stats.launches[st]++;
-				}
-				float a = 0, b = 0; // when the stage ran on the device, relative to the session's base event
-				if (timeline && hipEventElapsedTime(&a, e->ev_base, f.tm.ev[st][0]) == hipSuccess &&
-				    hipEventElapsedTime(&b, e->ev_base, f.tm.ev[st][1]) == hipSuccess)
-					fprintf(stderr, "timeline frame %llu %s %.3f %.3f\n", (unsigned long long)e->stats.frames, stage_name[st], a, b);
-			}
-	}
+	account_frame(e, f, total);
 	e->stats.frames++;
 	e->stats.encode_wall_ms += now_ms() - t0;
 	return (int)total; // cedar.c:1207-1208: bytes now valid at bytestream offset 0

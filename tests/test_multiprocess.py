@@ -116,7 +116,7 @@ import pytest  # noqa: E402
 def test_two_processes_on_one_gpu_only_one_pipelines(tmp_path):
     """A pipelined session's deblock workgroups are resident and poll; enc_plan.h budgets them against the CUs of the
     device, which only holds if no OTHER process does the same on that device. The session that pipelines holds the
-    device's lock file (enc_session.cpp, pipe_lock_acquire); the second process finds it taken and runs its frames back
+    device's lock file (enc_config.cpp, pipe_lock_acquire); the second process finds it taken and runs its frames back
     to back. Both emit the golden bytes of configs[2] (tests/golden/indep_fullsize.json), side by side on one GPU."""
     import json
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "indep_fullsize.json")))["cases"][1]
