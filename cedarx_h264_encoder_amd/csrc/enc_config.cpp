@@ -161,8 +161,12 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 	int best[NROLE] = { 0, 1, 2, 3, 5, 6, 4 }, cur[NROLE];
 	double best_cost = 1e30;
 	bool taken[NP] = {};
+	// (CEDAR_STREAM_PRIO=1, setup_streams: roles in classes, the analysis on pool[0])
+	static const int cls_of_stream[7] = { 1, 1, -1, -1, -1, 0, 0 };
+	static const int cls_of_role[NROLE] = { 1, 1, -1, -1, 0, 0, -1 }; // MAIN ENT DB0 DB1 IDR IN DB2
 	struct Rec { // depth-first over the 7! assignments
 		const double *blocked_frac, *launches;
+		bool classes;
 		void go(int r, int *cur, bool *taken, double cost, const double (*slow)[7], int *best, double &best_cost) const
 		{
 			if (cost >= best_cost)
@@ -174,7 +178,7 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 				return;
 			}
 			for (int sidx = 0; sidx < 7; sidx++) {
-				if (taken[sidx])
+				if (taken[sidx] || (classes && (cls_of_role[r] != cls_of_stream[sidx] || (r == 0) != (sidx == 0))))
 					continue;
 				double add = 0;
 				for (int q = 0; q < r; q++)
@@ -186,7 +190,7 @@ int assign_stream_roles(cedar_enc *e, int db_streams_wanted)
 			}
 		}
 	};
-	Rec{ blocked_frac, launches }.go(0, cur, taken, 0.0, slow, best, best_cost);
+	Rec{ blocked_frac, launches, e->main_prio }.go(0, cur, taken, 0.0, slow, best, best_cost);
 	const int spare = best[DB2];
 	e->s_main = pool[best[MAIN]];
 	e->s_ana[0] = e->s_main;
@@ -766,7 +770,25 @@ static int setup_streams(cedar_enc *e, const struct cedar_enc_config *cfg, const
 	Params &P = e->P;
 	(void)P;
 	(void)cfg;
-	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+	// CEDAR_STREAM_PRIO=1: the first stream of the pool at the greatest stream priority. For callers whose process keeps its
+	// NULL stream busy (PyTorch's default stream): with 7 streams and the null stream on 8 hardware queues, the stream the
+	// roles give the analysis -- the one without a pipe-mate among the session's seven (assign_stream_roles) -- has the null
+	// stream's queue for its mate, and a null stream that holds a running kernel with a packet behind it costs every launch
+	// of the analysis stream ~20 us: one 1080p stream 60 -> 19 M MB/s with spinning kernels queued there, 59.8 M with this
+	// switch (tools/dev/null_blocked.py, profiles/r04_null_stream.txt). The roles are then dealt in classes -- analysis and
+	// entropy on the first two streams of the pool (the analysis on the one with the priority, which its own mate no longer
+	// slows), the deblock roles on the next three, IDR and input on the last two: the null stream's mate, the fourth stream
+	// in creation order, gets a deblock role, one or two launches a frame. Off by default: a queue of another priority in
+	// the process moved other sessions of the same process (854x480 17.5 -> 15 M; 32 streams with it themselves 196 -> 169).
+	{
+		const char *envp = getenv("CEDAR_STREAM_PRIO");
+		int pr_least = 0, pr_greatest = 0;
+		e->main_prio = envp && atoi(envp) != 0 && hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) == hipSuccess && pr_least != pr_greatest;
+		if (e->main_prio)
+			HIP_TRY(e, hipStreamCreateWithPriority(&e->s_main, hipStreamNonBlocking, pr_greatest));
+		else
+			HIP_TRY(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+	}
 	e->s_ana[0] = e->s_main;
 	HIP_TRY(e, hipStreamCreateWithFlags(&e->s_ent, hipStreamNonBlocking));
 	for (int i = 0; i < DB_STREAMS; i++)

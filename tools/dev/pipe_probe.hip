@@ -17,9 +17,19 @@ int main(int argc, char **argv)
 {
 	const int n = argc > 1 ? atoi(argv[1]) : 8;
 	const int behind = argc > 2 ? atoi(argv[2]) : 1;
+	const int prio = argc > 3 ? atoi(argv[3]) : 0; // bit 0: the chain's stream at the highest priority; bit 1: the others at the lowest
+	int lo = 0, hi = 0;
+	hipDeviceGetStreamPriorityRange(&lo, &hi); // (lo = least, hi = greatest: numerically lower is higher)
+	printf("stream priorities: least %d, greatest %d; chain stream %s, the others %s\n", lo, hi, prio & 1 ? "greatest" : "default", prio & 2 ? "least" : "default");
 	std::vector<hipStream_t> st(n);
-	for (auto &s : st)
-		hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+	for (int i = 0; i < n; i++) {
+		if (i == 0 && (prio & 1))
+			hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi);
+		else if (i > 0 && (prio & 2))
+			hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, lo);
+		else
+			hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+	}
 	unsigned *d;
 	hipMalloc(&d, 4096);
 	hipMemset(d, 0, 4096);
