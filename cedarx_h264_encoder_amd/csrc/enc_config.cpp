@@ -841,6 +841,18 @@ static int setup_streams(cedar_enc *e, const struct cedar_enc_config *cfg, const
 	return 0;
 }
 
+// Steps of k_deblock_rows between two progress words of a band. Every word costs its writer wave a release fence (an L2
+// write-back beside a busy chip), every step of delay costs the gates of the next picture's stripes: measured at the end of
+// round 4 (tools/dev/r04_single_sweep{6,7}.txt, tools/dev/pub_check.sh; K 300, M MB/s) 2 / 4 / 8 / 16 / 32 steps: 49.3 / 56.8 /
+// 59-60 / 60.8-61.2 / 60.1-60.3 for one 1080p stream, 16 against 8: 3840x2160 91-93 against 83-86, in four slices 93 against
+// 88-90, two 1080p streams 85 against 83.3. CEDAR_DB_PUB_STEP (development).
+static int db_pub_step()
+{
+	const char *envp = getenv("CEDAR_DB_PUB_STEP");
+	const int st = envp ? atoi(envp) : 16;
+	return st == 2 || st == 4 || st == 8 || st == 32 ? st : 16;
+}
+
 // The diagonal stripes of a pipelined P picture's analysis and how many of them are held back (DeferredTail).
 static int setup_stripes(cedar_enc *e)
 {
@@ -902,11 +914,11 @@ static int setup_stripes(cedar_enc *e)
 			// diagonal stripe_s[j + 1] + 4, in every band that has such diagonals) on what is published of the
 			// previous picture's analysis when that gate runs: its stripes up to kd + j - 1 are in front of the gate,
 			// but the end of a stripe is published by the gate of the NEXT one, so diagonal stripe_s[kd + j - 1] it is.
-			// How far ahead of the asked diagonal the analysis must be: the progress words move every 8 steps (+8), a
+			// How far ahead of the asked diagonal the analysis must be: the progress words move every db_pub_step() steps, a
 			// stager waits for the analysis of 5 steps ahead (+5), and -- k_deblock_rows -- every band is on the SAME
 			// diagonal as the band above (one macroblock behind its last row, like the rows of a band). (k_deblock2_planes,
 			// bands inside one workgroup, every band a diagonal behind: the margin it has always run with.)
-			const int slack = e->db_rows ? 4 + 8 + 5 + 3 : bands_max + 14;
+			const int slack = e->db_rows ? 4 + db_pub_step() + 5 + 3 : bands_max + 14;
 			for (int j = 0; j < kd && kd < nb; j++)
 				if (e->stripe_s[j + 1] + slack > e->stripe_s[std::min(nb, kd + j - (e->db_rows ? 1 : 0))])
 					kd = nb;
@@ -998,6 +1010,7 @@ static void static_pointers(cedar_enc *e, int n_units, int mb_w)
 	P.db_pairs = e->db_pairs;
 	P.wf_hb_slots = e->hb_slots;
 	P.db_rows = e->db_rows ? 1 : 0;
+	P.db_pub_mask = db_pub_step() - 1;
 	P.db_lds_kb = getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb; // (see launch_deblock_rows)
 	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;

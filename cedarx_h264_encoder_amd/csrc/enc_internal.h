@@ -165,6 +165,7 @@ struct Params {
 	int32_t wf_hb_slots;             // workgroup boundaries per unit the hand-off buffers have room for
 	int32_t db_rows;                 // 1: deblocking with a wave per macroblock row (k_deblock_rows), a workgroup per band of 4 rows ...
 	int32_t db_lds_kb;               // ... KiB of LDS each claims: what its tiles take, or enough that no second band shares its CU
+	int32_t db_pub_mask;             // ... a band publishes its progress every (mask + 1) steps (enc_config.cpp: db_pub_step)
 	int32_t db_bands;                // ... and plane, this many per unit (the bands of the session's tallest slice)
 	uint64_t *db_hbuf;               // [n_units][db_bands][mb_w][DBR_HB_GRANULES] k_deblock_rows: bottom rows of a band for the band below,
 	uint32_t db_tag;                 // ... every 8-byte granule = 4 bytes of samples | this frame's tag << 32 (never 0; the buffer starts zeroed)

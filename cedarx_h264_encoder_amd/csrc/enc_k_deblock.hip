@@ -466,7 +466,7 @@ DEVI void deblock_rows_body(const Params &p)
 			// row 3 is through macroblock t - 3 and through the vertical edges of it: macroblock t - 4 is final
 			if (feeds_next && t >= 4)
 				push(t - 4);
-			if ((t & 7) == 0 && t >= 8) // steps < t have been written back: x + y < t + y0b
+			if ((t & p.db_pub_mask) == 0 && t > p.db_pub_mask) // steps < t have been written back: x + y < t + y0b
 				publish_diag((uint32_t)(t + y0b));
 			const int mx = t - g;
 			const bool act = row_ok && mx >= 0 && mx < p.mb_w;
