@@ -906,7 +906,11 @@ static int setup_stripes(cedar_enc *e)
 			// kernels that wait for work only the NEXT submit enqueues; a device-wide synchronisation by anybody in
 			// the process in between would wait for them, so the session's flush thread enqueues the tail itself
 			// CEDAR_DEFER_FLUSH_US (100) after the submit unless the next submit has come (Flusher).
-			const int want = envd ? atoi(envd) : e->defer_default;
+			// tail_gate (a stripe's launch ends when the next stripe's gate would have passed): only with the stripes of a picture
+			// one behind the other on the stream -- a held-back stripe of the picture before, enqueued between two of them, would
+			// sit behind the very wait it is needed for. CEDAR_TAIL_GATE=0: a k_gate in front of every stripe, as until round 4.
+			e->tail_gate = e->row_pipe && e->cohorts == 1 && !(getenv("CEDAR_TAIL_GATE") && atoi(getenv("CEDAR_TAIL_GATE")) == 0);
+			const int want = e->tail_gate ? 0 : envd ? atoi(envd) : e->defer_default;
 			int kd = nb;
 			if (e->row_pipe && e->cohorts == 1 && !e->mux && want > 0 && want < nb && nb >= 3 && one_front)
 				kd = nb - want;
@@ -1011,6 +1015,8 @@ static void static_pointers(cedar_enc *e, int n_units, int mb_w)
 	P.wf_hb_slots = e->hb_slots;
 	P.db_rows = e->db_rows ? 1 : 0;
 	P.db_pub_mask = db_pub_step() - 1;
+	P.gate_publish = -1;
+	P.gate_next_need = 0;
 	P.db_lds_kb = getenv("CEDAR_DEBLOCK_LDS_KB") ? std::max(1, atoi(getenv("CEDAR_DEBLOCK_LDS_KB"))) : e->db_lds_kb; // (see launch_deblock_rows)
 	P.db_bands = e->db_bands;
 	P.wf_split_intra = e->wf_split_intra;

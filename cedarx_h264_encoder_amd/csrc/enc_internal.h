@@ -189,6 +189,10 @@ struct Params {
 	uint32_t prog_tag, prev_tag;
 	int32_t stripe_s0, stripe_s1;    // k_inter: this launch covers s0 <= x + y < s1 (stripe_s1 <= 0: the whole picture)
 	const uint32_t *stripe_tab;      // [row_num + 1] macroblocks of the stripe in the rows before row r (per stream)
+	// A stripe's launch doing the gate work of the NEXT stripe (cedar_enc::tail_gate): its first wave publishes that the
+	// stripe before it is complete (gate_publish >= 0) and, its own macroblock done, waits for what the next stripe's gate
+	// would have waited for (gate_next_need > 0) -- the launch ends no earlier than that gate would have passed
+	int32_t gate_publish, gate_next_need;
 	uint8_t *dummy_rec;              // 16 + 8 rows of cw bytes: where the idle waves of k_inter's last workgroup write
 	int64_t dummy_mb;                // ... and the macroblock record they fill: one past the session's last stream
 	uint32_t *wf_err;                // pinned host word of this frame: a hand-off that timed out leaves a non-zero code

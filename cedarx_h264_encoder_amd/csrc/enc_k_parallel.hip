@@ -276,6 +276,45 @@ DEVI QpSet qp_set(const Params &p, int qp_mb)
 
 // MBQP: macroblocks differ in QP (regions of interest, MAD classes) -- a kernel of its own, like the
 // sub-sample refinement and the refresh branch, so that the plain one keeps its registers
+// What k_gate (below) waits for, as one wave of another kernel: every deblock band of the previous picture that owns diagonals
+// below need_d has written them back. No acquire here: the caller reads nothing after it -- the next launch on the stream
+// starts behind it with the acquire of a kernel's start.
+DEVI void wait_prev_deblock(const Params &p, int lane, int need_d)
+{
+	if (need_d <= 0 || !p.prev_db)
+		return;
+	const int n_units = p.n_streams * p.slice_num;
+	const int n = 2 * n_units * PROG_BANDS;
+	for (int e0 = 0; e0 < n; e0 += 64) {
+		const int e = e0 + lane;
+		bool pending = false;
+		if (e < n) {
+			const int band = e % PROG_BANDS, unit = (e / PROG_BANDS) % n_units;
+			int r0, r1;
+			slice_rows(p.mb_h, p.slice_count, p.slice_first + unit % p.slice_num, &r0, &r1);
+			pending = band < ((r1 - r0 + 3) >> 2) && r0 + 4 * band < need_d;
+		}
+		uint32_t spins = 0;
+		uint64_t t0 = 0;
+		while (true) {
+			if (pending) {
+				const uint32_t v = __hip_atomic_load(&p.prev_db[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				pending = (int32_t)(v - (p.prev_tag | (uint32_t)need_d)) < 0;
+			}
+			if (!__any(pending))
+				break;
+			if (wait_expired(++spins, t0) || ((spins & 63u) == 0 && __hip_atomic_load(p.abort_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+				if (lane == 0) {
+					__hip_atomic_store(p.wf_err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(p.abort_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				return;
+			}
+			__builtin_amdgcn_s_sleep(32);
+		}
+	}
+}
+
 template <int SUBPEL, bool REFRESH, bool MBQP>
 __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 {
@@ -290,6 +329,9 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform, and the compiler knows
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 		dbg_event(p, 9, p.db_tag, (uint32_t)p.stripe_s0);
+	// (tail_gate: the launches before this one have completed -- stream order --, the stripe before this one among them)
+	if (blockIdx.x == 0 && threadIdx.x == 0 && p.gate_publish >= 0 && p.prog_inter)
+		__hip_atomic_store(p.prog_inter, p.prog_tag | (uint32_t)p.gate_publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	uint8_t *const arena = sa_arena[wave];
 	uint8_t *const s_ref = arena + IA_REF, *const s_cur = arena + IA_CUR, *const s_curc = arena + IA_CURC;
 	uint8_t *const s_s8 = arena + IA_U;                              // search only
@@ -949,6 +991,10 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 		m.mvy = (int16_t)qy;
 		p.mbi[mbaddr] = m;
 	}
+	// tail_gate: one wave holds the launch open until the NEXT stripe may start (what k_gate in front of that stripe would
+	// have waited for, without its launch): a launch ends when its last wave does
+	if (p.gate_next_need > 0 && blockIdx.x == 0 && wave == 0)
+		wait_prev_deblock(p, lane, p.gate_next_need);
 }
 
 // ------------------------------------------------------------------------

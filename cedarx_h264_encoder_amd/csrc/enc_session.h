@@ -228,6 +228,7 @@ struct cedar_enc {
 	uint32_t *d_bit_off[ENT_LANES] = {}, *d_run[ENT_LANES] = {}, *d_unit_bits[ENT_LANES] = {};
 	bool last_src_direct = false; // ... and the last frame was
 	bool main_prio = false;      // CEDAR_STREAM_PRIO=1: the analysis stream at the greatest stream priority, roles in classes (setup_streams)
+	bool tail_gate = false;      // a stripe's launch waits at its end for the next stripe's gate (emit_stripes; CEDAR_TAIL_GATE)
 	bool db_first = false;        // frames back to back: the deblock kernel is enqueued before the entropy chain (CEDAR_DB_FIRST)
 	bool src_direct_ok = false;  // the width is a multiple of 16: frames may be read where the caller put them (CEDAR_SRC_DIRECT=0: always through k_input)
 	// k_pack_out's workgroups per unit: twice what the session's pictures of the kind (IDR, P) have needed so far -- a guess by

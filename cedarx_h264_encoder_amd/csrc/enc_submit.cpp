@@ -105,10 +105,18 @@ static int emit_stripes(cedar_enc *e, Params &Pc, hipStream_t s_ana, int k0, int
 		Pc.stripe_s0 = e->stripe_s[k];
 		Pc.stripe_s1 = e->stripe_s[k + 1];
 		Pc.stripe_tab = e->d_stripe_tab + (size_t)k * (Pc.row_num + 1);
-		if (Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 4))
+		// tail_gate: the stripe before this one has waited for this one's gate (one of its waves, k_inter), and this launch's
+		// first wave publishes that stripe's end: no k_gate in between. Only between two stripes that both have macroblocks.
+		const bool gated_by_prev = e->tail_gate && k > 0 && e->stripe_n[k] > 0 && e->stripe_n[k - 1] > 0;
+		const bool gates_next = e->tail_gate && k + 1 < e->inter_bands && e->stripe_n[k] > 0 && e->stripe_n[k + 1] > 0;
+		if (!gated_by_prev && Launch::gate(Pc, s_ana, k > 0 ? Pc.stripe_s0 : -1, Pc.stripe_s1 + 4))
 			return fail(e, -EIO, "k_gate launch failed");
+		Pc.gate_publish = gated_by_prev ? Pc.stripe_s0 : -1;
+		Pc.gate_next_need = gates_next ? e->stripe_s[k + 2] + 4 : 0;
 		if (e->stripe_n[k] > 0 && Launch::inter(Pc, s_ana, e->stripe_n[k] * S))
 			return fail(e, -EIO, "k_inter launch failed");
+		Pc.gate_publish = -1;
+		Pc.gate_next_need = 0;
 	}
 	return 0;
 }

@@ -719,11 +719,12 @@ def test_two_sessions_interleaved_pipelined(ce):
     {"CEDAR_WF_SPLIT": "8", "CEDAR_WF_SPLIT_INTRA": "8", "CEDAR_ROW_PIPE": "0"},
     {"CEDAR_ENTROPY_FUSED": "0", "CEDAR_INTRA_ROWS": "0"},   # round 3's back end (k_zero .. k_esc_write, k_copy_out) and intra wavefront
     {"CEDAR_STREAM_PRIO": "1"},                               # the analysis stream at the greatest priority, roles dealt in classes
+    {"CEDAR_TAIL_GATE": "0"},                                 # a k_gate in front of every stripe and the held-back tail, as until round 4
 ])
 def test_1080p_wavefront_shapes_match_oracle(ce, monkeypatch, env):
     """The wavefront kernels' work split (workgroups per unit, bands per workgroup, planes per wave
     pair) is a launch-shape choice: every shape must give the oracle's bytes."""
-    for k in ("CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DEBLOCK_PLANES", "CEDAR_ROW_PIPE", "CEDAR_ENTROPY_FUSED", "CEDAR_INTRA_ROWS", "CEDAR_STREAM_PRIO"):
+    for k in ("CEDAR_WF_SPLIT", "CEDAR_WF_SPLIT_INTRA", "CEDAR_DEBLOCK_PLANES", "CEDAR_ROW_PIPE", "CEDAR_ENTROPY_FUSED", "CEDAR_INTRA_ROWS", "CEDAR_STREAM_PRIO", "CEDAR_TAIL_GATE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

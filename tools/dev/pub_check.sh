@@ -2,9 +2,9 @@
 # Runs ON THE GPU BOX (through gpurun): the whole default bench and two 1080p streams with a band's progress word every 8 and
 # every 16 steps of k_deblock_rows (CEDAR_DB_PUB_STEP). Development only.
 cd $GRAFT_REPO_ROOT
-for P in 8 16 8 16; do
-  echo "== CEDAR_DB_PUB_STEP=$P"
-  ( export CEDAR_DB_PUB_STEP=$P
+for P in ${VALS:-8 16 8 16}; do
+  echo "== ${VAR:-CEDAR_DB_PUB_STEP}=$P"
+  ( export ${VAR:-CEDAR_DB_PUB_STEP}=$P
     timeout -k 10 300 python3 bench.py --cpu-frames 0 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.readline())
