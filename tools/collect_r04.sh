@@ -36,6 +36,17 @@ pmc() { # name, counter, bench args
   rm -rf $OUT/pmc_${name}_$ctr
   echo "pmc $name $ctr done"
 }
+if [ -n "$LEGS" ]; then # (only the kernel-trace legs named, e.g. LEGS="w1 p1")
+  for l in $LEGS; do
+    case $l in
+      w1) leg w1 CEDAR_ROW_PIPE=0 --steps 50 --warmup 25;;
+      p1) leg p1 "" --steps 100 --warmup 25;;
+      s8) leg s8 "" --streams 8 --steps 50 --warmup 25;;
+      s32) leg s32 "" --streams 32 --steps 50 --warmup 25;;
+    esac || exit 1
+  done
+  echo collected $TAG; exit 0
+fi
 leg w1 CEDAR_ROW_PIPE=0 --steps 50 --warmup 25 &&
 leg p1 "" --steps 100 --warmup 25 &&
 leg s8 "" --streams 8 --steps 50 --warmup 25 &&
