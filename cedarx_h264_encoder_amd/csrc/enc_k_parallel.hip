@@ -993,8 +993,13 @@ __global__ __launch_bounds__(64 * INTER_WAVES) void k_inter(Params p)
 	}
 	// tail_gate: one wave holds the launch open until the NEXT stripe may start (what k_gate in front of that stripe would
 	// have waited for, without its launch): a launch ends when its last wave does
-	if (p.gate_next_need > 0 && blockIdx.x == 0 && wave == 0)
+	if (p.gate_next_need > 0 && blockIdx.x == 0 && wave == 0) {
+		if (lane == 0)
+			dbg_event(p, 10, p.db_tag, (uint32_t)p.gate_next_need);
 		wait_prev_deblock(p, lane, p.gate_next_need);
+		if (lane == 0)
+			dbg_event(p, 11, p.db_tag, (uint32_t)p.gate_next_need);
+	}
 }
 
 // ------------------------------------------------------------------------

@@ -390,6 +390,8 @@ extern "C" void cedar_enc_close(cedar_enc *e)
 		}
 		flusher_stop(e);
 		hipDeviceSynchronize();
+		if (getenv("CEDAR_DEBUG_LOG_DUMP"))
+			dump_event_log(e);
 	}
 	pipe_token_release(e->device, e->holds_pipe_token, e->pipe_lock_fd);
 	free_all(e);

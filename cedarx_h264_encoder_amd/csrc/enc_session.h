@@ -398,5 +398,6 @@ int collect_frame(cedar_enc *e);
 int flush_deferred(cedar_enc *e);
 void flusher_main(cedar_enc *e);
 void flusher_stop(cedar_enc *e);
+void dump_event_log(cedar_enc *e);
 
 } // namespace cedar

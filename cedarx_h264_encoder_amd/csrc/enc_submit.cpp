@@ -825,6 +825,33 @@ static int recover(cedar_enc *e, const InFlight &failed, const ReplayIn *again =
 
 // Development (CEDAR_DEBUG_HANG): what the progress and ticket words, and the device's own event log, say when a hand-off of
 // frame f timed out.
+// CEDAR_DEBUG_HANG: the device's own account of what its kernels did -- code, frame tag, argument, microseconds since the first
+// entry -- printed when a hand-off times out, or when the session closes if CEDAR_DEBUG_LOG_DUMP is set (tools/dev/loop_timeline.py).
+void dump_event_log(cedar_enc *e)
+{
+	if (e->d_dbg_log) { // the device's own account: code, frame tag, argument, microseconds since the first entry
+		std::vector<uint32_t> lg((size_t)4 + 4 * DBG_LOG_ENTRIES);
+		if (hipMemcpy(lg.data(), e->d_dbg_log, lg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+			const size_t n = std::min<size_t>(lg[0], DBG_LOG_ENTRIES);
+			std::vector<std::array<uint64_t, 3>> ev;
+			for (size_t i = 0; i < n; i++)
+				ev.push_back({ (uint64_t)lg[4 + 4 * i + 2] | (uint64_t)lg[4 + 4 * i + 3] << 32, lg[4 + 4 * i], lg[4 + 4 * i + 1] });
+			std::sort(ev.begin(), ev.end());
+			static const char *const names[12] = { "?", "input", "intra_decide", "intra_rows start", "intra_rows end", "deblock start", "deblock end", "gate start",
+							       "gate end", "inter", "inter tail wait", "inter tail wait over" };
+			fprintf(stderr, " device log, %zu entries (us since the first | event | frame tag | argument):\n", n);
+			for (size_t i = 0; i < n; i++) {
+				const uint32_t code = (uint32_t)ev[i][1] & 0xff, tag = (uint32_t)ev[i][1] >> 8, arg = (uint32_t)ev[i][2];
+				if (code == 3 || code == 4 || code == 5 || code == 6) {
+					if ((arg & 0xff) != 0 && (arg & 0xff) != (uint32_t)e->db_bands - 1 && (arg & 0xff) != (uint32_t)e->db_bands / 2)
+						continue; // (first, middle and last band of a picture say enough)
+				}
+				fprintf(stderr, "  %10.1f %-16s tag %3u arg %08x\n", (double)(ev[i][0] - ev[0][0]) / 100.0, names[code < 12 ? code : 0], tag, arg);
+			}
+		}
+	}
+}
+
 static void dump_hang_state(cedar_enc *e, const InFlight &f, uint32_t wf_err)
 {
 	const int S = e->ext.n_streams;
@@ -837,27 +864,7 @@ static void dump_hang_state(cedar_enc *e, const InFlight &f, uint32_t wf_err)
 	if (hipMemcpy(ab, e->d_abort_all, sizeof(ab), hipMemcpyDeviceToHost) == hipSuccess)
 		fprintf(stderr, " first wait that ran out: band %u planes %u idr %u unit %u | need %u saw %08x %08x %08x at step %u, tag %08x | %dx%d mb, db_bands %d\n", (ab[1] - 1) & 0xff, (ab[1] >> 8) & 15,
 			(ab[1] >> 12) & 1, ab[1] >> 16, ab[2], ab[3], ab[4], ab[5], ab[6], ab[7], e->P.mb_w, e->P.mb_h, e->db_bands);
-	if (e->d_dbg_log) { // the device's own account: code, frame tag, argument, microseconds since the first entry
-		std::vector<uint32_t> lg((size_t)4 + 4 * DBG_LOG_ENTRIES);
-		if (hipMemcpy(lg.data(), e->d_dbg_log, lg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
-			const size_t n = std::min<size_t>(lg[0], DBG_LOG_ENTRIES);
-			std::vector<std::array<uint64_t, 3>> ev;
-			for (size_t i = 0; i < n; i++)
-				ev.push_back({ (uint64_t)lg[4 + 4 * i + 2] | (uint64_t)lg[4 + 4 * i + 3] << 32, lg[4 + 4 * i], lg[4 + 4 * i + 1] });
-			std::sort(ev.begin(), ev.end());
-			static const char *const names[12] = { "?", "input", "intra_decide", "intra_rows start", "intra_rows end", "deblock start", "deblock end", "gate start",
-							       "gate end", "inter", "?", "?" };
-			fprintf(stderr, " device log, %zu entries (us since the first | event | frame tag | argument):\n", n);
-			for (size_t i = 0; i < n; i++) {
-				const uint32_t code = (uint32_t)ev[i][1] & 0xff, tag = (uint32_t)ev[i][1] >> 8, arg = (uint32_t)ev[i][2];
-				if (code == 3 || code == 4 || code == 5 || code == 6) {
-					if ((arg & 0xff) != 0 && (arg & 0xff) != (uint32_t)e->db_bands - 1 && (arg & 0xff) != (uint32_t)e->db_bands / 2)
-						continue; // (first, middle and last band of a picture say enough)
-				}
-				fprintf(stderr, "  %10.1f %-16s tag %3u arg %08x\n", (double)(ev[i][0] - ev[0][0]) / 100.0, names[code < 12 ? code : 0], tag, arg);
-			}
-		}
-	}
+	dump_event_log(e);
 	for (int k = 0; k < e->depth; k++) {
 		if (hipMemcpy(w.data(), e->d_prog[k], w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sy.data(), e->d_wf_sync[k], sy.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
 			break;
