@@ -137,3 +137,19 @@ def test_ctypes_mirrors_have_the_layout_of_the_c_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(ct), cname
         for f in ct._fields_:
             assert int(got["%s.%s" % (cname, f[0])]) == getattr(ct, f[0]).offset, (cname, f[0])
+
+
+def test_every_environment_switch_the_library_reads_is_documented():
+    """INTEGRATION.md lists the CEDAR_* switches; the library must not read one it does not name, nor the document name one
+    that nothing reads."""
+    import glob
+    doc = set(re.findall(r"CEDAR_[A-Z0-9_]+", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "cedarx_h264_encoder_amd", "csrc", "*")):
+        if f.endswith((".cpp", ".hip", ".h", ".c")):
+            src += open(f).read()
+    read = set(re.findall(r'getenv\("(CEDAR_[A-Z0-9_]+)"\)', src))
+    assert not sorted(read - doc), "read but not documented"
+    everywhere = set(re.findall(r"CEDAR_[A-Z0-9_]+", src + open(os.path.join(ROOT, "include", "cedar_h264enc.h")).read() +
+                                open(os.path.join(ROOT, "bench.py")).read() + open(os.path.join(ROOT, "cedarx_h264_encoder_amd", "encoder.py")).read()))
+    assert not sorted(doc - everywhere), "documented but unknown to the sources"
